@@ -1,0 +1,155 @@
+"""ORACLE (test infrastructure only -- never imported by the product path).
+
+CPU fp32 restatement, in plain torch functional ops, of the reference model
+graphs on the hot path.  It consumes a state_dict with the reference's key names
+ and is pinned against outputs of the reference itself
+(tests/golden/*.npz, produced by tools/gen_golden.py which imports
+/root/reference on CPU).
+
+Follows:
+  DBNet:  pytocr/modeling/backbones/det_resnet.py:66-82, 282-309 (BasicBlock, stem, layers)
+          pytocr/modeling/necks/fpn.py:102-134 (FPN forward, nearest upsample-add, concat p5,p4,p3,p2)
+          pytocr/modeling/heads/det_db_head.py:9-17,47-50 (binarize branch, eval early return)
+  CRNN:   pytocr/modeling/backbones/rec_vgg.py:29-36,78-91 (v1 layout, asymmetric pools)
+          pytocr/modeling/necks/rnn.py:9-15,29-36,38-48 (Im2Seq, BiLSTM + Linear, BiLSTM)
+          pytocr/modeling/heads/rec_ctc_head.py:17-36 (Linear + softmax(dim=2) in eval)
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _t(sd, k):
+    v = sd[k]
+    return v if isinstance(v, torch.Tensor) else torch.from_numpy(v)
+
+
+def _bn(sd, p, x, eps=1e-5):
+    return F.batch_norm(x, _t(sd, p + ".running_mean"), _t(sd, p + ".running_var"),
+                        _t(sd, p + ".weight"), _t(sd, p + ".bias"), False, 0.0, eps)
+
+
+def _basic_block(sd, p, x, stride):
+    out = F.conv2d(x, _t(sd, p + ".conv1.weight"), None, stride, 1)
+    out = F.relu(_bn(sd, p + ".bn1", out))
+    out = F.conv2d(out, _t(sd, p + ".conv2.weight"), None, 1, 1)
+    out = _bn(sd, p + ".bn2", out)
+    if (p + ".downsample.0.weight") in sd:
+        idt = F.conv2d(x, _t(sd, p + ".downsample.0.weight"), None, stride, 0)
+        idt = _bn(sd, p + ".downsample.1", idt)
+    else:
+        idt = x
+    return F.relu(out + idt)
+
+
+def resnet18_forward(sd, x, prefix="backbone."):
+    x = F.conv2d(x, _t(sd, prefix + "conv1.weight"), None, 2, 3)
+    x = F.relu(_bn(sd, prefix + "bn1", x))
+    x = F.max_pool2d(x, 3, 2, 1)
+    outs = []
+    for li, stride in ((1, 1), (2, 2), (3, 2), (4, 2)):
+        x = _basic_block(sd, f"{prefix}layer{li}.0", x, stride)
+        x = _basic_block(sd, f"{prefix}layer{li}.1", x, 1)
+        outs.append(x)
+    return outs
+
+
+def _cbr(sd, p, x, pad):
+    x = F.conv2d(x, _t(sd, p + ".0.weight"), None, 1, pad)
+    return F.relu(_bn(sd, p + ".1", x))
+
+
+def fpn_db_forward(sd, feats, prefix="neck."):
+    c2, c3, c4, c5 = feats
+    in5 = _cbr(sd, prefix + "in5", c5, 0)
+    in4 = _cbr(sd, prefix + "in4", c4, 0)
+    in3 = _cbr(sd, prefix + "in3", c3, 0)
+    in2 = _cbr(sd, prefix + "in2", c2, 0)
+    up = lambda a: F.interpolate(a, scale_factor=2, mode="nearest")
+    out4 = up(in5) + in4
+    out3 = up(out4) + in3
+    out2 = up(out3) + in2
+    p5 = _cbr(sd, prefix + "out5", in5, 1)
+    p4 = _cbr(sd, prefix + "out4", out4, 1)
+    p3 = _cbr(sd, prefix + "out3", out3, 1)
+    p2 = _cbr(sd, prefix + "out2", out2, 1)
+    p5 = F.interpolate(p5, scale_factor=8, mode="nearest")
+    p4 = F.interpolate(p4, scale_factor=4, mode="nearest")
+    p3 = F.interpolate(p3, scale_factor=2, mode="nearest")
+    return torch.cat((p5, p4, p3, p2), dim=1)
+
+
+def db_head_forward(sd, x, prefix="head.binarize."):
+    x = F.relu(_bn(sd, prefix + "1", F.conv2d(x, _t(sd, prefix + "0.weight"), None, 1, 1)))
+    x = F.conv_transpose2d(x, _t(sd, prefix + "3.weight"), _t(sd, prefix + "3.bias"), 2)
+    x = F.relu(_bn(sd, prefix + "4", x))
+    x = F.conv_transpose2d(x, _t(sd, prefix + "6.weight"), _t(sd, prefix + "6.bias"), 2)
+    return torch.sigmoid(x)
+
+
+def dbnet_r18_forward(sd, x, return_feats=False):
+    """x: f32[N,3,H,W] (H,W multiples of 32) -> {"maps": f32[N,1,H,W]}."""
+    with torch.no_grad():
+        feats = resnet18_forward(sd, x)
+        fuse = fpn_db_forward(sd, feats)
+        maps = db_head_forward(sd, fuse)
+    if return_feats:
+        return {"maps": maps, "backbone_out": feats, "neck_out": fuse}
+    return {"maps": maps}
+
+
+# --------------------------------------------------------------------------- CRNN
+def vgg_v1_forward(sd, x, prefix="backbone.cnn."):
+    def conv(i, x, pad):
+        return F.conv2d(x, _t(sd, f"{prefix}conv{i}.weight"), _t(sd, f"{prefix}conv{i}.bias"), 1, pad)
+    x = F.relu(conv(0, x, 1)); x = F.max_pool2d(x, 2, 2)
+    x = F.relu(conv(1, x, 1)); x = F.max_pool2d(x, 2, 2)
+    x = F.relu(_bn(sd, prefix + "batchnorm2", conv(2, x, 1)))
+    x = F.relu(conv(3, x, 1)); x = F.max_pool2d(x, (2, 2), (2, 1), (0, 1))
+    x = F.relu(_bn(sd, prefix + "batchnorm4", conv(4, x, 1)))
+    x = F.relu(conv(5, x, 1)); x = F.max_pool2d(x, (2, 2), (2, 1), (0, 1))
+    x = F.relu(_bn(sd, prefix + "batchnorm6", conv(6, x, 0)))
+    return x
+
+
+def _lstm_dir(x, w_ih, w_hh, b_ih, b_hh, reverse):
+    """x: [T,B,I]; torch gate order i,f,g,o; zero initial state."""
+    T, B, _ = x.shape
+    H = w_hh.shape[1]
+    h = x.new_zeros(B, H); c = x.new_zeros(B, H)
+    out = x.new_zeros(T, B, H)
+    steps = range(T - 1, -1, -1) if reverse else range(T)
+    for t in steps:
+        g = x[t] @ w_ih.t() + b_ih + h @ w_hh.t() + b_hh
+        i, f, gg, o = g.chunk(4, dim=1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        out[t] = h
+    return out
+
+
+def bilstm_forward(sd, p, x):
+    fw = _lstm_dir(x, _t(sd, p + ".rnn.weight_ih_l0"), _t(sd, p + ".rnn.weight_hh_l0"),
+                   _t(sd, p + ".rnn.bias_ih_l0"), _t(sd, p + ".rnn.bias_hh_l0"), False)
+    bw = _lstm_dir(x, _t(sd, p + ".rnn.weight_ih_l0_reverse"), _t(sd, p + ".rnn.weight_hh_l0_reverse"),
+                   _t(sd, p + ".rnn.bias_ih_l0_reverse"), _t(sd, p + ".rnn.bias_hh_l0_reverse"), True)
+    out = torch.cat((fw, bw), dim=2)
+    if (p + ".embedding.weight") in sd:
+        T, B, Hh = out.shape
+        out = F.linear(out.reshape(T * B, Hh), _t(sd, p + ".embedding.weight"), _t(sd, p + ".embedding.bias"))
+        out = out.reshape(T, B, -1)
+    return out
+
+
+def crnn_forward(sd, x, return_logits=False):
+    """x: f32[B,1,32,W] -> softmax f32[T,B,C] (reference rec_ctc_head.py:32-36)."""
+    with torch.no_grad():
+        f = vgg_v1_forward(sd, x)
+        assert f.shape[2] == 1
+        seq = f.squeeze(2).permute(2, 0, 1).contiguous()
+        seq = bilstm_forward(sd, "neck.encoder.rnn.0", seq)
+        seq = bilstm_forward(sd, "neck.encoder.rnn.1", seq)
+        T, B, Hh = seq.shape
+        logits = F.linear(seq.reshape(T * B, Hh), _t(sd, "head.fc.weight"), _t(sd, "head.fc.bias")).reshape(T, B, -1)
+        if return_logits:
+            return logits
+        return F.softmax(logits, dim=2)

@@ -1,0 +1,129 @@
+"""Portable synthetic weights / inputs (no torch RNG, no files).
+
+BASELINE.json asks for synthetic data of the reference's shapes; the GPU box has
+no checkpoints and no reference tree, so every weight tensor and every input is
+regenerated from a counter-based generator (splitmix64) that gives the same
+float32 bits on any host.  The golden fixtures under tests/golden/ were produced
+by feeding exactly these tensors to the reference model (tools/gen_golden.py).
+
+State-dict key contract: SURVEY.md Appendix A (reference
+pytocr/utils/save_load.py:81-101 loads with strict=True).
+"""
+import zlib
+
+import numpy as np
+
+_G = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+
+def splitmix64(idx, seed):
+    """idx: array of uint64 counters; returns uint64 hash per counter."""
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + (idx.astype(np.uint64) + np.uint64(1)) * _G
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def uniform01(n, seed):
+    """n float32 values in [0,1) with 24 random bits each."""
+    z = splitmix64(np.arange(n, dtype=np.uint64), seed)
+    return ((z >> np.uint64(40)).astype(np.float32)) * np.float32(1.0 / (1 << 24))
+
+
+def uniform(shape, seed, lo, hi):
+    n = int(np.prod(shape)) if len(shape) else 1
+    u = uniform01(n, seed)
+    return (np.float32(lo) + u * np.float32(hi - lo)).astype(np.float32).reshape(shape)
+
+
+def key_seed(key, seed):
+    return (zlib.crc32(key.encode("utf-8")) * 2654435761 + seed * 97) & 0xFFFFFFFFFFFF
+
+
+def _fan_in(shape, transposed):
+    if len(shape) == 4:
+        rf = shape[2] * shape[3]
+        return (shape[0] if transposed else shape[1]) * rf
+    if len(shape) == 2:
+        return shape[1]
+    return 1
+
+
+def synth_state_dict(ref_shapes, seed=2022):
+    """ref_shapes: ordered {key: (shape tuple, dtype str)} -> {key: np.ndarray}.
+
+    Rules (by key suffix) keep activations O(1) through the net so that the 1e-4
+    probability-map tolerance is a real test, not a saturated sigmoid:
+      conv / linear weights        : U(-a, a), a = sqrt(3 / fan_in)   (var = 1/fan_in);
+                                     CRNN VGG convs and LSTM weight_ih use sqrt(6 / fan_in),
+                                     weight_hh 1/sqrt(H), head.fc 12x, embedding 2x (logit spread)
+      *.bias (conv/linear/lstm)    : U(-0.1, 0.1)
+      BN weight U(0.6, 1.4); BN bias U(-0.2, 0.2); running_mean U(-0.2, 0.2);
+      running_var U(0.5, 1.5); num_batches_tracked = 0
+    """
+    out = {}
+    bn_prefixes = {k[: -len(".running_var")] for k in ref_shapes if k.endswith(".running_var")}
+    for key, (shape, dtype) in ref_shapes.items():
+        s = key_seed(key, seed)
+        prefix = key.rsplit(".", 1)[0]
+        if key.endswith("num_batches_tracked"):
+            out[key] = np.zeros(shape, dtype=np.int64)
+        elif prefix in bn_prefixes:
+            if key.endswith(".weight"):
+                out[key] = uniform(shape, s, 0.6, 1.4)
+            elif key.endswith(".running_var"):
+                out[key] = uniform(shape, s, 0.5, 1.5)
+            else:  # bias, running_mean
+                out[key] = uniform(shape, s, -0.2, 0.2)
+        elif "bias" in key.rsplit(".", 1)[-1]:
+            out[key] = uniform(shape, s, -0.1, 0.1)
+            if key == "head.fc.bias":                  # make the CTC blank (index 0) win often
+                out[key][0] = np.float32(13.0)
+        else:
+            transposed = (".binarize.3." in key or ".binarize.6." in key
+                          or ".thresh.3." in key or ".thresh.6." in key)
+            fan = max(_fan_in(shape, transposed), 1)
+            if "weight_hh" in key:
+                a = 1.0 / np.sqrt(shape[1])
+            elif "weight_ih" in key:
+                a = np.sqrt(6.0 / fan)
+            elif key.startswith("backbone.cnn."):      # CRNN VGG stack (plain conv+ReLU chain)
+                a = np.sqrt(6.0 / fan)
+            elif key == "head.fc.weight":              # CTC logits with a real spread
+                a = 12.0 * np.sqrt(3.0 / fan)
+            elif ".embedding." in key:
+                a = 2.0 * np.sqrt(3.0 / fan)
+            else:
+                a = np.sqrt(3.0 / fan)
+            out[key] = uniform(shape, s, -a, a)
+    return out
+
+
+def synth_images(n, c, h, w, seed=2022):
+    """Normalised float32 NCHW images: u8 uniform -> /255 -> ImageNet mean/std
+    (reference pytocr/data/imaug/operators.py:41-112) for c==3; (x/255-0.5)/0.5
+    for c==1 (reference pytocr/data/imaug/rec_img_aug.py:108-134)."""
+    u8 = (uniform01(n * c * h * w, seed ^ 0x5EED) * np.float32(256.0)).astype(np.uint8)
+    x = u8.astype(np.float32).reshape(n, c, h, w) / np.float32(255.0)
+    if c == 3:
+        mean = np.array([0.485, 0.456, 0.406], np.float32).reshape(1, 3, 1, 1)
+        std = np.array([0.229, 0.224, 0.225], np.float32).reshape(1, 3, 1, 1)
+        return ((x - mean) / std).astype(np.float32)
+    return ((x - np.float32(0.5)) / np.float32(0.5)).astype(np.float32)
+
+
+def synth_text_lines(n, h, w, seed=2022):
+    """Gray text-line-like crops f32[n,1,h,w]: 8-px column bands with their own level plus
+    noise, so the CRNN output varies along T (uniform noise gives a constant argmax).
+    Normalised as reference pytocr/data/imaug/rec_img_aug.py:108-134: (x/255 - 0.5)/0.5."""
+    nb = (w + 7) // 8
+    base = uniform01(n * nb, seed ^ 0xBA5E).reshape(n, 1, 1, nb)
+    base = np.repeat(base, 8, axis=3)[:, :, :, :w]
+    noise = uniform01(n * h * w, seed ^ 0x5EED).reshape(n, 1, h, w)
+    u8 = np.clip(base * np.float32(224.0) + noise * np.float32(32.0), 0, 255).astype(np.uint8)
+    x = u8.astype(np.float32) / np.float32(255.0)
+    return ((x - np.float32(0.5)) / np.float32(0.5)).astype(np.float32)

@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* from the REFERENCE itself (runs only where /root/reference exists).
+
+What it does (nothing from the reference is copied; only inputs-by-seed and outputs are stored):
+  * stubs `torchvision.models.utils` (absent here; only imported, never called with pretrained=False),
+    imports the reference model code on CPU, loads the portable synthetic state_dict
+    (pytorchocr_amd/utils/synth.py), runs small inputs, stores outputs;
+  * imports pytocr/postprocess/rec_postprocess.py BY FILE PATH (the package __init__ needs cv2) and
+    records CTCLabelDecode results on hand-made index/prob cases;
+  * records the state_dict key/shape/dtype contract of each model.
+
+Usage: python tools/gen_golden.py   (writes tests/golden/)
+"""
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("PTOCR_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+from pytorchocr_amd.utils.synth import synth_state_dict, synth_images, synth_text_lines, uniform  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _import_reference_models():
+    tv = types.ModuleType("torchvision")
+    tvm = types.ModuleType("torchvision.models")
+    tvu = types.ModuleType("torchvision.models.utils")
+
+    def _no(*a, **k):
+        raise RuntimeError("network fetch is not available")
+
+    tvu.load_state_dict_from_url = _no
+    tv.models = tvm
+    tvm.utils = tvu
+    sys.modules.update({"torchvision": tv, "torchvision.models": tvm, "torchvision.models.utils": tvu})
+    sys.path.insert(0, REF)
+    from pytocr.modeling.architectures import build_model
+    return build_model
+
+
+DET_R18 = dict(model_type="det", algorithm="DB", Transform=None,
+               Backbone=dict(name="ResNet", layers=18, pretrained=False),
+               Neck=dict(name="FPN", out_channels=256, mode="DB", use_asf=False,
+                         attention_type="scale_channel_spatial"),
+               Head=dict(name="DBHead", k=50))
+DETPP_R18 = dict(model_type="det", algorithm="DB", Transform=None,
+                 Backbone=dict(name="ResNet", layers=18, pretrained=False),
+                 Neck=dict(name="FPN", out_channels=256, mode="DB", use_asf=True,
+                           attention_type="scale_channel_spatial"),
+                 Head=dict(name="DBHead", k=50))
+DET_MBV3S = dict(model_type="det", algorithm="DB", Transform=None,
+                 Backbone=dict(name="MobileNetV3", model_name="small", scale=1.0, pretrained=False),
+                 Neck=dict(name="FPN", out_channels=96, mode="DB", use_asf=False),
+                 Head=dict(name="DBHead", k=50))
+
+
+def crnn_cfg(nclass):
+    return dict(model_type="rec", algorithm="CRNN", in_channels=1, Transform=None,
+                Backbone=dict(name="VGG", model_name="v1", scale=1.0, pretrained=False, ckpt_path=None),
+                Neck=dict(name="SequenceEncoder", encoder_type="rnn", hidden_size=256),
+                Head=dict(name="CTCHead", out_channels=nclass))
+
+
+def build_with_synth(build_model, cfg, seed=2022):
+    m = build_model(cfg).eval()
+    shapes = {k: (tuple(v.shape), str(v.dtype)) for k, v in m.state_dict().items()}
+    w = synth_state_dict(shapes, seed)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=True)
+    return m, shapes
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    build_model = _import_reference_models()
+    contract = {}
+
+    # ---------------- DBNet r18: maps + intermediates on a small input, maps on a ragged batch
+    m, shapes = build_with_synth(build_model, DET_R18)
+    contract["det_r18_db"] = {k: [list(s), d] for k, (s, d) in shapes.items()}
+    x = torch.from_numpy(synth_images(1, 3, 64, 96, seed=11))
+    m.return_all_feats = True
+    with torch.no_grad():
+        y = m(x)
+    np.savez_compressed(
+        os.path.join(GOLD, "det_r18_db_1x3x64x96.npz"),
+        seed=np.int64(11), maps=y["maps"].numpy(),
+        c2=y["backbone_out"][0].numpy(), c3=y["backbone_out"][1].numpy(),
+        c4=y["backbone_out"][2].numpy(), c5=y["backbone_out"][3].numpy(),
+        neck=y["neck_out"].numpy())
+    m.return_all_feats = False
+    x = torch.from_numpy(synth_images(2, 3, 96, 160, seed=12))
+    with torch.no_grad():
+        y = m(x)
+    np.savez_compressed(os.path.join(GOLD, "det_r18_db_2x3x96x160.npz"), seed=np.int64(12), maps=y["maps"].numpy())
+
+    # ---------------- DB++ r18 and DB mbv3-small: maps only (later rows of SURVEY 8a: M3, M5)
+    for name, cfg, seed in (("detpp_r18_db", DETPP_R18, 13), ("det_mbv3s_db", DET_MBV3S, 14)):
+        m, shapes = build_with_synth(build_model, cfg)
+        contract[name] = {k: [list(s), d] for k, (s, d) in shapes.items()}
+        x = torch.from_numpy(synth_images(1, 3, 64, 96, seed=seed))
+        with torch.no_grad():
+            y = m(x)
+        np.savez_compressed(os.path.join(GOLD, f"{name}_1x3x64x96.npz"), seed=np.int64(seed), maps=y["maps"].numpy())
+
+    # ---------------- CRNN (6624 classes as with char_dict_6623.txt; infer_rec.py:62-63)
+    nclass = 6624
+    m, shapes = build_with_synth(build_model, crnn_cfg(nclass))
+    contract["rec_vgg_bilstm_ctc"] = {k: [list(s), d] for k, (s, d) in shapes.items()}
+    x = torch.from_numpy(synth_text_lines(3, 32, 320, seed=15))
+    with torch.no_grad():
+        p = m(x)                       # softmax [T,B,C]
+    pn = p.numpy()
+    idx = pn.transpose(1, 0, 2).argmax(axis=2)
+    prob = pn.transpose(1, 0, 2).max(axis=2)
+    cols = np.arange(0, nclass, 97)
+    np.savez_compressed(os.path.join(GOLD, "crnn_3x1x32x320.npz"), seed=np.int64(15),
+                        idx=idx.astype(np.int32), prob=prob, cols=cols.astype(np.int32),
+                        probs_cols=pn[:, :, cols], shape=np.array(pn.shape, np.int64))
+
+    with open(os.path.join(GOLD, "state_dict_contract.json"), "w") as f:
+        json.dump(contract, f, indent=0, sort_keys=False)
+
+    # ---------------- CTCLabelDecode known answers from the reference class itself
+    spec = importlib.util.spec_from_file_location("ref_rec_postprocess",
+                                                  os.path.join(REF, "pytocr/postprocess/rec_postprocess.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    dict_path = os.path.join(REF, "pytocr/utils/char_dict_6623.txt")
+    dec = mod.CTCLabelDecode(character_dict_path=dict_path, use_space_char=False)
+    dec36 = mod.CTCLabelDecode(character_dict_path=None, use_space_char=False)
+    cases = []
+    rng_cases = [
+        [1, 1, 0, 1, 2, 2], [0, 0, 0, 0], [5], [0], [3, 3, 3], [3, 0, 3], [0, 7, 7, 0, 7, 8, 8, 0],
+        [36, 1, 36, 36, 2], [1, 2, 3, 4, 5, 6, 7, 8, 9, 10],
+    ]
+    for k, seq in enumerate(rng_cases):
+        T = len(seq)
+        C = 37
+        pr = uniform((T, 1, C), 1000 + k, 0.0, 0.5)
+        for t, c in enumerate(seq):
+            pr[t, 0, c] = 0.6 + 0.01 * t
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res = dec36(torch.from_numpy(pr))
+        txt, conf = res[0]
+        cases.append({"dict": "default36", "seed": 1000 + k, "T": T, "C": C, "seq": seq, "text": txt,
+                      "conf": None if np.isnan(conf) else float(conf)})
+    # big-dictionary case: indices map through char_dict_6623.txt
+    seq = [1, 1, 0, 6623, 100, 100, 0, 100, 4321]
+    T, C = len(seq), 6624
+    pr = np.zeros((T, 2, C), np.float32)
+    for t, c in enumerate(seq):
+        pr[t, 0, c] = 0.9
+        pr[t, 1, (c * 7 + 1) % C] = 0.8
+    res = dec(torch.from_numpy(pr))
+    cases.append({"dict": "char_dict_6623", "T": T, "C": C, "seq": seq,
+                  "text": [r[0] for r in res], "conf": [float(r[1]) for r in res],
+                  "nclass": len(dec.character)})
+    with open(os.path.join(GOLD, "ctc_decode.json"), "w", encoding="utf-8") as f:
+        json.dump(cases, f, ensure_ascii=False, indent=0)
+    print("golden fixtures written to", GOLD)
+    for fn in sorted(os.listdir(GOLD)):
+        print("  %-40s %8d B" % (fn, os.path.getsize(os.path.join(GOLD, fn))))
+
+
+if __name__ == "__main__":
+    main()
