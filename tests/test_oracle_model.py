@@ -1,0 +1,41 @@
+"""The torch-fp32 model oracle against outputs of the reference itself (tests/golden, tools/gen_golden.py)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import model_oracle
+from pytorchocr_amd.utils.synth import synth_images, synth_state_dict, synth_text_lines
+
+
+def test_dbnet_r18_oracle_matches_reference_small(gold_dir, contract):
+    g = np.load(os.path.join(gold_dir, "det_r18_db_1x3x64x96.npz"))
+    sd = synth_state_dict(contract["det_r18_db"])
+    x = torch.from_numpy(synth_images(1, 3, 64, 96, seed=int(g["seed"])))
+    y = model_oracle.dbnet_r18_forward(sd, x, return_feats=True)
+    assert np.abs(y["maps"].numpy() - g["maps"]).max() <= 1e-6
+    for k, f in zip(("c2", "c3", "c4", "c5"), y["backbone_out"]):
+        assert np.abs(f.numpy() - g[k]).max() <= 1e-4 * max(1.0, np.abs(g[k]).max())
+    assert np.abs(y["neck_out"].numpy() - g["neck"]).max() <= 1e-4 * np.abs(g["neck"]).max()
+
+
+def test_dbnet_r18_oracle_matches_reference_batch(gold_dir, contract):
+    g = np.load(os.path.join(gold_dir, "det_r18_db_2x3x96x160.npz"))
+    sd = synth_state_dict(contract["det_r18_db"])
+    x = torch.from_numpy(synth_images(2, 3, 96, 160, seed=int(g["seed"])))
+    y = model_oracle.dbnet_r18_forward(sd, x)
+    assert y["maps"].shape == (2, 1, 96, 160)
+    assert np.abs(y["maps"].numpy() - g["maps"]).max() <= 1e-6
+
+
+def test_crnn_oracle_matches_reference(gold_dir, contract):
+    g = np.load(os.path.join(gold_dir, "crnn_3x1x32x320.npz"))
+    sd = synth_state_dict(contract["rec_vgg_bilstm_ctc"])
+    x = torch.from_numpy(synth_text_lines(3, 32, 320, seed=int(g["seed"])))
+    p = model_oracle.crnn_forward(sd, x).numpy()
+    assert tuple(p.shape) == tuple(g["shape"])
+    assert np.abs(p[:, :, g["cols"]] - g["probs_cols"]).max() <= 1e-5
+    idx = p.transpose(1, 0, 2).argmax(axis=2)
+    assert np.array_equal(idx, g["idx"])
+    assert np.abs(p.transpose(1, 0, 2).max(axis=2) - g["prob"]).max() <= 1e-5
+    assert (g["idx"] == 0).any() and (g["idx"] != 0).any()

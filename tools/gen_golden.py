@@ -173,5 +173,42 @@ def main():
         print("  %-40s %8d B" % (fn, os.path.getsize(os.path.join(GOLD, fn))))
 
 
+
+
+def gen_clipper_vectors():
+    """Unclip golden vectors from the reference's vendored Clipper (oracle/_ref): input int path, delta,
+    full solution.  The float mini-boxes come from seeded rotated rectangles (reference UnClip,
+    db_postprocess.cpp:34-56: distance from GetContourArea, vertices truncated to int)."""
+    sys.path.insert(0, ROOT)
+    from oracle import dbpost
+    dbpost.build(ref=True)
+    assert dbpost.ref_lib() is not None
+    vecs = []
+    fixed = [([[10, 10], [110, 10], [110, 40], [10, 40]], 19.615385),
+             ([[20, 30], [90, 12], [98, 41], [27, 58]], 17.780228)]
+    for path, delta in fixed:
+        sol = dbpost.clipper_ref_offset(path, delta)
+        vecs.append({"path": path, "delta": delta, "solution": [s.tolist() for s in sol]})
+    u = uniform((60, 5), 777, 0.0, 1.0)
+    for r in u:
+        cx, cy = 50 + r[0] * 1100, 50 + r[1] * 600
+        w, h = 3 + r[2] * 300, 2 + r[3] * 50
+        th = r[4] * np.pi
+        c, s = np.cos(th), np.sin(th)
+        pts = (np.array([[-w / 2, -h / 2], [w / 2, -h / 2], [w / 2, h / 2], [-w / 2, h / 2]]) @ np.array([[c, s], [-s, c]])
+               + [cx, cy]).astype(np.float32)
+        area = abs(0.5 * sum(pts[i, 0] * pts[(i + 1) % 4, 1] - pts[i, 1] * pts[(i + 1) % 4, 0] for i in range(4)))
+        per = sum(np.hypot(*(pts[i] - pts[(i + 1) % 4])) for i in range(4))
+        delta = float(np.float32(area * 1.7 / per))
+        path = pts.astype(np.int32).tolist()
+        sol = dbpost.clipper_ref_offset(path, delta)
+        vecs.append({"path": path, "delta": delta, "solution": [s.tolist() for s in sol]})
+    with open(os.path.join(GOLD, "clipper_unclip.json"), "w") as f:
+        json.dump(vecs, f)
+    print("clipper vectors:", len(vecs))
+
+
 if __name__ == "__main__":
-    main()
+    if "--clipper-only" not in sys.argv:
+        main()
+    gen_clipper_vectors()
