@@ -1,0 +1,107 @@
+/*
+ * ptocr_hip.h -- C ABI of libptocr_hip.so, the MI355X (gfx950) implementation of the PyTorchOCR
+ * detection + recognition inference hot path.
+ *
+ * Conventions
+ *   - every pointer named d_* is DEVICE memory (HBM) owned by the caller; h_* is host memory.
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); all work is stream-ordered, no call
+ *     synchronises the device unless its comment says so.
+ *   - return value 0 = ok, non-zero = error; ptocr_last_error() gives the message of the last failing call
+ *     of the calling thread.  No call falls back to the CPU.
+ *   - activations are fp32 NHWC in HBM (channel-contiguous, 16-byte aligned), probability maps are
+ *     f32[N,1,H,W] == NHWC with C=1, exactly the tensor the reference model returns under key "maps".
+ *
+ * What each entry point replaces in the reference (file:line under /root/reference):
+ *   ptocr_conv2d_f32 / ptocr_maxpool2d_f32 / ptocr_nchw_to_nhwc_f32 / ptocr_convt2x2_sigmoid_f32
+ *       the ATen conv / BN / ReLU / max_pool / conv_transpose / sigmoid calls issued by
+ *       pytocr/modeling/backbones/det_resnet.py:66-82,282-309, necks/fpn.py:102-134,
+ *       heads/det_db_head.py:9-17,47-50, backbones/rec_vgg.py:78-120 (BN folded into weights/bias at load).
+ *   ptocr_db_postprocess
+ *       pybind11 `db_postprocess.db_postprocess(pred, bitmap, box_thresh, det_db_unclip_ratio, src_w, src_h,
+ *       use_padding_resize)` = DBProcess, pytocr/postprocess/db_postprocess_fast/src/db_postprocess.cpp:319-370,
+ *       plus the threshold of pytocr/postprocess/db_postprocess.py:45-46, batched over N images.
+ *   ptocr_ctc_greedy_f32
+ *       preds.argmax(axis=2) / preds.max(axis=2) of pytocr/postprocess/rec_postprocess.py:80-84.
+ *   ptocr_lstm_bidir_f32, ptocr_linear_f32
+ *       nn.LSTM(bidirectional) / nn.Linear of pytocr/modeling/necks/rnn.py:18-36, heads/rec_ctc_head.py:17-36.
+ */
+#ifndef PTOCR_HIP_H
+#define PTOCR_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char *ptocr_last_error(void);
+int ptocr_version(void);
+/* fills name (<=255 chars) with the gcnArchName of device `dev`, returns 0 or error */
+int ptocr_device_arch(int dev, char *name);
+
+/* ---- convolution (implicit GEMM on v_mfma_f32_32x32x2_f32, fp32 in / fp32 accumulate) ------------------- */
+enum { PTOCR_RES_NONE = 0, PTOCR_RES_ADD_PRE_RELU = 1, PTOCR_RES_ADD_UP2_POST_RELU = 2 };
+
+typedef struct {
+    int N, H, W, Cin;          /* input  f32[N,H,W,Cin]; Cin % 32 == 0, or Cin == 4 (zero-padded 1/3-channel images) */
+    int Cout, KH, KW;          /* weights packed f32[Cout][Kpad], K index = (kh*KW + kw)*Cin + ci, Kpad = roundup(KH*KW*Cin, 32) */
+    int stride, pad_h, pad_w;
+    int Ho, Wo;                /* output spatial size (before out_up / convt expansion) */
+    int relu;                  /* 1: ReLU in the epilogue */
+    int res_mode;              /* PTOCR_RES_*: d_res is f32[N,Ho,Wo,Cout] (PRE_RELU) or f32[N,Ho/2,Wo/2,Cout] (UP2_POST_RELU) */
+    int out_up;                /* >= 1: every output pixel is stored to an out_up x out_up block (nearest upsample) */
+    int out_ldc, out_coff;     /* output tensor channel stride / channel offset (concat-in-place); ldc >= coff + Cout */
+    int convt2x2;              /* 1: ConvTranspose2d k=2 s=2: Cout here = 4*Co, column (a*2+b)*Co + co goes to pixel (2y+a, 2x+b) */
+} ptocr_conv_desc;
+
+int ptocr_conv2d_f32(const ptocr_conv_desc *d, const float *d_x, const float *d_w, const float *d_bias,
+                     const float *d_res, float *d_y, void *stream);
+
+/* f32[N,C,H,W] -> f32[N,H,W,Cpad] (channels >= C zero-filled; Cpad % 4 == 0) */
+int ptocr_nchw_to_nhwc_f32(const float *d_x, float *d_y, int N, int C, int H, int W, int Cpad, void *stream);
+/* f32[N,H,W,C] -> f32[N,C,H,W] */
+int ptocr_nhwc_to_nchw_f32(const float *d_x, float *d_y, int N, int C, int H, int W, void *stream);
+/* NHWC max pool, -inf padding like torch.nn.MaxPool2d; C % 4 == 0 */
+int ptocr_maxpool2d_f32(const float *d_x, float *d_y, int N, int H, int W, int C, int kh, int kw, int sh, int sw,
+                        int ph, int pw, int Ho, int Wo, void *stream);
+/* DB head tail: ConvTranspose2d(C->1, k=2, s=2, bias) + sigmoid.  d_x f32[N,H,W,C] (C % 4 == 0, C <= 256),
+ * d_w f32[4][C] (index a*2+b), bias scalar -> d_maps f32[N,2H,2W]. */
+int ptocr_convt2x2_sigmoid_f32(const float *d_x, const float *d_w, float bias, float *d_maps, int N, int H, int W,
+                               int C, void *stream);
+
+/* ---- DB post-process ------------------------------------------------------------------------------------ */
+typedef struct ptocr_dbpost *ptocr_dbpost_t;
+
+/* Workspace for batches of up to max_n maps of up to max_h x max_w (device buffers are allocated here, once). */
+int ptocr_dbpost_create(ptocr_dbpost_t *out, int max_n, int max_h, int max_w);
+int ptocr_dbpost_destroy(ptocr_dbpost_t h);
+
+/* d_maps f32[N,H,W] probability maps (device).  h_src_wh int[N][2] = (src_w, src_h) per image.
+ * If d_bitmap != NULL it is used as the u8[N,H,W] segmentation (caller-made, e.g. dilated); otherwise the
+ * segmentation is pred > thresh computed on the device.
+ * Output (host): h_boxes int16[N][max_boxes][4][2] in the reference's order, h_counts int32[N] (boxes per
+ * image), h_flags int32[N] (bit 0: a candidate's unclip distance was < 0.75 px -- Clipper's union clean-up of
+ * sub-pixel slivers is not reproduced; bit 1: score within 1e-7 of box_thresh resolved by the
+ * exact raster-order re-summation; bit 2: internal capacity exceeded -> the call fails with an error).
+ * Synchronises `stream` before returning (the boxes are host data, like the reference's return value). */
+int ptocr_db_postprocess(ptocr_dbpost_t h, const float *d_maps, const uint8_t *d_bitmap, int N, int H, int W,
+                         float thresh, float box_thresh, float unclip_ratio, const int *h_src_wh,
+                         int use_padding_resize, int16_t *h_boxes, int max_boxes, int32_t *h_counts,
+                         int32_t *h_flags, void *stream);
+
+/* ---- recognition ---------------------------------------------------------------------------------------- */
+/* y[M,Nout] = x[M,K] @ w[Nout,K]^T + bias; K % 32 == 0, Nout % 64 == 0 (pad rows of w with zeros) */
+int ptocr_linear_f32(const float *d_x, const float *d_w, const float *d_bias, float *d_y, int M, int K, int Nout,
+                     int ldy, void *stream);
+/* One bidirectional LSTM layer, zero initial state, torch gate order i,f,g,o.
+ * d_xproj f32[2][T][B][4H]: input projections x@W_ih^T + b_ih + b_hh per direction (made with ptocr_linear_f32);
+ * d_whh f32[2][4H][H]; d_out f32[T][B][2H] (forward half, backward half).  H == 256. */
+int ptocr_lstm_bidir_f32(const float *d_xproj, const float *d_whh, float *d_out, int T, int B, int H, void *stream);
+/* logits f32[T*B][ldl] (first C columns valid) -> softmax max prob and first arg-max per row:
+ * d_idx int32[B][T], d_prob f32[B][T]  (== preds.argmax(2), preds.max(2) after the (1,0,2) transpose). */
+int ptocr_ctc_greedy_f32(const float *d_logits, int T, int B, int C, int ldl, int32_t *d_idx, float *d_prob,
+                         void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,62 @@
+"""ctypes binding of libptocr_hip.so (include/ptocr_hip.h).  There is NO fallback: if the library is missing
+or a call fails, a RuntimeError is raised (the product path must never silently run on the CPU)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libptocr_hip.so")
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "N", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad_h", "pad_w", "Ho", "Wo",
+        "relu", "res_mode", "out_up", "out_ldc", "out_coff", "convt2x2")]
+
+
+RES_NONE, RES_ADD_PRE_RELU, RES_ADD_UP2_POST_RELU = 0, 1, 2
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "pytorchocr_amd: %s is missing -- build it with `python -m pytorchocr_amd.build` "
+                "(there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.ptocr_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+# every symbol include/ptocr_hip.h declares
+EXPORTS = [
+    "ptocr_last_error", "ptocr_version", "ptocr_device_arch",
+    "ptocr_conv2d_f32", "ptocr_nchw_to_nhwc_f32", "ptocr_nhwc_to_nchw_f32", "ptocr_maxpool2d_f32",
+    "ptocr_convt2x2_sigmoid_f32",
+    "ptocr_dbpost_create", "ptocr_dbpost_destroy", "ptocr_db_postprocess",
+    "ptocr_linear_f32", "ptocr_lstm_bidir_f32", "ptocr_ctc_greedy_f32",
+]
+
+
+def missing_exports():
+    """Symbols declared in include/ptocr_hip.h that the built library does not export (should be empty)."""
+    L = lib()
+    return [n for n in EXPORTS if not hasattr(L, n)]
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError("libptocr_hip %s failed: %s" % (what, lib().ptocr_last_error().decode()))
+
+
+def ptr(t):
+    """torch tensor (device or host) -> void*"""
+    return C.c_void_p(t.data_ptr())
+
+
+def cur_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,163 @@
+// Memory-bound layout / pooling / head-tail kernels (HBM roofline; 16-byte accesses, grid-stride).
+// Replaces: the implicit NCHW layout of the reference's tensors (boundary conversion only),
+//   nn.MaxPool2d (det_resnet.py:209, rec_vgg.py:80-90), and the DB head tail
+//   ConvTranspose2d(64->1,k2,s2)+Sigmoid (det_db_head.py:16-17).
+#include "common.h"
+
+namespace ptocr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+thread_local char g_err[512] = "";
+
+// ---- f32[N,C,H,W] -> f32[N,H,W,Cpad]: one thread per pixel, planes are read coalesced, one 16-B store per 4 ch.
+__global__ void nchw_to_nhwc_kernel(const float *__restrict__ x, float *__restrict__ y, int C, int HW, int Cpad, long total) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / HW;
+        const int p = (int)(i - n * HW);
+        const float *src = x + n * (long)C * HW + p;
+        float *dst = y + i * Cpad;
+        for (int c0 = 0; c0 < Cpad; c0 += 4) {
+            f32x4 v;
+            v[0] = c0 + 0 < C ? src[(long)(c0 + 0) * HW] : 0.f;
+            v[1] = c0 + 1 < C ? src[(long)(c0 + 1) * HW] : 0.f;
+            v[2] = c0 + 2 < C ? src[(long)(c0 + 2) * HW] : 0.f;
+            v[3] = c0 + 3 < C ? src[(long)(c0 + 3) * HW] : 0.f;
+            *reinterpret_cast<f32x4 *>(dst + c0) = v;
+        }
+    }
+}
+
+// ---- f32[N,H,W,C] -> f32[N,C,H,W] through a 64x64 LDS tile (coalesced on both sides)
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float *__restrict__ x, float *__restrict__ y, int C, int HW) {
+    __shared__ float t[64][65];
+    const int n = blockIdx.z, p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int p = p0 + r, c = c0 + tx;
+        t[r][tx] = (p < HW && c < C) ? x[((long)n * HW + p) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int c = c0 + r, p = p0 + tx;
+        if (c < C && p < HW) y[((long)n * C + c) * HW + p] = t[tx][r];
+    }
+}
+
+// ---- NHWC max pool, one thread per (pixel, 4 channels)
+__global__ void maxpool_kernel(const float *__restrict__ x, float *__restrict__ y, int H, int W, int C4, int kh, int kw,
+                               int sh, int sw, int ph, int pw, int Ho, int Wo, long total) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long r = i / C4;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const long n = r / Ho;
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int a = 0; a < kh; a++) {
+            const int iy = oy * sh - ph + a;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            for (int b = 0; b < kw; b++) {
+                const int ix = ox * sw - pw + b;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(x + (((n * H + iy) * W + ix) * (long)C4 + c) * 4);
+                m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+            }
+        }
+        *reinterpret_cast<f32x4 *>(y + i * 4) = m;
+    }
+}
+
+// ---- ConvTranspose2d(C->1, k2, s2) + bias + sigmoid.  16 lanes per input pixel (each 4 channels x C/64 rounds),
+// xor-shuffle reduction inside the 16-lane group, lane 0 of the group writes the 2x2 output block.
+__global__ __launch_bounds__(256) void convt2x2_sigmoid_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                               float bias, float *__restrict__ out, int H, int W, int C,
+                                                               long npix) {
+    const int sub = threadIdx.x & 15;
+    const long gstride = (long)gridDim.x * (blockDim.x >> 4);
+    const long npix16 = ((npix + 15) / 16) * 16;
+    for (long pix = blockIdx.x * (long)(blockDim.x >> 4) + (threadIdx.x >> 4); pix < npix16; pix += gstride) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        const bool ok = pix < npix;
+        if (ok) {
+            for (int c = sub * 4; c < C; c += 64) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(x + pix * C + c);
+                const f32x4 w0 = *reinterpret_cast<const f32x4 *>(w + c);
+                const f32x4 w1 = *reinterpret_cast<const f32x4 *>(w + C + c);
+                const f32x4 w2 = *reinterpret_cast<const f32x4 *>(w + 2 * C + c);
+                const f32x4 w3 = *reinterpret_cast<const f32x4 *>(w + 3 * C + c);
+                s0 += v[0] * w0[0] + v[1] * w0[1] + v[2] * w0[2] + v[3] * w0[3];
+                s1 += v[0] * w1[0] + v[1] * w1[1] + v[2] * w1[2] + v[3] * w1[3];
+                s2 += v[0] * w2[0] + v[1] * w2[1] + v[2] * w2[2] + v[3] * w2[3];
+                s3 += v[0] * w3[0] + v[1] * w3[1] + v[2] * w3[2] + v[3] * w3[3];
+            }
+        }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) {
+            s0 += __shfl_xor(s0, o, 16); s1 += __shfl_xor(s1, o, 16);
+            s2 += __shfl_xor(s2, o, 16); s3 += __shfl_xor(s3, o, 16);
+        }
+        if (ok && sub == 0) {
+            const long n = pix / ((long)H * W);
+            const int rem = (int)(pix - n * (long)H * W);
+            const int y = rem / W, xx = rem - y * W;
+            float *o = out + (n * 2 * H + 2 * y) * (long)(2 * W) + 2 * xx;
+            o[0] = 1.f / (1.f + expf(-(s0 + bias)));
+            o[1] = 1.f / (1.f + expf(-(s1 + bias)));
+            o[2 * W] = 1.f / (1.f + expf(-(s2 + bias)));
+            o[2 * W + 1] = 1.f / (1.f + expf(-(s3 + bias)));
+        }
+    }
+}
+
+static inline int grid_for(long total, int block, int per_cu = 8) {
+    long g = (total + block - 1) / block;
+    const long cap = 256L * per_cu;
+    return (int)(g < cap ? (g > 0 ? g : 1) : cap);
+}
+
+}  // namespace ptocr
+
+using namespace ptocr;
+
+extern "C" const char *ptocr_last_error(void) { return g_err; }
+extern "C" int ptocr_version(void) { return 1; }
+extern "C" int ptocr_device_arch(int dev, char *name) {
+    hipDeviceProp_t prop;
+    PT_HIP(hipGetDeviceProperties(&prop, dev));
+    strncpy(name, prop.gcnArchName, 255); name[255] = 0;
+    return 0;
+}
+
+extern "C" int ptocr_nchw_to_nhwc_f32(const float *d_x, float *d_y, int N, int C, int H, int W, int Cpad, void *stream) {
+    PT_CHECK(d_x && d_y && Cpad % 4 == 0 && Cpad >= C, "ptocr_nchw_to_nhwc_f32: bad arguments");
+    const long total = (long)N * H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, d_x, d_y, C, H * W, Cpad, total);
+    return launch_ok("nchw_to_nhwc_kernel");
+}
+
+extern "C" int ptocr_nhwc_to_nchw_f32(const float *d_x, float *d_y, int N, int C, int H, int W, void *stream) {
+    PT_CHECK(d_x && d_y && N <= 65535, "ptocr_nhwc_to_nchw_f32: bad arguments");
+    dim3 grid(cdiv(H * W, 64), cdiv(C, 64), N);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_x, d_y, C, H * W);
+    return launch_ok("nhwc_to_nchw_kernel");
+}
+
+extern "C" int ptocr_maxpool2d_f32(const float *d_x, float *d_y, int N, int H, int W, int C, int kh, int kw, int sh, int sw,
+                                   int ph, int pw, int Ho, int Wo, void *stream) {
+    PT_CHECK(d_x && d_y && C % 4 == 0, "ptocr_maxpool2d_f32: C must be a multiple of 4");
+    PT_CHECK(Ho == (H + 2 * ph - kh) / sh + 1 && Wo == (W + 2 * pw - kw) / sw + 1, "ptocr_maxpool2d_f32: Ho/Wo mismatch");
+    const long total = (long)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, d_x, d_y, H, W, C / 4,
+                       kh, kw, sh, sw, ph, pw, Ho, Wo, total);
+    return launch_ok("maxpool_kernel");
+}
+
+extern "C" int ptocr_convt2x2_sigmoid_f32(const float *d_x, const float *d_w, float bias, float *d_maps, int N, int H, int W,
+                                          int C, void *stream) {
+    PT_CHECK(d_x && d_w && d_maps && C % 4 == 0 && C >= 4, "ptocr_convt2x2_sigmoid_f32: bad arguments");
+    const long npix = (long)N * H * W;
+    hipLaunchKernelGGL(convt2x2_sigmoid_kernel, dim3(grid_for(npix, 16)), dim3(256), 0, (hipStream_t)stream, d_x, d_w, bias,
+                       d_maps, H, W, C, npix);
+    return launch_ok("convt2x2_sigmoid_kernel");
+}

@@ -1,0 +1,63 @@
+"""BaseModel: mirror of reference pytocr/modeling/architectures/base_model.py:12-73.
+
+Same config mutation (`in_channels` threaded through Backbone -> Neck -> Head), same `forward(x, data=None)`
+contract: det eval returns {"maps": f32[N,1,H,W]}, rec eval returns softmax f32[T,B,C];
+`return_all_feats` adds "backbone_out" / "neck_out" (converted to NCHW like the reference's tensors).
+Internally activations stay NHWC on the device between backbone, neck and head.
+"""
+from torch import nn
+
+from .. import ops
+from ..backbones import build_backbone
+from ..heads import build_head
+from ..necks import build_neck
+
+__all__ = ["BaseModel"]
+
+
+class BaseModel(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        in_channels = config.get("in_channels", 3)
+        model_type = config["model_type"]
+        self.model_type = model_type
+        if config.get("Transform") is not None:
+            raise NotImplementedError("pytorchocr_amd: Transform (TPS) is outside the hot path; both hot-path ymls leave it empty")
+        self.use_transform = False
+        config["Backbone"]["in_channels"] = in_channels
+        self.backbone = build_backbone(config["Backbone"], model_type)
+        in_channels = self.backbone.out_channels
+        if "Neck" not in config or config["Neck"] is None:
+            self.use_neck = False
+        else:
+            self.use_neck = True
+            config["Neck"]["in_channels"] = in_channels
+            self.neck = build_neck(config["Neck"])
+            in_channels = self.neck.out_channels
+        config["Head"]["in_channels"] = in_channels
+        self.head = build_head(config["Head"])
+        self.return_all_feats = config.get("return_all_feats", False)
+
+    def forward(self, x, data=None):
+        if not x.is_cuda:
+            raise RuntimeError("pytorchocr_amd BaseModel.forward: input is on %s; the HIP path has no CPU fallback" % x.device)
+        y = dict()
+        if self.model_type == "det":
+            feats = self.backbone.forward_nhwc(ops.nchw_to_nhwc(x, 4))
+            neck = self.neck.forward_nhwc(feats) if self.use_neck else feats
+            out = self.head.forward_nhwc(neck)
+            if self.return_all_feats:
+                y["backbone_out"] = [ops.nhwc_to_nchw(f) for f in feats]
+                y["neck_out"] = ops.nhwc_to_nchw(neck) if self.use_neck else y["backbone_out"]
+        else:
+            feats = self.backbone.forward_nhwc(ops.nchw_to_nhwc(x, 4))
+            neck = self.neck.forward_seq(feats) if self.use_neck else feats
+            out = self.head.forward_seq(neck)
+            if self.return_all_feats:
+                y["backbone_out"] = ops.nhwc_to_nchw(feats)
+                y["neck_out"] = neck
+        if isinstance(out, dict):
+            y.update(out)
+        else:
+            y["head_out"] = out
+        return y if self.return_all_feats else out

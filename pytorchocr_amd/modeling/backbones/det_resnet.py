@@ -1,0 +1,108 @@
+"""ResNet-18/34 detection backbone on the HIP conv engine.
+
+Mirror of the reference class `ResNet` (pytocr/modeling/backbones/det_resnet.py:143-312): same constructor
+arguments, same parameter/buffer names (state_dict contract), same four outputs
+(C2..C5).  nn.Conv2d / nn.BatchNorm2d objects are kept only as parameter containers; forward runs
+BN-folded fp32 MFMA convolutions with fused ReLU / residual-add epilogues on NHWC activations.
+"""
+import logging
+import os
+
+import torch
+from torch import nn
+
+from .. import ops
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def pack(self, dev):
+        p = {"c1": ops.PackedConv(self.conv1, self.bn1, dev, relu=True),
+             "c2": ops.PackedConv(self.conv2, self.bn2, dev, relu=True)}
+        if self.downsample is not None:
+            p["ds"] = ops.PackedConv(self.downsample[0], self.downsample[1], dev, relu=False)
+        return p
+
+    @staticmethod
+    def run(p, x):
+        out = ops.conv2d(x, p["c1"])
+        idt = ops.conv2d(x, p["ds"]) if "ds" in p else x
+        # conv2 + bn2, += identity, ReLU  (reference det_resnet.py:72-80) in one epilogue
+        return ops.conv2d(out, p["c2"], res=idt, res_mode=ops.RES_ADD_PRE_RELU)
+
+
+class ResNet(ops.PackedModule):
+    def __init__(self, in_channels=3, layers=50, mode_3x3=False, pretrained=False, ckpt_path=None, **kwargs):
+        super().__init__()
+        if layers == 18:
+            depth = [2, 2, 2, 2]
+        elif layers == 34:
+            depth = [3, 4, 6, 3]
+        else:
+            raise NotImplementedError("pytorchocr_amd ResNet: only BasicBlock depths 18/34 are on the hot path (got %s)" % layers)
+        if mode_3x3:
+            raise NotImplementedError("pytorchocr_amd ResNet: mode_3x3 stem is not on the hot path")
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(in_channels, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.out_channels = []
+        self.layer1 = self._make_layer(64, depth[0], 1)
+        self.layer2 = self._make_layer(128, depth[1], 2)
+        self.layer3 = self._make_layer(256, depth[2], 2)
+        self.layer4 = self._make_layer(512, depth[3], 2)
+        self.out_channels = [64, 128, 256, 512]
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        if pretrained:
+            # local files only: the reference falls back to a URL fetch (det_resnet.py:246-254); never here
+            if ckpt_path and os.path.exists(ckpt_path):
+                logging.getLogger("root").info("load imagenet weights from %s", ckpt_path)
+                self.load_state_dict(torch.load(ckpt_path, map_location="cpu"), strict=False)
+            else:
+                logging.getLogger("root").warning("pretrained backbone checkpoint %r not found; keeping random init "
+                                                  "(no network fetch in pytorchocr_amd)", ckpt_path)
+
+    def _make_layer(self, planes, blocks, stride):
+        downsample = None
+        if stride != 1 or self.inplanes != planes:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+        layers = [BasicBlock(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes
+        for _ in range(1, blocks):
+            layers.append(BasicBlock(planes, planes))
+        return nn.Sequential(*layers)
+
+    def _pack(self, dev):
+        p = {"stem": ops.PackedConv(self.conv1, self.bn1, dev, relu=True, cin_pad=4)}
+        for li in (1, 2, 3, 4):
+            p["layer%d" % li] = [blk.pack(dev) for blk in getattr(self, "layer%d" % li)]
+        return p
+
+    def forward_nhwc(self, x4):
+        """x4: f32[N,H,W,4] (RGB + zero channel) -> [C2, C3, C4, C5] NHWC."""
+        self._check_eval()
+        p = self.packed()
+        x = ops.conv2d(x4, p["stem"])
+        x = ops.maxpool2d(x, 3, 2, 1)
+        outs = []
+        for li in (1, 2, 3, 4):
+            for bp in p["layer%d" % li]:
+                x = BasicBlock.run(bp, x)
+            outs.append(x)
+        return outs
+
+    def forward(self, x):
+        """NCHW in, list of NCHW feature maps out (reference contract, det_resnet.py:282-312)."""
+        feats = self.forward_nhwc(ops.nchw_to_nhwc(x, 4))
+        return [ops.nhwc_to_nchw(f) for f in feats]

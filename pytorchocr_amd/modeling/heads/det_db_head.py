@@ -1,0 +1,53 @@
+"""DB head (eval path) on the HIP engine.
+
+Mirror of reference `DBHead` (pytocr/modeling/heads/det_db_head.py:5-58).  Both branches' parameters exist
+(the train-only `thresh.*` tensors are part of the strict state_dict contract) but eval runs only `binarize`
+(det_db_head.py:47-50): 3x3 conv+BN+ReLU -> ConvT 2x2/s2 (+bias)+BN+ReLU as a 4-column-group MFMA GEMM with
+pixel-scatter epilogue -> ConvT 2x2/s2 to 1 channel + sigmoid in one memory-bound kernel.
+"""
+import torch
+from torch import nn
+
+from .. import ops
+
+
+def _branch(cin):
+    c4 = cin // 4
+    return nn.Sequential(
+        nn.Conv2d(cin, c4, 3, 1, 1, bias=False), nn.BatchNorm2d(c4), nn.ReLU(inplace=True),
+        nn.ConvTranspose2d(c4, c4, 2, 2, 0, bias=True), nn.BatchNorm2d(c4), nn.ReLU(inplace=True),
+        nn.ConvTranspose2d(c4, 1, 2, 2, 0, bias=True), nn.Sigmoid())
+
+
+class DBHead(ops.PackedModule):
+    def __init__(self, in_channels, k=50, **kwargs):
+        super().__init__()
+        self.k = k
+        if (in_channels // 4) % 64 != 0:
+            raise NotImplementedError("pytorchocr_amd DBHead: in_channels//4 must be a multiple of 64 (got %d)" % in_channels)
+        self.binarize = _branch(in_channels)
+        self.thresh = _branch(in_channels)
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                nn.init.kaiming_normal_(m.weight)
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1.)
+                m.bias.data.fill_(1e-4)
+
+    def _pack(self, dev):
+        b = self.binarize
+        w6 = b[6].weight.detach().double().cpu()                       # [C4, 1, 2, 2]
+        w4 = w6[:, 0].permute(1, 2, 0).reshape(4, -1).float().contiguous().to(dev)
+        return {"c0": ops.PackedConv(b[0], b[1], dev, relu=True),
+                "t3": ops.PackedConvT2x2(b[3], b[4], dev, relu=True),
+                "w6": w4, "b6": float(b[6].bias.detach().cpu()[0])}
+
+    def forward_nhwc(self, fuse):
+        self._check_eval()
+        p = self.packed()
+        x = ops.conv2d(fuse, p["c0"])
+        x = ops.conv2d(x, p["t3"])
+        return {"maps": ops.convt2x2_sigmoid(x, p["w6"], p["b6"])}
+
+    def forward(self, x, **kwargs):
+        return self.forward_nhwc(ops.nchw_to_nhwc(x, x.shape[1]))

@@ -1,0 +1,70 @@
+"""DB-style FPN neck on the HIP conv engine.
+
+Mirror of reference `FPN` (pytocr/modeling/necks/fpn.py:8-134), mode "DB": 4 lateral 1x1 conv+BN+ReLU,
+top-down nearest-x2 upsample-add, 4 smoothing 3x3 conv+BN+ReLU to C/4, nearest x8/x4/x2, concat (p5,p4,p3,p2).
+Fusions: the upsample-add runs in the lateral conv's epilogue (add AFTER its ReLU, fpn.py:133-134), and the
+smoothing convs store their nearest-upsampled result straight into their channel slice of the `fuse` tensor,
+so interpolate + cat never exist as separate passes.
+"""
+import torch
+from torch import nn
+
+from .. import ops
+
+
+def _cbr(cin, cout, k, pad):
+    return nn.Sequential(nn.Conv2d(cin, cout, k, 1, pad, bias=False), nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
+
+
+class FPN(ops.PackedModule):
+    def __init__(self, in_channels, out_channels=256, mode=None, use_asf=False, attention_type="scale_spatial", **kwargs):
+        super().__init__()
+        if mode != "DB":
+            raise NotImplementedError("pytorchocr_amd FPN: only mode='DB' is on the hot path")
+        if use_asf:
+            raise NotImplementedError("pytorchocr_amd FPN: DB++ ASF (use_asf=True) is not built yet (SURVEY.md 8a M5)")
+        if (out_channels // 4) % 64 != 0:
+            raise NotImplementedError("pytorchocr_amd FPN: out_channels//4 must be a multiple of 64 on the MFMA path "
+                                      "(got out_channels=%d)" % out_channels)
+        self.mode, self.use_asf = mode, use_asf
+        self.in5 = _cbr(in_channels[-1], out_channels, 1, 0)
+        self.in4 = _cbr(in_channels[-2], out_channels, 1, 0)
+        self.in3 = _cbr(in_channels[-3], out_channels, 1, 0)
+        self.in2 = _cbr(in_channels[-4], out_channels, 1, 0)
+        sm = out_channels // 4
+        self.out_channels = out_channels
+        self.out5 = _cbr(out_channels, sm, 3, 1)
+        self.out4 = _cbr(out_channels, sm, 3, 1)
+        self.out3 = _cbr(out_channels, sm, 3, 1)
+        self.out2 = _cbr(out_channels, sm, 3, 1)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight)
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1.)
+                m.bias.data.fill_(1e-4)
+
+    def _pack(self, dev):
+        return {k: ops.PackedConv(getattr(self, k)[0], getattr(self, k)[1], dev, relu=True)
+                for k in ("in5", "in4", "in3", "in2", "out5", "out4", "out3", "out2")}
+
+    def forward_nhwc(self, feats):
+        self._check_eval()
+        p = self.packed()
+        c2, c3, c4, c5 = feats
+        in5 = ops.conv2d(c5, p["in5"])
+        out4 = ops.conv2d(c4, p["in4"], res=in5, res_mode=ops.RES_ADD_UP2_POST_RELU)
+        out3 = ops.conv2d(c3, p["in3"], res=out4, res_mode=ops.RES_ADD_UP2_POST_RELU)
+        out2 = ops.conv2d(c2, p["in2"], res=out3, res_mode=ops.RES_ADD_UP2_POST_RELU)
+        N, H4, W4, _ = c2.shape
+        sm = self.out_channels // 4
+        fuse = torch.empty((N, H4, W4, self.out_channels), dtype=torch.float32, device=c2.device)
+        ops.conv2d(in5, p["out5"], out=fuse, out_up=8, out_coff=0)
+        ops.conv2d(out4, p["out4"], out=fuse, out_up=4, out_coff=sm)
+        ops.conv2d(out3, p["out3"], out=fuse, out_up=2, out_coff=2 * sm)
+        ops.conv2d(out2, p["out2"], out=fuse, out_up=1, out_coff=3 * sm)
+        return fuse
+
+    def forward(self, x):
+        feats = [ops.nchw_to_nhwc(f, f.shape[1]) for f in x]
+        return ops.nhwc_to_nchw(self.forward_nhwc(feats))

@@ -1,0 +1,153 @@
+"""Host-side wrappers of the C ABI (include/ptocr_hip.h) used by the model mirror classes.
+
+Activations are fp32 NHWC torch tensors on the MI355X; torch only provides device memory and streams."""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+from .._lib import ConvDesc, RES_NONE, RES_ADD_PRE_RELU, RES_ADD_UP2_POST_RELU  # noqa: F401
+
+
+def _require_cuda(t, what):
+    if not t.is_cuda:
+        raise RuntimeError("%s: tensor is on %s -- the HIP path needs a cuda (ROCm) device, there is no CPU fallback"
+                           % (what, t.device))
+
+
+def fold_bn(w, conv_bias, bn, cout_dim=0):
+    """Fold eval-mode BatchNorm into conv weight/bias (float64 on the host).  bn: nn.BatchNorm2d or None."""
+    w = w.detach().double().cpu()
+    cout = w.shape[cout_dim]
+    b = conv_bias.detach().double().cpu() if conv_bias is not None else torch.zeros(cout, dtype=torch.float64)
+    if bn is not None:
+        scale = bn.weight.detach().double().cpu() / torch.sqrt(bn.running_var.detach().double().cpu() + bn.eps)
+        shape = [1] * w.dim()
+        shape[cout_dim] = cout
+        w = w * scale.view(shape)
+        b = (b - bn.running_mean.detach().double().cpu()) * scale + bn.bias.detach().double().cpu()
+    return w, b
+
+
+class PackedConv:
+    """Weights of one convolution in the kernel's layout: f32[Cout][Kpad], K = (kh*KW+kw)*Cin_pad + ci."""
+
+    def __init__(self, conv, bn, device, relu, cin_pad=None):
+        w, b = fold_bn(conv.weight, conv.bias, bn)
+        cout, cin, kh, kw = w.shape
+        cin_pad = cin_pad or cin
+        wk = torch.zeros(cout, kh, kw, cin_pad, dtype=torch.float64)
+        wk[..., :cin] = w.permute(0, 2, 3, 1)
+        k = kh * kw * cin_pad
+        kpad = (k + 31) // 32 * 32
+        wp = torch.zeros(cout, kpad, dtype=torch.float64)
+        wp[:, :k] = wk.reshape(cout, k)
+        self.w = wp.float().contiguous().to(device)
+        self.b = b.float().contiguous().to(device)
+        self.cin, self.cout, self.kh, self.kw = cin_pad, cout, kh, kw
+        self.stride = conv.stride[0]
+        self.pad_h, self.pad_w = conv.padding
+        self.relu = relu
+        self.convt = False
+
+
+class PackedConvT2x2:
+    """ConvTranspose2d(k=2, s=2) as a 1x1 GEMM with 4*Co columns: column (a*2+b)*Co + co."""
+
+    def __init__(self, convt, bn, device, relu):
+        w, b = fold_bn(convt.weight, convt.bias, bn, cout_dim=1)       # [Cin, Co, 2, 2]
+        cin, co = w.shape[0], w.shape[1]
+        wp = w.permute(2, 3, 1, 0).reshape(4 * co, cin)               # [(a,b,co), ci]
+        self.w = wp.float().contiguous().to(device)
+        self.b = b.repeat(4).float().contiguous().to(device)
+        self.cin, self.cout, self.kh, self.kw = cin, 4 * co, 1, 1
+        self.stride, self.pad_h, self.pad_w = 1, 0, 0
+        self.relu = relu
+        self.convt = True
+        self.co = co
+
+
+def conv2d(x, pc, res=None, res_mode=RES_NONE, out=None, out_up=1, out_coff=0):
+    """x f32[N,H,W,Cin] -> f32[N,Ho*,Wo*,C] (new tensor unless `out` is given for in-place concat)."""
+    _require_cuda(x, "conv2d")
+    N, H, W, Cin = x.shape
+    assert Cin == pc.cin, (Cin, pc.cin)
+    Ho = (H + 2 * pc.pad_h - pc.kh) // pc.stride + 1
+    Wo = (W + 2 * pc.pad_w - pc.kw) // pc.stride + 1
+    co_real = pc.co if pc.convt else pc.cout
+    scale = 2 if pc.convt else out_up
+    if out is None:
+        out = torch.empty((N, Ho * scale, Wo * scale, co_real), dtype=torch.float32, device=x.device)
+    d = ConvDesc(N, H, W, Cin, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad_h, pc.pad_w, Ho, Wo,
+                 int(pc.relu), res_mode, out_up, out.shape[3], out_coff, int(pc.convt))
+    L = _lib.lib()
+    _lib.check(L.ptocr_conv2d_f32(C.byref(d), _lib.ptr(x), _lib.ptr(pc.w), _lib.ptr(pc.b),
+                                  _lib.ptr(res) if res is not None else C.c_void_p(0), _lib.ptr(out),
+                                  _lib.cur_stream()), "ptocr_conv2d_f32")
+    return out
+
+
+def nchw_to_nhwc(x, cpad):
+    _require_cuda(x, "nchw_to_nhwc")
+    x = x.contiguous().float()
+    N, Cc, H, W = x.shape
+    y = torch.empty((N, H, W, cpad), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().ptocr_nchw_to_nhwc_f32(_lib.ptr(x), _lib.ptr(y), N, Cc, H, W, cpad, _lib.cur_stream()),
+               "ptocr_nchw_to_nhwc_f32")
+    return y
+
+
+def nhwc_to_nchw(x):
+    _require_cuda(x, "nhwc_to_nchw")
+    N, H, W, Cc = x.shape
+    y = torch.empty((N, Cc, H, W), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().ptocr_nhwc_to_nchw_f32(_lib.ptr(x), _lib.ptr(y), N, Cc, H, W, _lib.cur_stream()),
+               "ptocr_nhwc_to_nchw_f32")
+    return y
+
+
+def maxpool2d(x, k, s, p):
+    _require_cuda(x, "maxpool2d")
+    kh, kw = (k, k) if isinstance(k, int) else k
+    sh, sw = (s, s) if isinstance(s, int) else s
+    ph, pw = (p, p) if isinstance(p, int) else p
+    N, H, W, Cc = x.shape
+    Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+    y = torch.empty((N, Ho, Wo, Cc), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().ptocr_maxpool2d_f32(_lib.ptr(x), _lib.ptr(y), N, H, W, Cc, kh, kw, sh, sw, ph, pw, Ho, Wo,
+                                              _lib.cur_stream()), "ptocr_maxpool2d_f32")
+    return y
+
+
+def convt2x2_sigmoid(x, w4, bias):
+    _require_cuda(x, "convt2x2_sigmoid")
+    N, H, W, Cc = x.shape
+    y = torch.empty((N, 1, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().ptocr_convt2x2_sigmoid_f32(_lib.ptr(x), _lib.ptr(w4), C.c_float(bias), _lib.ptr(y), N, H, W, Cc,
+                                                     _lib.cur_stream()), "ptocr_convt2x2_sigmoid_f32")
+    return y
+
+
+class PackedModule(torch.nn.Module):
+    """Mixin: packed (BN-folded, kernel-layout) weights are rebuilt whenever a parameter/buffer changed
+    (load_state_dict, .to(device), in-place edits) -- detected through tensor versions and device."""
+
+    def _sig(self):
+        sig = []
+        for t in list(self.parameters()) + list(self.buffers()):
+            sig.append((t._version, t.data_ptr(), str(t.device)))
+        return tuple(sig)
+
+    def packed(self):
+        sig = self._sig()
+        if getattr(self, "_packed_sig", None) != sig:
+            dev = next(self.parameters()).device
+            if dev.type != "cuda":
+                raise RuntimeError("pytorchocr_amd: model is on %s; move it to a cuda (ROCm) device -- no CPU fallback" % dev)
+            self._packed = self._pack(dev)
+            self._packed_sig = sig
+        return self._packed
+
+    def _check_eval(self):
+        if self.training:
+            raise NotImplementedError("pytorchocr_amd implements the inference (eval) hot path only; call .eval()")

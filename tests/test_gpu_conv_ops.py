@@ -1,0 +1,144 @@
+"""HIP conv / pool / layout kernels against plain torch fp32 CPU ops on the same seeded inputs (-m gpu)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _rand(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(*shape, generator=g) * 2 - 1
+
+
+CASES = [
+    # N, Cin, H, W, Cout, k, stride, pad
+    (2, 64, 20, 36, 64, 3, 1, 1),
+    (1, 64, 23, 40, 128, 3, 2, 1),
+    (2, 128, 12, 20, 128, 3, 1, 1),
+    (1, 64, 16, 24, 128, 1, 2, 0),
+    (1, 512, 5, 7, 256, 1, 1, 0),
+    (3, 256, 9, 11, 64, 3, 1, 1),
+    (1, 256, 6, 10, 512, 3, 2, 1),
+    (1, 512, 2, 40, 512, 2, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_bn_relu_matches_torch(case):
+    from pytorchocr_amd.modeling import ops
+    N, Cin, H, W, Cout, k, s, p = case
+    dev = _dev()
+    conv = nn.Conv2d(Cin, Cout, k, s, p, bias=True)
+    bn = nn.BatchNorm2d(Cout).eval()
+    with torch.no_grad():
+        conv.weight.copy_(_rand(Cout, Cin, k, k, seed=1) * (3.0 / (Cin * k * k)) ** 0.5)
+        conv.bias.copy_(_rand(Cout, seed=2) * 0.1)
+        bn.weight.copy_(_rand(Cout, seed=3) * 0.4 + 1); bn.bias.copy_(_rand(Cout, seed=4) * 0.2)
+        bn.running_mean.copy_(_rand(Cout, seed=5) * 0.2); bn.running_var.copy_(_rand(Cout, seed=6) * 0.5 + 1)
+    x = _rand(N, Cin, H, W, seed=7)
+    with torch.no_grad():
+        ref = F.relu(bn(conv(x)))
+    pc = ops.PackedConv(conv, bn, dev, relu=True)
+    y = ops.conv2d(_nhwc(x).to(dev), pc)
+    torch.cuda.synchronize()
+    got = y.cpu().permute(0, 3, 1, 2)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_stem_7x7_cin3():
+    from pytorchocr_amd.modeling import ops
+    dev = _dev()
+    conv = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+    bn = nn.BatchNorm2d(64).eval()
+    with torch.no_grad():
+        conv.weight.copy_(_rand(64, 3, 7, 7, seed=1) * 0.15)
+        bn.running_mean.copy_(_rand(64, seed=5) * 0.2); bn.running_var.copy_(_rand(64, seed=6) * 0.5 + 1)
+    x = _rand(2, 3, 64, 96, seed=7)
+    with torch.no_grad():
+        ref = F.relu(bn(conv(x)))
+    pc = ops.PackedConv(conv, bn, dev, relu=True, cin_pad=4)
+    x4 = ops.nchw_to_nhwc(x.to(dev), 4)
+    assert torch.equal(x4.cpu()[..., :3], _nhwc(x)) and float(x4[..., 3].abs().max()) == 0.0
+    y = ops.conv2d(x4, pc)
+    got = y.cpu().permute(0, 3, 1, 2)
+    assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_residual_and_upsample_epilogues():
+    from pytorchocr_amd.modeling import ops
+    dev = _dev()
+    conv = nn.Conv2d(64, 64, 3, 1, 1, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(_rand(64, 64, 3, 3, seed=1) * 0.07)
+    x = _rand(2, 64, 12, 20, seed=2)
+    res = _rand(2, 64, 12, 20, seed=3)
+    small = _rand(2, 64, 6, 10, seed=4)
+    with torch.no_grad():
+        ref1 = F.relu(conv(x) + res)
+        ref2 = F.relu(conv(x)) + F.interpolate(small, scale_factor=2, mode="nearest")
+        ref3 = F.interpolate(F.relu(conv(x)), scale_factor=4, mode="nearest")
+    pc = ops.PackedConv(conv, None, dev, relu=True)
+    xd = _nhwc(x).to(dev)
+    y1 = ops.conv2d(xd, pc, res=_nhwc(res).to(dev), res_mode=ops.RES_ADD_PRE_RELU)
+    y2 = ops.conv2d(xd, pc, res=_nhwc(small).to(dev), res_mode=ops.RES_ADD_UP2_POST_RELU)
+    big = torch.full((2, 48, 80, 256), -7.0, device=dev)
+    ops.conv2d(xd, pc, out=big, out_up=4, out_coff=128)
+    for got, ref in ((y1, ref1), (y2, ref2), (big[..., 128:192], ref3)):
+        assert (got.cpu().permute(0, 3, 1, 2) - ref).abs().max().item() <= 2e-5
+    assert float((big[..., :128] + 7).abs().max()) == 0 and float((big[..., 192:] + 7).abs().max()) == 0
+
+
+def test_convtranspose_and_head_tail():
+    from pytorchocr_amd.modeling import ops
+    dev = _dev()
+    t3 = nn.ConvTranspose2d(64, 64, 2, 2)
+    bn = nn.BatchNorm2d(64).eval()
+    t6 = nn.ConvTranspose2d(64, 1, 2, 2)
+    with torch.no_grad():
+        t3.weight.copy_(_rand(64, 64, 2, 2, seed=1) * 0.2); t3.bias.copy_(_rand(64, seed=2) * 0.1)
+        bn.running_mean.copy_(_rand(64, seed=5) * 0.2); bn.running_var.copy_(_rand(64, seed=6) * 0.5 + 1)
+        t6.weight.copy_(_rand(64, 1, 2, 2, seed=3) * 0.3); t6.bias.copy_(_rand(1, seed=4))
+    x = _rand(2, 64, 9, 13, seed=7)
+    with torch.no_grad():
+        mid = F.relu(bn(t3(x)))
+        ref = torch.sigmoid(t6(mid))
+    pt = ops.PackedConvT2x2(t3, bn, dev, relu=True)
+    y = ops.conv2d(_nhwc(x).to(dev), pt)
+    assert (y.cpu().permute(0, 3, 1, 2) - mid).abs().max().item() <= 2e-5
+    w4 = t6.weight.detach()[:, 0].permute(1, 2, 0).reshape(4, -1).contiguous().to(dev)
+    maps = ops.convt2x2_sigmoid(y, w4, float(t6.bias[0]))
+    assert maps.shape == ref.shape
+    assert (maps.cpu() - ref).abs().max().item() <= 1e-5
+
+
+def test_maxpool_variants():
+    from pytorchocr_amd.modeling import ops
+    dev = _dev()
+    x = _rand(2, 64, 17, 23, seed=1)
+    for k, s, p in ((3, 2, 1), (2, 2, 0), ((2, 2), (2, 1), (0, 1))):
+        ref = F.max_pool2d(x, k, s, p)
+        got = ops.maxpool2d(_nhwc(x).to(dev), k, s, p).cpu().permute(0, 3, 1, 2)
+        assert torch.equal(got, ref)
+
+
+def test_layout_roundtrip():
+    from pytorchocr_amd.modeling import ops
+    dev = _dev()
+    x = _rand(2, 70, 9, 13, seed=1).to(dev)
+    y = ops.nchw_to_nhwc(x, 72)
+    assert torch.equal(y[..., :70].permute(0, 3, 1, 2), x)
+    z = ops.nhwc_to_nchw(y)
+    assert torch.equal(z[:, :70], x)

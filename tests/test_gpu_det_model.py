@@ -1,0 +1,69 @@
+"""DBNet-r18 on the HIP engine against outputs of the REFERENCE model (tests/golden) and the oracle (-m gpu).
+Tolerance from BASELINE.json north_star: fp32 probability maps within 1e-4."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from pytorchocr_amd.utils.synth import synth_images, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+
+DET_R18 = dict(model_type="det", algorithm="DB", Transform=None,
+               Backbone=dict(name="ResNet", layers=18, pretrained=False),
+               Neck=dict(name="FPN", out_channels=256, mode="DB", use_asf=False, attention_type="scale_channel_spatial"),
+               Head=dict(name="DBHead", k=50))
+
+
+def _model(contract, **extra):
+    from pytorchocr_amd.modeling.architectures import build_model
+    cfg = dict(DET_R18, **extra)
+    m = build_model(cfg)
+    sd = synth_state_dict(contract["det_r18_db"])
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return m.to("cuda:0").eval()
+
+
+def test_maps_and_features_match_reference_small(gold_dir, contract):
+    g = np.load(os.path.join(gold_dir, "det_r18_db_1x3x64x96.npz"))
+    m = _model(contract, return_all_feats=True)
+    x = torch.from_numpy(synth_images(1, 3, 64, 96, seed=int(g["seed"]))).to("cuda:0")
+    with torch.no_grad():
+        y = m(x)
+    for k, f in zip(("c2", "c3", "c4", "c5"), y["backbone_out"]):
+        err = np.abs(f.cpu().numpy() - g[k]).max()
+        assert err <= 1e-4 * max(1.0, np.abs(g[k]).max()), (k, err)
+    assert np.abs(y["neck_out"].cpu().numpy() - g["neck"]).max() <= 1e-4 * np.abs(g["neck"]).max()
+    maps = y["maps"].cpu().numpy()
+    assert maps.shape == g["maps"].shape and maps.dtype == np.float32
+    assert np.abs(maps - g["maps"]).max() <= 1e-4
+
+
+def test_maps_match_reference_batch(gold_dir, contract):
+    g = np.load(os.path.join(gold_dir, "det_r18_db_2x3x96x160.npz"))
+    m = _model(contract)
+    x = torch.from_numpy(synth_images(2, 3, 96, 160, seed=int(g["seed"]))).to("cuda:0")
+    with torch.no_grad():
+        y = m(x)
+    assert set(y.keys()) == {"maps"}
+    assert np.abs(y["maps"].cpu().numpy() - g["maps"]).max() <= 1e-4
+
+
+def test_full_size_against_oracle(contract):
+    """BASELINE config size 736x1280 (one image): HIP maps vs the torch-fp32 oracle on the same input."""
+    from oracle import model_oracle
+    m = _model(contract)
+    xs = synth_images(1, 3, 736, 1280, seed=3)
+    with torch.no_grad():
+        y = m(torch.from_numpy(xs).to("cuda:0"))["maps"].cpu().numpy()
+    ref = model_oracle.dbnet_r18_forward(synth_state_dict(contract["det_r18_db"]), torch.from_numpy(xs))["maps"].numpy()
+    assert y.shape == (1, 1, 736, 1280)
+    assert np.abs(y - ref).max() <= 1e-4
+
+
+def test_cpu_input_fails_loudly(contract):
+    m = _model(contract)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 64, 64))
