@@ -88,6 +88,12 @@ int ptocr_db_postprocess(ptocr_dbpost_t h, const float *d_maps, const uint8_t *d
                          int use_padding_resize, int16_t *h_boxes, int max_boxes, int32_t *h_counts,
                          int32_t *h_flags, void *stream);
 
+/* Inspection hook for the parity tests: per-candidate records of the LAST ptocr_db_postprocess call for image `img`
+ * (synchronises the device).  h_results: 1000 x {int status; int box[8]; float score; float rect[5]; int npix;
+ * float distance;}  h_cands: 1000 x {int trigger_pixel; int is_hole;}  h_info: 1000 x {int npts; int off;
+ * short xmin, xmax, ymin, ymax;}  status: 0 box, 1 <=2 points, 2 ssid<3, 3 score<box_thresh, 4 unclip<1.001, 5 ssid<5. */
+int ptocr_dbpost_debug_results(ptocr_dbpost_t h, int img, int32_t *h_total, void *h_results, void *h_cands, void *h_info);
+
 /* ---- recognition ---------------------------------------------------------------------------------------- */
 /* y[M,Nout] = x[M,K] @ w[Nout,K]^T + bias; K % 32 == 0, Nout % 64 == 0 (pad rows of w with zeros) */
 int ptocr_linear_f32(const float *d_x, const float *d_w, const float *d_bias, float *d_y, int M, int K, int Nout,

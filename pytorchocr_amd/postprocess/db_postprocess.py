@@ -1,0 +1,126 @@
+"""DBPostProcess on the MI355X.
+
+Mirror of reference `DBPostProcess` (pytocr/postprocess/db_postprocess.py:10-74) with cpp_speedup=True
+semantics, i.e. the behaviour of the pybind11 extension db_postprocess_fast (src/db_postprocess.cpp:231-358):
+hard-coded min_size 3 / max_candidates 1000, long-side size filter, polygon score on the raw contour with
+4-connected edges, roundf rescale, scores reported as 1.0.  The whole batch runs on the device through
+`ptocr_db_postprocess`; only int16 boxes and counts come back to the host.
+
+`db_postprocess(pred, bitmap, ...)` below keeps the exact signature of the pybind function the reference
+binds (src/db_postprocess.cpp:362-370) for callers that used the extension directly.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+MAX_CANDIDATES = 1000
+
+
+class _Workspace:
+    def __init__(self):
+        self.handle = None
+        self.dims = (0, 0, 0)
+
+    def get(self, n, h, w):
+        mn, mh, mw = self.dims
+        if self.handle is None or n > mn or h > mh or w > mw or h * w > mh * mw:
+            self.close()
+            dims = (max(n, mn), max(h, mh), max(w, mw))
+            hd = C.c_void_p()
+            _lib.check(_lib.lib().ptocr_dbpost_create(C.byref(hd), *dims), "ptocr_dbpost_create")
+            self.handle, self.dims = hd, dims
+        return self.handle
+
+    def close(self):
+        if self.handle is not None:
+            _lib.lib().ptocr_dbpost_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_ws = _Workspace()
+
+
+def device_boxes(maps, src_wh, thresh, box_thresh, unclip_ratio, bitmap=None, use_padding_resize=False):
+    """maps: f32 cuda tensor [N,H,W]; src_wh: int array [N,2] (src_w, src_h); bitmap: optional u8 cuda tensor [N,H,W].
+    -> (list of int16[K,4,2] per image, flags int32[N])"""
+    if not maps.is_cuda:
+        raise RuntimeError("device_boxes: maps must be on a cuda (ROCm) device; there is no CPU fallback")
+    maps = maps.contiguous().float()
+    n, h, w = maps.shape
+    hd = _ws.get(n, h, w)
+    src = np.ascontiguousarray(src_wh, np.int32).reshape(n, 2)
+    boxes = np.empty((n, MAX_CANDIDATES, 4, 2), np.int16)
+    counts = np.zeros(n, np.int32)
+    flags = np.zeros(n, np.int32)
+    bptr = C.c_void_p(0)
+    if bitmap is not None:
+        if not bitmap.is_cuda:
+            raise RuntimeError("device_boxes: bitmap must be on the same cuda device")
+        bitmap = bitmap.contiguous().to(torch.uint8)
+        bptr = _lib.ptr(bitmap)
+    _lib.check(_lib.lib().ptocr_db_postprocess(
+        hd, _lib.ptr(maps), bptr, n, h, w, C.c_float(thresh), C.c_float(box_thresh), C.c_float(unclip_ratio),
+        src.ctypes.data_as(C.c_void_p), int(bool(use_padding_resize)), boxes.ctypes.data_as(C.c_void_p), MAX_CANDIDATES,
+        counts.ctypes.data_as(C.c_void_p), flags.ctypes.data_as(C.c_void_p), _lib.cur_stream()), "ptocr_db_postprocess")
+    return [boxes[i, :counts[i]].copy() for i in range(n)], flags
+
+
+class DBPostProcess(object):
+    """The post process for Differentiable Binarization (DB) -- same constructor and call contract as the reference."""
+
+    def __init__(self, thresh=0.3, box_thresh=0.5, max_candidates=1000, unclip_ratio=1.5, use_dilation=False,
+                 score_mode="poly", cpp_speedup=False, out_polygon=False, **kwargs):
+        self.thresh = thresh
+        self.box_thresh = box_thresh
+        self.max_candidates = max_candidates
+        self.unclip_ratio = unclip_ratio
+        self.min_size = 3
+        self.out_polygon = out_polygon
+        self.score_mode = score_mode
+        assert score_mode in ["box", "poly"], "Score mode must be in [box, poly] but got: {}".format(score_mode)
+        self.use_dilation = use_dilation
+        self.cpp_speedup = cpp_speedup
+        self.last_flags = None
+        if not cpp_speedup:
+            raise NotImplementedError(
+                "pytorchocr_amd DBPostProcess implements the cpp_speedup=True semantics (the reference's C++ extension, "
+                "what configs/det/det_r18_db.yml runs); the pure-Python branch differs from it (short-side filter, "
+                "np.round, 8-connected fill) and is not built")
+        if out_polygon:
+            raise NotImplementedError("out_polygon=True needs cpp_speedup=False in the reference; not on the hot path")
+        if use_dilation:
+            raise NotImplementedError("use_dilation=True (cv2.dilate 2x2 before the C++ call) is not built yet")
+
+    def __call__(self, outs_dict, shape_list, use_padding_resize=False):
+        pred = outs_dict["maps"]
+        if isinstance(pred, np.ndarray):
+            pred = torch.from_numpy(np.ascontiguousarray(pred, np.float32))
+        if not pred.is_cuda:
+            # host buffers are accepted like the reference does, but the work still happens on the GPU
+            pred = pred.to("cuda:%d" % torch.cuda.current_device())
+        pred = pred[:, 0, :, :]
+        shape_list = np.asarray(shape_list)
+        src_wh = np.stack([shape_list[:, 1].astype(np.int64), shape_list[:, 0].astype(np.int64)], axis=1)   # (src_w, src_h)
+        boxes, flags = device_boxes(pred, src_wh, self.thresh, self.box_thresh, self.unclip_ratio,
+                                    use_padding_resize=use_padding_resize)
+        self.last_flags = flags
+        return [{"points": b, "scores": [1.0] * len(b)} for b in boxes]
+
+
+def db_postprocess(pred, bitmap, box_thresh, det_db_unclip_ratio, src_w, src_h, use_padding_resize=False):
+    """Drop-in for the pybind11 `db_postprocess.db_postprocess` (reference src/db_postprocess.cpp:319-370):
+    pred f32[H,W], bitmap u8[H,W] (host arrays) -> list[K][4][2] of int."""
+    p = torch.from_numpy(np.ascontiguousarray(pred, np.float32))[None].cuda()
+    b = torch.from_numpy(np.ascontiguousarray(bitmap).astype(np.uint8))[None].cuda()
+    boxes, _ = device_boxes(p, [[src_w, src_h]], 0.0, box_thresh, det_db_unclip_ratio, bitmap=b,
+                            use_padding_resize=use_padding_resize)
+    return boxes[0].astype(np.int64).tolist()

@@ -127,3 +127,52 @@ def synth_text_lines(n, h, w, seed=2022):
     u8 = np.clip(base * np.float32(224.0) + noise * np.float32(32.0), 0, 255).astype(np.uint8)
     x = u8.astype(np.float32) / np.float32(255.0)
     return ((x - np.float32(0.5)) / np.float32(0.5)).astype(np.float32)
+
+
+def synth_prob_maps(n, h, w, seed=0, noise=0.0):
+    """Text-like probability maps f32[n,h,w] for the post-process: text lines laid out in jittered rows
+    (about 150 per 736x1280 map: 20-400 px long, 8-40 px high, small rotations, some steep, some touching,
+    some with holes), soft edges, values kept >= 2e-3 away from 0.3 and 0.5
+    (SURVEY.md 8d 'post-process stress input')."""
+    out = np.zeros((n, h, w), np.float32)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    for i in range(n):
+        r = uniform01(4096 * 8, seed * 7919 + i * 104729 + 17).reshape(4096, 8)
+        m = np.zeros((h, w), np.float32)
+        qi = 0
+        y0 = 6.0
+        while y0 < h - 8 and qi < 4000:
+            row_h = 10 + r[qi, 0] * 34
+            qi += 1
+            x0 = r[qi, 1] * 40
+            while x0 < w - 10 and qi < 4000:
+                q = r[qi]
+                qi += 1
+                L = 20 + q[2] * q[2] * 380
+                T = min(row_h, 8 + q[3] * 32)
+                th = (q[4] - 0.5) * min(0.25, 16.0 / L) if (q[5] < 0.85 or L > 70) else (q[4] - 0.5) * 1.6
+                cx, cy = x0 + L / 2, y0 + row_h / 2 + (q[6] - 0.5) * 6
+                c, s_ = np.float32(np.cos(th)), np.float32(np.sin(th))
+                ys, ye = int(max(0, cy - L / 2 - T - 3)), int(min(h, cy + L / 2 + T + 3))
+                xs, xe = int(max(0, cx - L / 2 - T - 3)), int(min(w, cx + L / 2 + T + 3))
+                if ye > ys and xe > xs:
+                    X, Y = xx[ys:ye, xs:xe], yy[ys:ye, xs:xe]
+                    u = (X - cx) * c + (Y - cy) * s_
+                    v = -(X - cx) * s_ + (Y - cy) * c
+                    d = np.maximum(np.abs(u) - L / 2, np.abs(v) - T / 2)
+                    base = 0.58 + 0.4 * q[7]
+                    val = (base - (base - 0.34) * np.clip((d + 3.0) / 3.0, 0, 1)).astype(np.float32)
+                    val[d > 0] = 0
+                    if q[7] > 0.8 and T > 12:                   # a hole in the middle of the line
+                        val[(np.abs(u) < L / 6) & (np.abs(v) < T / 5)] = 0.05
+                    m[ys:ye, xs:xe] = np.maximum(m[ys:ye, xs:xe], val)
+                gap = -2 if q[0] > 0.93 else 8 + q[1] * 30       # now and then two lines touch
+                x0 += L + gap
+            y0 += row_h + 10 + r[qi % 4096, 2] * 8
+        if noise > 0:
+            m = np.clip(m + (uniform01(h * w, seed * 31 + i).reshape(h, w) - 0.5) * np.float32(noise), 0, 1)
+        for t in (0.3, 0.5):
+            near = np.abs(m - np.float32(t)) < 2e-3
+            m[near] = np.float32(t + 4e-3)
+        out[i] = m.astype(np.float32)
+    return out

@@ -1,0 +1,155 @@
+"""GPU DB post-process against the C oracle on identical probability maps: boxes bit-exact (-m gpu).
+
+Candidates whose unclip distance is < 0.75 px are the documented exception (Clipper's integer union clean-up of
+sub-pixel slivers is not reproduced): the GPU flags them (flags bit 0) and they are compared against the
+restated offset instead of the real Clipper."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dbpost
+from pytorchocr_amd.utils.synth import synth_prob_maps, uniform01
+
+pytestmark = pytest.mark.gpu
+
+
+class Res(C.Structure):
+    _fields_ = [("status", C.c_int), ("box", C.c_int * 8), ("score", C.c_float), ("rect", C.c_float * 5),
+                ("npix", C.c_int), ("distance", C.c_float)]
+
+
+class Cand(C.Structure):
+    _fields_ = [("p", C.c_int), ("is_hole", C.c_int)]
+
+
+class Info(C.Structure):
+    _fields_ = [("npts", C.c_int), ("off", C.c_int), ("xmin", C.c_short), ("xmax", C.c_short), ("ymin", C.c_short), ("ymax", C.c_short)]
+
+
+def _gpu(maps, src_wh, thresh=0.3, box_thresh=0.5, ratio=1.7):
+    from pytorchocr_amd.postprocess.db_postprocess import device_boxes
+    return device_boxes(torch.from_numpy(maps).cuda(), src_wh, thresh, box_thresh, ratio)
+
+
+def _debug(img, W):
+    from pytorchocr_amd import _lib
+    from pytorchocr_amd.postprocess import db_postprocess as m
+    tot = C.c_int(0)
+    res = (Res * 1000)(); cands = (Cand * 1000)(); info = (Info * 1000)()
+    _lib.check(_lib.lib().ptocr_dbpost_debug_results(m._ws.handle, img, C.byref(tot), res, cands, info))
+    return tot.value, res, cands, info
+
+
+def _compare(maps, src_wh, thresh=0.3, box_thresh=0.5, ratio=1.7, strict=True):
+    n, H, W = maps.shape
+    got, flags = _gpu(maps, src_wh, thresh, box_thresh, ratio)
+    dbpost.use_reference_clipper(False)
+    nthin = 0
+    for i in range(n):
+        bm = dbpost.binarize(maps[i], thresh)
+        exp, dbg, ncont = dbpost.boxes_from_bitmap(maps[i], bm, box_thresh, ratio, src_wh[i][0], src_wh[i][1], True)
+        tot, res, cands, info = _debug(i, W)
+        msg = ""
+        if tot != ncont:
+            msg = "image %d: %d borders on the GPU, %d in the oracle" % (i, tot, ncont)
+        else:
+            for k in range(min(tot, 1000)):
+                d, r = dbg[k], res[k]
+                trig = d.trig_y * W + d.trig_x
+                if cands[k].p != trig or cands[k].is_hole != d.is_hole or info[k].npts != d.npts:
+                    msg = "image %d border %d: start/kind/npts (%d,%d,%d) vs oracle (%d,%d,%d)" % (
+                        i, k, cands[k].p, cands[k].is_hole, info[k].npts, trig, d.is_hole, d.npts)
+                    break
+                if r.status != d.status:
+                    msg = "image %d border %d: status %d vs oracle %d (score %r vs %r, rect %r vs %r)" % (
+                        i, k, r.status, d.status, r.score, d.score, list(r.rect), list(d.rect))
+                    break
+                if d.status == 0 and list(r.box) != list(d.box):
+                    msg = "image %d border %d: box %r vs oracle %r" % (i, k, list(r.box), list(d.box))
+                    break
+                if d.status in (0, 4, 5) and d.distance < 0.75:
+                    nthin += 1
+        assert not msg, msg
+        assert got[i].dtype == np.int16 and got[i].shape == (len(exp), 4, 2)
+        assert np.array_equal(got[i].astype(np.int32), exp), "image %d: boxes differ" % i
+        assert bool(flags[i] & 1) == any(d.status in (0, 4, 5) and d.distance < 0.75 for d in dbg)
+    return got, flags, nthin
+
+
+def test_text_like_maps_small():
+    maps = synth_prob_maps(3, 96, 160, seed=5)
+    _compare(maps, [[160, 96], [320, 200], [97, 61]])
+
+
+def test_text_like_maps_full_size():
+    """BASELINE size 736x1280, batch of 4 (about 130 boxes per image, holes, touching lines)."""
+    maps = synth_prob_maps(4, 736, 1280, seed=1)
+    got, flags, _ = _compare(maps, [[1280, 736]] * 3 + [[1920, 1080]])
+    assert min(len(g) for g in got) > 50
+
+
+def test_noisy_maps_many_tiny_borders():
+    """Speckle noise: thousands of 1..10-pixel components, holes, single pixels, the 1000-candidate cut."""
+    for seed, (h, w) in enumerate(((64, 96), (128, 160), (200, 333))):
+        m = uniform01(h * w, 100 + seed).reshape(1, h, w).astype(np.float32)
+        m = np.where(np.abs(m - 0.3) < 2e-3, 0.31, m).astype(np.float32)
+        _compare(m, [[w, h]], thresh=0.3 + 0.2 * seed, box_thresh=0.5)
+
+
+def test_blobs_with_noise_and_rescale():
+    maps = synth_prob_maps(2, 160, 224, seed=9, noise=0.6)
+    _compare(maps, [[448, 320], [224, 160]])
+
+
+def test_edge_cases():
+    h, w = 40, 70
+    cases = []
+    z = np.zeros((h, w), np.float32); cases.append(z.copy())                       # empty
+    o = np.full((h, w), 0.9, np.float32); cases.append(o.copy())                   # everything foreground
+    a = z.copy(); a[0, 0] = 0.9; a[h - 1, w - 1] = 0.9; a[5, 5:8] = 0.9; cases.append(a)   # single pixels, 3-px line
+    b = z.copy(); b[10:30, 10:60] = 0.8; b[15:25, 20:50] = 0.1; b[18:22, 30:40] = 0.95; cases.append(b)   # ring + island
+    c = z.copy()
+    for k in range(25):
+        c[5 + k, 5 + k] = 0.9; c[5 + k, 6 + k] = 0.9                                # 2-px wide diagonal
+    cases.append(c)
+    d = o.copy(); d[::2, ::2] = 0.0; cases.append(d)                               # lattice of 1-px holes
+    e = z.copy(); e[3:37, 3] = 0.9; e[3:37, 66] = 0.9; e[3, 3:67] = 0.9; e[36, 3:67] = 0.9; cases.append(e)   # thin frame
+    maps = np.stack(cases)
+    _compare(maps, [[w, h]] * len(cases))
+
+
+def test_wide_component_uses_global_mask_slot():
+    h, w = 300, 1280
+    m = np.zeros((1, h, w), np.float32)
+    yy, xx = np.mgrid[0:h, 0:w]
+    band = np.abs(yy - (40 + 0.17 * xx)) < 14
+    m[0][band] = 0.8
+    m[0][(np.abs(yy - 150) < 3) & (xx > 600) & (xx < 700)] = 0.1
+    _compare(m, [[w, h]])
+
+
+def test_pybind_signature_shim():
+    from pytorchocr_amd.postprocess.db_postprocess import db_postprocess
+    m = synth_prob_maps(1, 96, 160, seed=2)[0]
+    bm = dbpost.binarize(m, 0.3)
+    out = db_postprocess(m, bm, 0.5, 1.7, 160, 96, False)
+    exp = dbpost.boxes_from_bitmap(m, bm, 0.5, 1.7, 160, 96)
+    assert isinstance(out, list) and out == exp.tolist()
+
+
+def test_dbpostprocess_class_contract():
+    from pytorchocr_amd.postprocess import build_post_process
+    post = build_post_process(dict(name="DBPostProcess", thresh=0.3, box_thresh=0.5, max_candidates=1000, unclip_ratio=1.7,
+                                   score_mode="poly", cpp_speedup=True, out_polygon=False), dict(use_gpu=True, seed=2022))
+    maps = synth_prob_maps(2, 96, 160, seed=4)
+    shape_list = np.array([[96, 160, 1.0, 1.0], [200, 320, 0.48, 0.5]])
+    for pred in (torch.from_numpy(maps[:, None]).cuda(), maps[:, None]):
+        res = post({"maps": pred}, shape_list)
+        assert len(res) == 2
+        for i, r in enumerate(res):
+            bm = dbpost.binarize(maps[i], 0.3)
+            exp = dbpost.boxes_from_bitmap(maps[i], bm, 0.5, 1.7, int(shape_list[i][1]), int(shape_list[i][0]))
+            assert r["points"].dtype == np.int16 and np.array_equal(r["points"], exp.astype(np.int16))
+            assert r["scores"] == [1.0] * len(exp)
