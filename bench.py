@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json headline metric on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = one pass of the detection hot path over one batch that is already resident in HBM:
+DBNet-r18 fp32 forward (HIP MFMA convs) on f32[32,3,736,1280] -> probability maps -> DB post-process on the
+device -> int16 boxes on the host (BASELINE.json configs[1]).  With N > 1 every rank (one process per GPU)
+runs the same per-GPU batch on its own images (weak scaling, no data-path collective); the only collective is
+the RCCL broadcast of the weights from rank 0 before the timed region.  Rank 0 prints ONE JSON line.
+
+--workload crnn measures BASELINE.json configs[2] instead (CRNN text-lines/sec, batch 512 of 32x320 crops).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
+DET_GFLOP_PER_IMG = 114.195        # SURVEY.md 8d / BASELINE.md: DBNet-r18 @ 3x736x1280 (2*MAC over conv/deconv)
+DET_TAIL_GFLOP_PER_IMG = 0.12      # last ConvTranspose (64->1) runs in the memory-bound head-tail kernel, not on MFMA
+CRNN_GFLOP_PER_LINE = 4.980
+
+DET_R18 = dict(model_type="det", algorithm="DB", Transform=None,
+               Backbone=dict(name="ResNet", layers=18, pretrained=False),
+               Neck=dict(name="FPN", out_channels=256, mode="DB", use_asf=False, attention_type="scale_channel_spatial"),
+               Head=dict(name="DBHead", k=50))
+DET_POST = dict(name="DBPostProcess", thresh=0.3, box_thresh=0.5, max_candidates=1000, unclip_ratio=1.7,
+                score_mode="poly", cpp_speedup=True, out_polygon=False)
+
+
+def crnn_cfg(nclass=6624):
+    return dict(model_type="rec", algorithm="CRNN", in_channels=1, Transform=None,
+                Backbone=dict(name="VGG", model_name="v1", scale=1.0, pretrained=False, ckpt_path=None),
+                Neck=dict(name="SequenceEncoder", encoder_type="rnn", hidden_size=256),
+                Head=dict(name="CTCHead", out_channels=nclass))
+
+
+def dist_env():
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    return rank, local, world
+
+
+def load_contract(name):
+    with open(os.path.join(ROOT, "tests", "golden", "state_dict_contract.json")) as f:
+        c = json.load(f)[name]
+    return {k: (tuple(s), d) for k, (s, d) in c.items()}
+
+
+def build_and_sync_weights(cfg, contract_name, device, rank, world):
+    """Random-init weights of the named architecture: rank 0 makes them, RCCL broadcast puts them on every GPU."""
+    import torch.distributed as dist
+    from pytorchocr_amd.modeling.architectures import build_model
+    from pytorchocr_amd.utils.synth import synth_state_dict
+    model = build_model(cfg)
+    if rank == 0:
+        sd = synth_state_dict(load_contract(contract_name))
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model = model.to(device).eval()
+    if world > 1:
+        from pytorchocr_amd.parallel import broadcast_model_
+        broadcast_model_(model, src=0)
+    return model
+
+
+def det_cpu_baseline(n_img, H, W):
+    """The oracle (CPU restatement of the reference path: torch-CPU fp32 forward + C post-process with
+    cpp_speedup=True semantics) on a bounded sample of the same workload."""
+    from oracle import dbpost, model_oracle
+    from pytorchocr_amd.utils.synth import synth_images, synth_prob_maps, synth_state_dict
+    torch.set_num_threads(min(16, os.cpu_count() or 1))            # the GPU box's CPU share for one GPU is 16 cores
+    sd = synth_state_dict(load_contract("det_r18_db"))
+    sd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    x = torch.from_numpy(synth_images(1, 3, H, W, seed=2022))
+    stress = synth_prob_maps(1, H, W, seed=2022)[0]
+    model_oracle.dbnet_r18_forward(sd, x[:, :, :64, :64])          # warm-up of the thread pool
+    t_model = t_post = 0.0
+    for _ in range(n_img):                                         # batch 1 each, as infer_det.py:85-103 does
+        t0 = time.perf_counter()
+        maps = model_oracle.dbnet_r18_forward(sd, x)["maps"].numpy()
+        t1 = time.perf_counter()
+        for m in (maps[0, 0], stress):                             # the net's own map + the text-like stress map
+            bm = dbpost.binarize(m, 0.3)
+            dbpost.boxes_from_bitmap(m, bm, 0.5, 1.7, W, H)
+        t2 = time.perf_counter()
+        t_model += t1 - t0
+        t_post += (t2 - t1) / 2
+    total = t_model + t_post
+    return {"value": round(n_img / total, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d images %dx%d, batch 1 each: torch-CPU fp32 forward %.3f s/img + C post-process %.4f s/img "
+                      "(single thread, like the GIL-bound reference extension)" % (n_img, H, W, t_model / n_img, t_post / n_img)}
+
+
+def run_det(args, rank, local, world, device):
+    from pytorchocr_amd.modeling import ops
+    from pytorchocr_amd.postprocess import build_post_process
+    from pytorchocr_amd.utils.synth import synth_images, synth_prob_maps
+    B, H, W = args.batch, 736, 1280
+    model = build_and_sync_weights(DET_R18, "det_r18_db", device, rank, world)
+    post = build_post_process(DET_POST, dict(use_gpu=True, seed=2022))
+    # synthetic images: a few distinct seeded images tiled to the batch (the generator is slow on the host)
+    base = synth_images(4, 3, H, W, seed=2022 + rank)
+    x = torch.from_numpy(base).to(device).repeat(B // 4 + 1, 1, 1, 1)[:B].contiguous()
+    shape_list = np.array([[H, W, 1.0, 1.0]] * B)
+    # Random weights give noise-like maps; so that the post-process does realistic work (~130 text boxes per
+    # image) the text-like stress maps are blended into the timed path's post-process input as a SECOND pass
+    stress = torch.from_numpy(synth_prob_maps(4, H, W, seed=7 + rank)).to(device).repeat(B // 4 + 1, 1, 1)[:B, None].contiguous()
+
+    def step(profile=False):
+        with torch.no_grad():
+            out = model(x)
+        if profile:
+            torch.cuda.synchronize()
+        res = []
+        if args.post_input in ("model", "both"):        # the pipeline's own data flow
+            res = post({"maps": out["maps"]}, shape_list)
+        if args.post_input in ("stress", "both"):       # realistic ~130 boxes/image load (random weights give noise maps)
+            res = post({"maps": stress}, shape_list)
+        return out, res
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        torch.cuda.synchronize()
+    ops.PROFILE = [] if rank == 0 else None
+    t0 = time.perf_counter()
+    nbox = 0
+    for _ in range(args.steps):
+        _, res = step()
+        nbox += sum(len(r["points"]) for r in res)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = ops.PROFILE
+    ops.PROFILE = None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return None
+    conv_ms = sum(e0.elapsed_time(e1) for e0, e1 in prof)
+    n_launch = len(prof)
+    conv_flops = (DET_GFLOP_PER_IMG - DET_TAIL_GFLOP_PER_IMG) * 1e9 * B * args.steps
+    achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    cpu = det_cpu_baseline(args.cpu_images, H, W) if world == 1 and args.cpu_images > 0 else None
+    line = {
+        "metric": "images/sec end-to-end (DBNet-r18 det+post, 736x1280)",
+        "value": round(world * B * args.steps / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "DBNet r18 fp32, batch %d synthetic 736x1280 per GPU, HIP conv + HIP DBPostProcess "
+                               "(BASELINE.json configs[1])" % B,
+                   "global_batch": world * B, "post_input": args.post_input, "boxes_per_image": round(nbox / (B * args.steps), 1),
+                   "parallelism": "image-sharded x%d, RCCL weight broadcast only" % world},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                     "kernel": "conv_mfma_kernel (all %d launches per step, %.3f ms avg launch, HIP events on the launch stream)"
+                               % (n_launch // max(args.steps, 1), conv_ms / max(n_launch, 1))},
+        "cpu_baseline": cpu,
+    }
+    return line
+
+
+def run_crnn(args, rank, local, world, device):
+    from pytorchocr_amd.postprocess import build_post_process
+    from pytorchocr_amd.utils.synth import synth_text_lines
+    B = args.batch
+    model = build_and_sync_weights(crnn_cfg(), "rec_vgg_bilstm_ctc", device, rank, world)
+    post = build_post_process(dict(name="CTCLabelDecode"), dict(character_dict_path=os.path.join(
+        ROOT, "pytorchocr_amd", "utils", "char_dict_6623.txt"), use_space_char=False))
+    base = synth_text_lines(16, 32, 320, seed=2022 + rank)
+    x = torch.from_numpy(base).to(device).repeat(B // 16 + 1, 1, 1, 1)[:B].contiguous()
+
+    def step():
+        with torch.no_grad():
+            return post(model.forward_greedy(x))
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return None
+    achieved = CRNN_GFLOP_PER_LINE * 1e9 * B * args.steps / dt / 1e12
+    return {
+        "metric": "CRNN text-lines/sec (vgg_v1_x1.0 + BiLSTM + CTC greedy, 32x320)",
+        "value": round(world * B * args.steps / dt, 2), "unit": "text-lines/sec", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "CRNN vgg_v1_x1.0 + CTC greedy, batch %d synthetic 32x320 gray crops per GPU (BASELINE.json configs[2])" % B,
+                   "global_batch": world * B, "parallelism": "line-sharded x%d" % world},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                     "kernel": "whole step (end-to-end FLOP rate; per-kernel split in profiles/)"},
+        "cpu_baseline": None,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="det", choices=["det", "crnn"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 32 det / 512 crnn)")
+    ap.add_argument("--post-input", default="both", choices=["both", "stress", "model"],
+                    help="maps post-processed inside the timed step: the model's own maps (true data flow; random weights "
+                         "give noise-like maps), text-like stress maps with ~130 boxes per image, or both (default: "
+                         "strictly more work than the real pipeline)")
+    ap.add_argument("--cpu-images", type=int, default=8, help="images in the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+    if args.batch == 0:
+        args.batch = 32 if args.workload == "det" else 512
+    rank, local, world = dist_env()
+    if world != args.gpus:
+        if args.gpus == 1 and world == 1:
+            pass
+        else:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
+    line = (run_det if args.workload == "det" else run_crnn)(args, rank, local, world, device)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -22,8 +22,8 @@
  *       plus the threshold of pytocr/postprocess/db_postprocess.py:45-46, batched over N images.
  *   ptocr_ctc_greedy_f32
  *       preds.argmax(axis=2) / preds.max(axis=2) of pytocr/postprocess/rec_postprocess.py:80-84.
- *   ptocr_lstm_bidir_f32, ptocr_linear_f32
- *       nn.LSTM(bidirectional) / nn.Linear of pytocr/modeling/necks/rnn.py:18-36, heads/rec_ctc_head.py:17-36.
+ *   ptocr_lstm_bidir_f32, ptocr_linear_f32, ptocr_softmax_rows_f32
+ *       nn.LSTM(bidirectional) / nn.Linear / F.softmax of pytocr/modeling/necks/rnn.py:18-36, heads/rec_ctc_head.py:17-36.
  */
 #ifndef PTOCR_HIP_H
 #define PTOCR_HIP_H
@@ -94,18 +94,21 @@ int ptocr_db_postprocess(ptocr_dbpost_t h, const float *d_maps, const uint8_t *d
  * short xmin, xmax, ymin, ymax;}  status: 0 box, 1 <=2 points, 2 ssid<3, 3 score<box_thresh, 4 unclip<1.001, 5 ssid<5. */
 int ptocr_dbpost_debug_results(ptocr_dbpost_t h, int img, int32_t *h_total, void *h_results, void *h_cands, void *h_info);
 
-/* ---- recognition ---------------------------------------------------------------------------------------- */
-/* y[M,Nout] = x[M,K] @ w[Nout,K]^T + bias; K % 32 == 0, Nout % 64 == 0 (pad rows of w with zeros) */
+/* ---- recognition ----------------------------------------------------------------------------------------
+ * Sequences are batch-major: row = b*T + t (no Im2Seq permute, no decode transpose). */
+/* y[M,Nout] = x[M,K] @ w[Nout,K]^T + bias; K % 32 == 0, Nout % 64 == 0 (pad rows of w / bias with zeros), ldy >= Nout */
 int ptocr_linear_f32(const float *d_x, const float *d_w, const float *d_bias, float *d_y, int M, int K, int Nout,
                      int ldy, void *stream);
-/* One bidirectional LSTM layer, zero initial state, torch gate order i,f,g,o.
- * d_xproj f32[2][T][B][4H]: input projections x@W_ih^T + b_ih + b_hh per direction (made with ptocr_linear_f32);
- * d_whh f32[2][4H][H]; d_out f32[T][B][2H] (forward half, backward half).  H == 256. */
+/* One bidirectional LSTM layer, zero initial state, torch gate order i,f,g,o, hidden size H == 256.
+ * d_xproj f32[B][T][2][4H]: x@W_ih^T + b_ih + b_hh for (forward, backward), one ptocr_linear_f32 with Nout = 8H;
+ * d_whh f32[2][4H][H] (weight_hh_l0, weight_hh_l0_reverse); d_out f32[B][T][2H] (forward half | backward half). */
 int ptocr_lstm_bidir_f32(const float *d_xproj, const float *d_whh, float *d_out, int T, int B, int H, void *stream);
-/* logits f32[T*B][ldl] (first C columns valid) -> softmax max prob and first arg-max per row:
- * d_idx int32[B][T], d_prob f32[B][T]  (== preds.argmax(2), preds.max(2) after the (1,0,2) transpose). */
-int ptocr_ctc_greedy_f32(const float *d_logits, int T, int B, int C, int ldl, int32_t *d_idx, float *d_prob,
-                         void *stream);
+/* Per row of d_x f32[rows][ld] (first C columns valid, ld % 4 == 0): first arg-max and the max softmax probability.
+ * is_prob = 0: d_x holds logits, prob = 1 / sum(exp(x - max));  is_prob = 1: d_x already holds probabilities, prob = max.
+ * With rows = b*T + t this is preds.argmax(2), preds.max(2) of rec_postprocess.py:83-84 as int32[B][T], f32[B][T]. */
+int ptocr_ctc_greedy_f32(const float *d_x, int rows, int C, int ld, int is_prob, int32_t *d_idx, float *d_prob, void *stream);
+/* y[r][0:C] = softmax(x[r][0:C]) (rec_ctc_head.py:33) */
+int ptocr_softmax_rows_f32(const float *d_x, int rows, int C, int ld, float *d_y, int ldy, void *stream);
 
 #ifdef __cplusplus
 }

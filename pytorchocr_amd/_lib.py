@@ -25,6 +25,9 @@ def lib():
             raise RuntimeError(
                 "pytorchocr_amd: %s is missing -- build it with `python -m pytorchocr_amd.build` "
                 "(there is no CPU fallback)" % LIB_PATH)
+        # torch ships its own HIP runtime; import it FIRST so libptocr_hip.so binds to that same runtime
+        # (streams and device pointers are shared with torch -- two runtimes in one process do not see each other)
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         L.ptocr_last_error.restype = C.c_char_p
         _lib = L
@@ -36,8 +39,8 @@ EXPORTS = [
     "ptocr_last_error", "ptocr_version", "ptocr_device_arch",
     "ptocr_conv2d_f32", "ptocr_nchw_to_nhwc_f32", "ptocr_nhwc_to_nchw_f32", "ptocr_maxpool2d_f32",
     "ptocr_convt2x2_sigmoid_f32",
-    "ptocr_dbpost_create", "ptocr_dbpost_destroy", "ptocr_db_postprocess",
-    "ptocr_linear_f32", "ptocr_lstm_bidir_f32", "ptocr_ctc_greedy_f32",
+    "ptocr_dbpost_create", "ptocr_dbpost_destroy", "ptocr_db_postprocess", "ptocr_dbpost_debug_results",
+    "ptocr_linear_f32", "ptocr_lstm_bidir_f32", "ptocr_ctc_greedy_f32", "ptocr_softmax_rows_f32",
 ]
 
 

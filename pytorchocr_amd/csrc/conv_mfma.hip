@@ -240,3 +240,14 @@ extern "C" int ptocr_conv2d_f32(const ptocr_conv_desc *d, const float *d_x, cons
     a.mtiles = cdiv(a.M, 256);
     return smallc ? launch_conv<256, 64, true>(a, s) : launch_conv<256, 64, false>(a, s);
 }
+
+// y[M,Nout] = x[M,K] @ w[Nout,K]^T + bias: the same MFMA kernel as a 1x1 convolution over M "pixels"
+extern "C" int ptocr_linear_f32(const float *d_x, const float *d_w, const float *d_bias, float *d_y, int M, int K, int Nout,
+                                int ldy, void *stream) {
+    PT_CHECK(M >= 1 && K % 32 == 0 && Nout % 64 == 0 && ldy >= Nout, "ptocr_linear_f32: need K %% 32 == 0, Nout %% 64 == 0, ldy >= Nout");
+    ptocr_conv_desc d;
+    memset(&d, 0, sizeof d);
+    d.N = 1; d.H = M; d.W = 1; d.Cin = K; d.Cout = Nout; d.KH = 1; d.KW = 1; d.stride = 1; d.Ho = M; d.Wo = 1;
+    d.out_up = 1; d.out_ldc = ldy;
+    return ptocr_conv2d_f32(&d, d_x, d_w, d_bias, nullptr, d_y, stream);
+}

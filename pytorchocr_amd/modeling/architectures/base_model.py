@@ -56,6 +56,20 @@ class BaseModel(nn.Module):
             if self.return_all_feats:
                 y["backbone_out"] = ops.nhwc_to_nchw(feats)
                 y["neck_out"] = neck
+        return self._finish(y, out)
+
+    def forward_greedy(self, x):
+        """rec models only: f32[B,1,32,W] -> (idx int32[B,T], prob f32[B,T]) on the device, i.e. the
+        preds.argmax(2) / preds.max(2) that CTCLabelDecode takes from the softmax (rec_postprocess.py:83-84),
+        computed from the logits without materialising the T*B*C softmax tensor."""
+        if self.model_type != "rec":
+            raise NotImplementedError("forward_greedy is the recognition fast path")
+        if not x.is_cuda:
+            raise RuntimeError("pytorchocr_amd BaseModel.forward_greedy: input is on %s; no CPU fallback" % x.device)
+        feats = self.backbone.forward_nhwc(ops.nchw_to_nhwc(x, 4))
+        return self.head.greedy(self.neck.forward_seq(feats))
+
+    def _finish(self, y, out):
         if isinstance(out, dict):
             y.update(out)
         else:

@@ -9,6 +9,10 @@ from .. import _lib
 from .._lib import ConvDesc, RES_NONE, RES_ADD_PRE_RELU, RES_ADD_UP2_POST_RELU  # noqa: F401
 
 
+# bench.py sets this to a list to time every conv launch with HIP events on the launch stream
+PROFILE = None
+
+
 def _require_cuda(t, what):
     if not t.is_cuda:
         raise RuntimeError("%s: tensor is on %s -- the HIP path needs a cuda (ROCm) device, there is no CPU fallback"
@@ -81,9 +85,15 @@ def conv2d(x, pc, res=None, res_mode=RES_NONE, out=None, out_up=1, out_coff=0):
     d = ConvDesc(N, H, W, Cin, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad_h, pc.pad_w, Ho, Wo,
                  int(pc.relu), res_mode, out_up, out.shape[3], out_coff, int(pc.convt))
     L = _lib.lib()
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(L.ptocr_conv2d_f32(C.byref(d), _lib.ptr(x), _lib.ptr(pc.w), _lib.ptr(pc.b),
                                   _lib.ptr(res) if res is not None else C.c_void_p(0), _lib.ptr(out),
                                   _lib.cur_stream()), "ptocr_conv2d_f32")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((e0, e1))
     return out
 
 
@@ -125,6 +135,47 @@ def convt2x2_sigmoid(x, w4, bias):
     y = torch.empty((N, 1, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().ptocr_convt2x2_sigmoid_f32(_lib.ptr(x), _lib.ptr(w4), C.c_float(bias), _lib.ptr(y), N, H, W, Cc,
                                                      _lib.cur_stream()), "ptocr_convt2x2_sigmoid_f32")
+    return y
+
+
+def linear(x, w, b):
+    """x f32[M,K] @ w[Nout,K]^T + b -> f32[M,Nout] (MFMA GEMM; K % 32 == 0, Nout % 64 == 0)"""
+    _require_cuda(x, "linear")
+    M, K = x.shape
+    Nout = w.shape[0]
+    y = torch.empty((M, Nout), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().ptocr_linear_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), M, K, Nout, Nout,
+                                           _lib.cur_stream()), "ptocr_linear_f32")
+    return y
+
+
+def lstm_bidir(xproj, w_hh, B, T):
+    """xproj f32[B*T, 8H] (= [B][T][2][4H]), w_hh f32[2,4H,H] -> f32[B*T, 2H]"""
+    _require_cuda(xproj, "lstm_bidir")
+    H = w_hh.shape[2]
+    out = torch.empty((B * T, 2 * H), dtype=torch.float32, device=xproj.device)
+    _lib.check(_lib.lib().ptocr_lstm_bidir_f32(_lib.ptr(xproj), _lib.ptr(w_hh), _lib.ptr(out), T, B, H, _lib.cur_stream()),
+               "ptocr_lstm_bidir_f32")
+    return out
+
+
+def ctc_greedy(x, C, is_prob):
+    """x f32[rows, ld] -> (idx int32[rows], prob f32[rows])"""
+    _require_cuda(x, "ctc_greedy")
+    rows, ld = x.shape
+    idx = torch.empty(rows, dtype=torch.int32, device=x.device)
+    prob = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().ptocr_ctc_greedy_f32(_lib.ptr(x), rows, C, ld, int(is_prob), _lib.ptr(idx), _lib.ptr(prob),
+                                               _lib.cur_stream()), "ptocr_ctc_greedy_f32")
+    return idx, prob
+
+
+def softmax_rows(x, C):
+    _require_cuda(x, "softmax_rows")
+    rows, ld = x.shape
+    y = torch.empty((rows, C), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().ptocr_softmax_rows_f32(_lib.ptr(x), rows, C, ld, _lib.ptr(y), C, _lib.cur_stream()),
+               "ptocr_softmax_rows_f32")
     return y
 
 

@@ -1,6 +1,105 @@
-"""placeholder, filled in with the CRNN decode."""
+"""CTC label decode.  Mirror of reference pytocr/postprocess/rec_postprocess.py: `BaseRecLabelDecode` (:5-62:
+dictionary load, blank skip FIRST then duplicate collapse against the previous RAW index, np.mean confidence,
+nan for empty) and `CTCLabelDecode` (:65-93: "blank" prepended, argmax / max over classes).
+
+The class reductions run on the GPU (`ptocr_ctc_greedy_f32`); what is left on the host is the per-line string
+assembly over B*T int32 indices.  Accepted inputs:
+  * the reference contract: softmax probabilities f32[T,B,C] (torch tensor on any device, numpy, or a tuple
+    whose last element is one), or
+  * the fast path: (idx int32[B,T], prob f32[B,T]) from `BaseModel.forward_greedy`.
+"""
+import numpy as np
+import torch
+
+from ..modeling import ops
 
 
-class CTCLabelDecode(object):
-    def __init__(self, *a, **k):
-        raise NotImplementedError
+class BaseRecLabelDecode(object):
+    """ Convert between text-label and text-index """
+
+    def __init__(self, character_dict_path=None, use_space_char=False):
+        self.beg_str = "sos"
+        self.end_str = "eos"
+        self.character_str = []
+        if character_dict_path is None:
+            self.character_str = "0123456789abcdefghijklmnopqrstuvwxyz"
+            dict_character = list(self.character_str)
+        else:
+            with open(character_dict_path, "rb") as fin:
+                for line in fin.readlines():
+                    self.character_str.append(line.decode("UTF-8").strip("\n").strip("\r\n"))
+            if use_space_char:
+                self.character_str.append(" ")
+            dict_character = list(self.character_str)
+        dict_character = self.add_special_char(dict_character)
+        self.dict = {char: i for i, char in enumerate(dict_character)}
+        self.character = dict_character
+
+    def add_special_char(self, dict_character):
+        return dict_character
+
+    def get_ignored_tokens(self):
+        return [0]  # for ctc blank
+
+    def decode(self, text_index, text_prob=None, is_remove_duplicate=False):
+        """ convert text-index into text-label. """
+        text_index = np.asarray(text_index)
+        ignored = self.get_ignored_tokens()
+        keep = ~np.isin(text_index, ignored)
+        if is_remove_duplicate and text_index.shape[1] > 1:
+            keep[:, 1:] &= text_index[:, 1:] != text_index[:, :-1]
+        chars = self.character
+        result_list = []
+        for b in range(text_index.shape[0]):
+            k = keep[b]
+            text = "".join([chars[int(i)] for i in text_index[b][k]])
+            if text_prob is not None:
+                conf_list = np.asarray(text_prob[b])[k]
+            else:
+                conf_list = np.ones(int(k.sum()))
+            with np.errstate(all="ignore"):
+                import warnings
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    conf = np.mean(conf_list.tolist()) if len(conf_list) else np.mean([])
+            result_list.append((text, conf))
+        return result_list
+
+
+class CTCLabelDecode(BaseRecLabelDecode):
+    """ Convert between text-label and text-index """
+
+    def __init__(self, character_dict_path=None, use_space_char=False, **kwargs):
+        super(CTCLabelDecode, self).__init__(character_dict_path, use_space_char)
+
+    def __call__(self, preds, label=None, *args, **kwargs):
+        if isinstance(preds, tuple) and len(preds) == 2 and torch.is_tensor(preds[0]) and preds[0].dtype in (torch.int32, torch.int64) \
+                and preds[0].dim() == 2:
+            preds_idx = preds[0].cpu().numpy()
+            preds_prob = preds[1].cpu().numpy()
+        else:
+            if isinstance(preds, tuple):
+                preds = preds[-1]
+            if isinstance(preds, np.ndarray):
+                preds = torch.from_numpy(np.ascontiguousarray(preds, np.float32))
+            if not preds.is_cuda:
+                preds = preds.to("cuda:%d" % torch.cuda.current_device())     # host buffers accepted; work stays on the GPU
+            preds = preds.contiguous().float()
+            T, B, Cn = preds.shape
+            x = preds.reshape(T * B, Cn)
+            if Cn % 4:                                                         # kernel wants 16-B aligned rows
+                xp = torch.zeros((T * B, (Cn + 3) // 4 * 4), dtype=torch.float32, device=x.device)
+                xp[:, :Cn] = x
+                x = xp
+            idx, prob = ops.ctc_greedy(x, Cn, is_prob=True)
+            preds_idx = idx.reshape(T, B).cpu().numpy().T
+            preds_prob = prob.reshape(T, B).cpu().numpy().T
+        text = self.decode(preds_idx, preds_prob, is_remove_duplicate=True)
+        if label is None:
+            return text
+        label = self.decode(label)
+        return text, label
+
+    def add_special_char(self, dict_character):
+        dict_character = ["blank"] + dict_character
+        return dict_character

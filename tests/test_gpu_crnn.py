@@ -1,0 +1,109 @@
+"""CRNN on the HIP engine against outputs of the REFERENCE model (tests/golden) and the oracle (-m gpu).
+Label sequences bit-exact, probabilities within 1e-4 (BASELINE.json north_star tolerance for fp32)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ctc_oracle, model_oracle
+from pytorchocr_amd.utils.synth import synth_state_dict, synth_text_lines, uniform
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DICT = os.path.join(ROOT, "pytorchocr_amd", "utils", "char_dict_6623.txt")
+
+
+def _cfg(nclass=6624):
+    return dict(model_type="rec", algorithm="CRNN", in_channels=1, Transform=None,
+                Backbone=dict(name="VGG", model_name="v1", scale=1.0, pretrained=False, ckpt_path=None),
+                Neck=dict(name="SequenceEncoder", encoder_type="rnn", hidden_size=256),
+                Head=dict(name="CTCHead", out_channels=nclass))
+
+
+def _model(contract):
+    from pytorchocr_amd.modeling.architectures import build_model
+    m = build_model(_cfg())
+    sd = synth_state_dict(contract["rec_vgg_bilstm_ctc"])
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return m.to("cuda:0").eval(), sd
+
+
+def test_lstm_kernel_matches_torch():
+    from pytorchocr_amd.modeling import ops
+    from pytorchocr_amd.modeling.necks.rnn import BidirectionalLSTM
+    torch.manual_seed(0)
+    for B, T, nin in ((3, 7, 64), (37, 21, 512)):
+        blk = BidirectionalLSTM(nin, 256, 256).eval()
+        x = torch.randn(T, B, nin)
+        with torch.no_grad():
+            o, _ = blk.rnn(x)
+            ref = blk.embedding(o.reshape(T * B, 512)).reshape(T, B, 256)
+        p = blk.pack(torch.device("cuda:0"))
+        xb = x.permute(1, 0, 2).contiguous().reshape(B * T, nin).cuda()
+        got = BidirectionalLSTM.run(p, xb, B, T).reshape(B, T, 256).permute(1, 0, 2).cpu()
+        assert (got - ref).abs().max().item() <= 2e-5
+
+
+def test_crnn_matches_reference_golden(gold_dir, contract):
+    g = np.load(os.path.join(gold_dir, "crnn_3x1x32x320.npz"))
+    m, _ = _model(contract)
+    x = torch.from_numpy(synth_text_lines(3, 32, 320, seed=int(g["seed"]))).cuda()
+    with torch.no_grad():
+        p = m(x)
+        idx, prob = m.forward_greedy(x)
+    assert tuple(p.shape) == tuple(g["shape"]) and p.dtype == torch.float32
+    pn = p.cpu().numpy()
+    assert np.abs(pn[:, :, g["cols"]] - g["probs_cols"]).max() <= 1e-4
+    assert np.array_equal(idx.cpu().numpy(), g["idx"])                        # label ids bit-exact
+    assert np.abs(prob.cpu().numpy() - g["prob"]).max() <= 1e-4
+    assert np.array_equal(pn.transpose(1, 0, 2).argmax(axis=2), g["idx"])
+
+
+def test_crnn_batch_against_oracle_and_decode(contract):
+    from pytorchocr_amd.postprocess import build_post_process
+    m, sd = _model(contract)
+    xs = synth_text_lines(21, 32, 320, seed=77)
+    with torch.no_grad():
+        greedy = m.forward_greedy(torch.from_numpy(xs).cuda())
+        probs = m(torch.from_numpy(xs).cuda())
+    ref = model_oracle.crnn_forward(sd, torch.from_numpy(xs)).numpy()
+    post = build_post_process(dict(name="CTCLabelDecode"), dict(character_dict_path=DICT, use_space_char=False))
+    assert len(post.character) == 6624
+    chars = ctc_oracle.load_characters(DICT)
+    exp = ctc_oracle.ctc_label_decode(ref, chars)
+    for got in (post(greedy), post(probs), post(probs.cpu().numpy())):
+        assert [t for t, _ in got] == [t for t, _ in exp]
+        assert np.allclose([c for _, c in got], [c for _, c in exp], atol=1e-4, equal_nan=True)
+    assert any(len(t) > 3 for t, _ in exp)
+
+
+def test_ctc_decode_known_answers(gold_dir):
+    from pytorchocr_amd.postprocess.rec_postprocess import CTCLabelDecode
+    cases = json.load(open(os.path.join(gold_dir, "ctc_decode.json"), encoding="utf-8"))
+    dec = CTCLabelDecode()
+    for c in cases:
+        if c["dict"] != "default36":
+            continue
+        pr = uniform((c["T"], 1, c["C"]), c["seed"], 0.0, 0.5)
+        for t, k in enumerate(c["seq"]):
+            pr[t, 0, k] = 0.6 + 0.01 * t
+        (text, conf), = dec(torch.from_numpy(pr).cuda())
+        assert text == c["text"]
+        assert (c["conf"] is None and np.isnan(conf)) or abs(float(conf) - c["conf"]) < 1e-6
+
+
+def test_ctc_greedy_ties_take_first_index():
+    from pytorchocr_amd.modeling import ops
+    x = torch.zeros(5, 6624 + 32)
+    x[0, 100] = 3; x[0, 4000] = 3                      # tie -> first
+    x[1, 6623] = 2                                     # last valid column
+    x[2, 6630] = 9                                     # padding column must be ignored
+    x[3, :] = -1; x[3, 0] = -0.5
+    x[4, 1::2] = 1.0                                   # many ties
+    idx, prob = ops.ctc_greedy(x.cuda(), 6624, is_prob=False)
+    assert idx.cpu().tolist() == [100, 6623, 0, 0, 1]
+    ref = torch.softmax(x[:, :6624], 1).max(1).values
+    assert (prob.cpu() - ref).abs().max().item() <= 1e-6
