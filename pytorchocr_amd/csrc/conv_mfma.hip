@@ -16,6 +16,7 @@
 // Epilogue (all fused): +bias (BN folded), residual add, ReLU, FPN nearest-x2 upsample-add, nearest-upsampled
 // store into a channel slice of a wider tensor (concat in place), ConvTranspose 2x2/s2 pixel scatter.
 #include "common.h"
+#include <cstdlib>
 
 namespace ptocr {
 
@@ -32,7 +33,110 @@ struct ConvArgs {
     int M, Kpad, nk;
     int relu, res_mode, out_up, out_ldc, out_coff, convt, co_real;
     int mtiles;
+    long x_bytes, w_bytes;
+    int vec_epilogue;
 };
+
+__device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x16 (&acc)[2][2], int m0, int n0, int wm0, int wn0, int frow, int fh) {
+    // ---- epilogue.  D layout: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            if (m >= p.M) continue;
+            int n = 0, oy = 0, ox = 0;
+            const bool need_pix = p.res_mode == PTOCR_RES_ADD_UP2_POST_RELU || p.out_up > 1 || p.convt;
+            if (need_pix) {
+                n = m / HoWo;
+                const int rem = m - n * HoWo;
+                oy = rem / p.Wo; ox = rem - oy * p.Wo;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int col = n0 + wn0 + j * 32 + frow;
+                float v = acc[i][j][r] + p.bias[col];
+                if (p.res_mode == PTOCR_RES_ADD_PRE_RELU) v += p.res[(long)m * p.Cout + col];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.res_mode == PTOCR_RES_ADD_UP2_POST_RELU)
+                    v += p.res[(((long)n * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * p.Cout + col];
+                if (p.convt) {
+                    const int ab = col / p.co_real, co = col - ab * p.co_real;
+                    const int Y = 2 * oy + (ab >> 1), X = 2 * ox + (ab & 1);
+                    p.y[(((long)n * (2 * p.Ho) + Y) * (2 * p.Wo) + X) * p.out_ldc + p.out_coff + co] = v;
+                } else if (p.out_up > 1) {
+                    const int U = p.out_up;
+                    for (int dy = 0; dy < U; dy++)
+                        for (int dx = 0; dx < U; dx++)
+                            p.y[(((long)n * (p.Ho * U) + oy * U + dy) * (p.Wo * U) + ox * U + dx) * p.out_ldc + p.out_coff + col] = v;
+                } else {
+                    p.y[(long)m * p.out_ldc + p.out_coff + col] = v;
+                }
+            }
+        }
+    }
+}
+
+// Epilogue through LDS: each wave parks 32 rows x 64 columns of accumulators in a private [32][68] tile, then every
+// lane handles 16-byte chunks of 4 consecutive channels: bias / residual / upsample-add loads and the stores are all
+// 16 B per lane with 16 consecutive lanes covering one pixel's 256 contiguous bytes (4x fewer store instructions than
+// the register-layout epilogue, fully coalesced).  Needs out_ldc, out_coff, Cout multiples of 4 (checked on the host).
+__device__ __forceinline__ void conv_epilogue_lds(const ConvArgs &p, f32x16 (&acc)[2][2], int m0, int n0, int wm0, int wn0,
+                                                  int lane, float *wsm) {
+    constexpr int EL = 68;
+    const int frow = lane & 31, fh = lane >> 5;
+    const int HoWo = p.Ho * p.Wo;
+    const int chunk = lane & 15, rsub = lane >> 4;
+    const int col = n0 + wn0 + chunk * 4;
+    const f32x4 bias4 = *reinterpret_cast<const f32x4 *>(p.bias + col);
+    const bool need_pix = p.res_mode == PTOCR_RES_ADD_UP2_POST_RELU || p.out_up > 1 || p.convt;
+    const int ab = (n0 + wn0) / p.co_real;                       // convt: the wave's 64 columns belong to one (a,b)
+    const int co = col - ab * p.co_real;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                wsm[((r & 3) + 8 * (r >> 2) + 4 * fh) * EL + j * 32 + frow] = acc[i][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int row = rsub + 4 * q;
+            const int m = m0 + wm0 + i * 32 + row;
+            if (m >= p.M) continue;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(wsm + row * EL + chunk * 4);
+            v += bias4;
+            int n = 0, oy = 0, ox = 0;
+            if (need_pix) {
+                n = m / HoWo;
+                const int rem = m - n * HoWo;
+                oy = rem / p.Wo; ox = rem - oy * p.Wo;
+            }
+            if (p.res_mode == PTOCR_RES_ADD_PRE_RELU) v += *reinterpret_cast<const f32x4 *>(p.res + (long)m * p.Cout + col);
+            if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            if (p.res_mode == PTOCR_RES_ADD_UP2_POST_RELU)
+                v += *reinterpret_cast<const f32x4 *>(p.res + (((long)n * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * p.Cout + col);
+            if (p.convt) {
+                const int Y = 2 * oy + (ab >> 1), X = 2 * ox + (ab & 1);
+                *reinterpret_cast<f32x4 *>(p.y + (((long)n * (2 * p.Ho) + Y) * (2 * p.Wo) + X) * p.out_ldc + p.out_coff + co) = v;
+            } else if (p.out_up > 1) {
+                const int U = p.out_up;
+                for (int dy = 0; dy < U; dy++)
+                    for (int dx = 0; dx < U; dx++)
+                        *reinterpret_cast<f32x4 *>(p.y + (((long)n * (p.Ho * U) + oy * U + dy) * (p.Wo * U) + ox * U + dx) * p.out_ldc + p.out_coff + col) = v;
+            } else {
+                *reinterpret_cast<f32x4 *>(p.y + (long)m * p.out_ldc + p.out_coff + col) = v;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
 
 template <int BM, int BN, bool SMALLC>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
@@ -156,44 +260,166 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
         }
     }
 
-    // ---- epilogue.  D layout: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    const int HoWo = p.Ho * p.Wo;
+    conv_epilogue(p, acc, m0, n0, wm0, wn0, frow, fh);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// v2: software-pipelined variant.  LDS is double-buffered (one barrier per k-step) and all side work of a k-step
+// -- ds_write of tile ks+1, buffer loads of tile ks+2, fragment reads of the next 8-k group -- is placed between
+// the MFMAs of tile ks, so a wave keeps the matrix pipe busy by itself (a 32x32x2 f32 MFMA occupies the pipe for
+// 64 cycles: room for ~10 other instructions per MFMA).  Gathers use raw buffer loads with 32-bit byte offsets:
+// an out-of-image tap gets an out-of-range offset and the hardware returns zeros (no branch, no select).
+template <int BM, int BN, int BKT, bool SMALLC>
+__global__ __launch_bounds__(256) void conv_mfma_v2_kernel(ConvArgs p) {
+    constexpr int WAVES_N = BN / 64;
+    constexpr int WAVES_M = 4 / WAVES_N;
+    static_assert(BM == WAVES_M * 64, "wave tile is 64x64");
+    constexpr int LD = BKT + 4;                 // LDS row stride (floats)
+    constexpr int PPR = BKT / 4;                // 16-B pieces per tile row
+    constexpr int RPP = 256 / PPR;              // rows covered by one pass of the block
+    constexpr int A_ROWS = BM / RPP;
+    constexpr int B_ROWS = BN / RPP;
+    constexpr int NKK = BKT / 8;
+    constexpr int STAGE = (BM + BN) * LD;
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave / WAVES_N) * 64;
+    const int wn0 = (wave % WAVES_N) * 64;
+
+    int bid = blockIdx.x;
+    {
+        const int nwg = p.mtiles, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int m0 = bid * BM;
+    const int n0 = blockIdx.y * BN;
+
+    const int c4 = tid % PPR;
+    const int lrow = tid / PPR;
+    // per row: byte offset of tap (0,0) (may be "negative" = wraps, only used when valid) and y/x validity masks
+    unsigned a_off[A_ROWS];
+    unsigned a_msk[A_ROWS];                     // bits 0..7: kh valid, bits 8..15: kw valid
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < A_ROWS; i++) {
+        const int m = m0 + lrow + RPP * i;
+        unsigned my = 0, mx = 0;
+        int off = 0;
+        if (m < p.M) {
+            const int n = m / (p.Ho * p.Wo);
+            const int rem = m - n * (p.Ho * p.Wo);
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            const int iy0 = oy * p.stride - p.pad_h, ix0 = ox * p.stride - p.pad_w;
+            for (int k = 0; k < p.KH; k++) my |= (unsigned)((unsigned)(iy0 + k) < (unsigned)p.H) << k;
+            for (int k = 0; k < p.KW; k++) mx |= (unsigned)((unsigned)(ix0 + k) < (unsigned)p.W) << k;
+            off = (((n * p.H + iy0) * p.W + ix0) * p.Cin) * 4;
+        }
+        a_off[i] = (unsigned)off;
+        a_msk[i] = my | (mx << 8);
+    }
+    const unsigned w_off0 = (unsigned)(((n0 + lrow) * p.Kpad + c4 * 4) * 4);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, (int)p.w_bytes, 0x00020000);
+
+    f32x4 ra[A_ROWS], rb[B_ROWS];
+    // `live` = false turns every offset out of range (zeros, no memory traffic): lets the pipeline tail run branch-free
+    auto gload = [&](int ks, bool live) {
+        int kh, kw;
+        unsigned tap_off;
+        if (SMALLC) {
+            const int tap = ks * PPR + c4;
+            kh = tap / p.KW; kw = tap - kh * p.KW;
+            tap_off = (unsigned)(((kh * p.W + kw) * p.Cin) * 4);
+            if (tap >= p.KH * p.KW) kh = 31;                     // no valid bit there -> zeros
+        } else {
+            const int k0 = ks * BKT;
+            const int tap = k0 / p.Cin;
+            kh = tap / p.KW; kw = tap - kh * p.KW;
+            tap_off = (unsigned)(((kh * p.W + kw) * p.Cin + (k0 - tap * p.Cin) + c4 * 4) * 4);
+        }
+        const unsigned oob = 0xfffffff0u;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-            if (m >= p.M) continue;
-            int n = 0, oy = 0, ox = 0;
-            const bool need_pix = p.res_mode == PTOCR_RES_ADD_UP2_POST_RELU || p.out_up > 1 || p.convt;
-            if (need_pix) {
-                n = m / HoWo;
-                const int rem = m - n * HoWo;
-                oy = rem / p.Wo; ox = rem - oy * p.Wo;
+        for (int i = 0; i < A_ROWS; i++) {
+            const bool ok = live && ((a_msk[i] >> kh) & (a_msk[i] >> (8 + kw)) & 1u) != 0;
+            const unsigned off = ok ? a_off[i] + tap_off : oob;                  // out of range -> hardware returns 0
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < B_ROWS; i++) {
+            const unsigned off = live ? w_off0 + (unsigned)((RPP * i * p.Kpad + ks * BKT) * 4) : oob;
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
+        }
+    };
+    auto lstore = [&](int buf) {
+        float *As = smem + buf * STAGE, *Bs = As + BM * LD;
+#pragma unroll
+        for (int i = 0; i < A_ROWS; i++) *reinterpret_cast<f32x4 *>(&As[(lrow + RPP * i) * LD + c4 * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_ROWS; i++) *reinterpret_cast<f32x4 *>(&Bs[(lrow + RPP * i) * LD + c4 * 4]) = rb[i];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int frow = lane & 31, fh = lane >> 5;
+    const int a_fo = (wm0 + frow) * LD + 4 * fh;
+    const int b_fo = BM * LD + (wn0 + frow) * LD + 4 * fh;
+
+    gload(0, true);
+    lstore(0);
+    gload(1, p.nk > 1);
+    __syncthreads();
+
+    for (int ks = 0; ks < p.nk; ks++) {
+        const float *st = smem + (ks & 1) * STAGE;
+        f32x4 fa0[2], fa1[2], fb0[2], fb1[2];
+        fa0[0] = *reinterpret_cast<const f32x4 *>(st + a_fo);
+        fa1[0] = *reinterpret_cast<const f32x4 *>(st + a_fo + 32 * LD);
+        fb0[0] = *reinterpret_cast<const f32x4 *>(st + b_fo);
+        fb1[0] = *reinterpret_cast<const f32x4 *>(st + b_fo + 32 * LD);
+#pragma unroll
+        for (int kk = 0; kk < NKK; kk++) {
+            const int c = kk & 1, nx = c ^ 1;
+            if (kk + 1 < NKK) {
+                fa0[nx] = *reinterpret_cast<const f32x4 *>(st + a_fo + (kk + 1) * 8);
+                fa1[nx] = *reinterpret_cast<const f32x4 *>(st + a_fo + 32 * LD + (kk + 1) * 8);
+                fb0[nx] = *reinterpret_cast<const f32x4 *>(st + b_fo + (kk + 1) * 8);
+                fb1[nx] = *reinterpret_cast<const f32x4 *>(st + b_fo + 32 * LD + (kk + 1) * 8);
             }
+            // side work of this k-step rides in the shadow of the MFMAs (branch-free so it shares their basic block):
+            // group 0 stores tile ks+1 (loaded one k-step ago) to the other LDS buffer, group 1 issues the loads of tile ks+2
+            if (kk == 0) lstore((ks + 1) & 1);
+            if (kk == (NKK > 1 ? 1 : 0)) gload(ks + 2, ks + 2 < p.nk);
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int col = n0 + wn0 + j * 32 + frow;
-                float v = acc[i][j][r] + p.bias[col];
-                if (p.res_mode == PTOCR_RES_ADD_PRE_RELU) v += p.res[(long)m * p.Cout + col];
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (p.res_mode == PTOCR_RES_ADD_UP2_POST_RELU)
-                    v += p.res[(((long)n * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * p.Cout + col];
-                if (p.convt) {
-                    const int ab = col / p.co_real, co = col - ab * p.co_real;
-                    const int Y = 2 * oy + (ab >> 1), X = 2 * ox + (ab & 1);
-                    p.y[(((long)n * (2 * p.Ho) + Y) * (2 * p.Wo) + X) * p.out_ldc + p.out_coff + co] = v;
-                } else if (p.out_up > 1) {
-                    const int U = p.out_up;
-                    for (int dy = 0; dy < U; dy++)
-                        for (int dx = 0; dx < U; dx++)
-                            p.y[(((long)n * (p.Ho * U) + oy * U + dy) * (p.Wo * U) + ox * U + dx) * p.out_ldc + p.out_coff + col] = v;
-                } else {
-                    p.y[(long)m * p.out_ldc + p.out_coff + col] = v;
-                }
+            for (int t = 0; t < 4; t++) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[c][t], fb0[c][t], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[c][t], fb1[c][t], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[c][t], fb0[c][t], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[c][t], fb1[c][t], acc[1][1], 0, 0, 0);
+            }
+            // interleave: one MFMA, then a few of the side instructions
+#pragma unroll
+            for (int g = 0; g < 16; g++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // DS write
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // VALU
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read
             }
         }
+        __syncthreads();
     }
+    static_assert(2 * STAGE >= 4 * 32 * 68, "epilogue tiles must fit in the staging LDS");
+    if (p.vec_epilogue) conv_epilogue_lds(p, acc, m0, n0, wm0, wn0, lane, smem + wave * (32 * 68));
+    else conv_epilogue(p, acc, m0, n0, wm0, wn0, frow, fh);
 }
 
 template <int BM, int BN, bool SMALLC>
@@ -201,6 +427,20 @@ static int launch_conv(const ConvArgs &a, hipStream_t s) {
     dim3 grid(a.mtiles, a.Cout / BN);
     hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, SMALLC>), grid, dim3(256), 0, s, a);
     return launch_ok("conv_mfma_kernel");
+}
+
+template <int BM, int BN, int BKT, bool SMALLC>
+static int launch_conv_v2(ConvArgs a, hipStream_t s) {
+    dim3 grid(a.mtiles, a.Cout / BN);
+    a.nk = a.Kpad / BKT;
+    hipLaunchKernelGGL((conv_mfma_v2_kernel<BM, BN, BKT, SMALLC>), grid, dim3(256), 0, s, a);
+    return launch_ok("conv_mfma_v2_kernel");
+}
+
+static int conv_impl() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("PTOCR_CONV_IMPL"); v = e ? atoi(e) : 3; }   // 1: v1 kernel, 2: v2 BK=32 for Cout%128==0, 3: v2 BK=16
+    return v;
 }
 
 }  // namespace ptocr
@@ -233,6 +473,19 @@ extern "C" int ptocr_conv2d_f32(const ptocr_conv_desc *d, const float *d_x, cons
     a.convt = d->convt2x2; a.co_real = co_real;
     hipStream_t s = (hipStream_t)stream;
     const bool smallc = d->Cin == 4;
+    a.x_bytes = (long)d->N * d->H * d->W * d->Cin * 4;
+    a.w_bytes = (long)d->Cout * a.Kpad * 4;
+    const int impl = conv_impl();
+    a.vec_epilogue = (d->out_ldc % 4 == 0 && d->out_coff % 4 == 0 && co_real % 4 == 0 && !getenv("PTOCR_CONV_SCALAR_EPILOGUE")) ? 1 : 0;
+    if (impl >= 2 && a.x_bytes < (1L << 31) && a.w_bytes < (1L << 31)) {
+        if (d->Cout % 128 == 0 && !smallc) {
+            a.mtiles = cdiv(a.M, 128);
+            return impl == 2 ? launch_conv_v2<128, 128, 32, false>(a, s) : launch_conv_v2<128, 128, 16, false>(a, s);
+        }
+        a.mtiles = cdiv(a.M, 256);
+        if (smallc) return launch_conv_v2<256, 64, 16, true>(a, s);
+        return launch_conv_v2<256, 64, 16, false>(a, s);
+    }
     if (d->Cout % 128 == 0 && !smallc) {
         a.mtiles = cdiv(a.M, 128);
         return launch_conv<128, 128, false>(a, s);
