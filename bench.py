@@ -116,20 +116,28 @@ def run_det(args, rank, local, world, device):
     # image) the text-like stress maps are blended into the timed path's post-process input as a SECOND pass
     stress = torch.from_numpy(synth_prob_maps(4, H, W, seed=7 + rank)).to(device).repeat(B // 4 + 1, 1, 1)[:B, None].contiguous()
 
-    def step(profile=False):
+    def step(pending):
+        """forward of this batch; its post-process is queued on the post-process stream and collected one step later,
+        so it overlaps with the next batch's convolutions (every batch's boxes are on the host before the clock stops)"""
         with torch.no_grad():
             out = model(x)
-        if profile:
-            torch.cuda.synchronize()
-        res = []
+        futs = []
         if args.post_input in ("model", "both"):        # the pipeline's own data flow
-            res = post({"maps": out["maps"]}, shape_list)
-        if args.post_input in ("stress", "both"):       # realistic ~130 boxes/image load (random weights give noise maps)
-            res = post({"maps": stress}, shape_list)
-        return out, res
+            futs.append(post.submit({"maps": out["maps"]}, shape_list))
+        if args.post_input in ("stress", "both"):       # realistic ~140 boxes/image load (random weights give noise maps)
+            futs.append(post.submit({"maps": stress}, shape_list))
+        res = [f.result() for f in pending] if args.overlap else []
+        if not args.overlap:
+            res = [f.result() for f in futs]
+            futs = []
+        return futs, (res[-1] if res else [])
 
+    pending = []
     for _ in range(args.warmup):
-        step()
+        pending, _ = step(pending)
+    for f in pending:
+        f.result()
+    pending = []
     torch.cuda.synchronize()
     if world > 1:
         import torch.distributed as dist
@@ -139,8 +147,11 @@ def run_det(args, rank, local, world, device):
     t0 = time.perf_counter()
     nbox = 0
     for _ in range(args.steps):
-        _, res = step()
+        pending, res = step(pending)
         nbox += sum(len(r["points"]) for r in res)
+    for f in pending:                                    # drain: the last batch's boxes
+        res = f.result()
+    nbox += sum(len(r["points"]) for r in res) if pending else 0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -166,7 +177,7 @@ def run_det(args, rank, local, world, device):
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "DBNet r18 fp32, batch %d synthetic 736x1280 per GPU, HIP conv + HIP DBPostProcess "
                                "(BASELINE.json configs[1])" % B,
-                   "global_batch": world * B, "post_input": args.post_input, "boxes_per_image": round(nbox / (B * args.steps), 1),
+                   "global_batch": world * B, "post_input": args.post_input, "post_overlap": bool(args.overlap), "boxes_per_image": round(nbox / (B * args.steps), 1),
                    "parallelism": "image-sharded x%d, RCCL weight broadcast only" % world},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
@@ -236,6 +247,8 @@ def main():
                     help="maps post-processed inside the timed step: the model's own maps (true data flow; random weights "
                          "give noise-like maps), text-like stress maps with ~130 boxes per image, or both (default: "
                          "strictly more work than the real pipeline)")
+    ap.add_argument("--no-overlap", dest="overlap", action="store_false",
+                    help="run the post-process synchronously after each forward instead of overlapping it with the next batch")
     ap.add_argument("--cpu-images", type=int, default=8, help="images in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
     if args.batch == 0:

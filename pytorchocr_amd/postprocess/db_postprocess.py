@@ -49,14 +49,14 @@ class _Workspace:
 _ws = _Workspace()
 
 
-def device_boxes(maps, src_wh, thresh, box_thresh, unclip_ratio, bitmap=None, use_padding_resize=False):
+def device_boxes(maps, src_wh, thresh, box_thresh, unclip_ratio, bitmap=None, use_padding_resize=False, ws=None):
     """maps: f32 cuda tensor [N,H,W]; src_wh: int array [N,2] (src_w, src_h); bitmap: optional u8 cuda tensor [N,H,W].
     -> (list of int16[K,4,2] per image, flags int32[N])"""
     if not maps.is_cuda:
         raise RuntimeError("device_boxes: maps must be on a cuda (ROCm) device; there is no CPU fallback")
     maps = maps.contiguous().float()
     n, h, w = maps.shape
-    hd = _ws.get(n, h, w)
+    hd = (ws or _ws).get(n, h, w)
     src = np.ascontiguousarray(src_wh, np.int32).reshape(n, 2)
     boxes = np.empty((n, MAX_CANDIDATES, 4, 2), np.int16)
     counts = np.zeros(n, np.int32)
@@ -90,6 +90,9 @@ class DBPostProcess(object):
         self.use_dilation = use_dilation
         self.cpp_speedup = cpp_speedup
         self.last_flags = None
+        self._ws = _Workspace()          # per-instance workspace: instances may run on different streams / threads
+        self._pool = None
+        self._stream = None
         if not cpp_speedup:
             raise NotImplementedError(
                 "pytorchocr_amd DBPostProcess implements the cpp_speedup=True semantics (the reference's C++ extension, "
@@ -100,6 +103,32 @@ class DBPostProcess(object):
         if use_dilation:
             raise NotImplementedError("use_dilation=True (cv2.dilate 2x2 before the C++ call) is not built yet")
 
+    def submit(self, outs_dict, shape_list, use_padding_resize=False):
+        """Asynchronous __call__: returns a future whose .result() is the reference's return value.  The post-process
+        runs on this instance's own HIP stream from a worker thread (the C call releases the GIL), ordered after the
+        work already queued on the caller's current stream -- so the next batch's convolutions overlap with it."""
+        import concurrent.futures
+        pred = outs_dict["maps"]
+        if isinstance(pred, np.ndarray):
+            pred = torch.from_numpy(np.ascontiguousarray(pred, np.float32))
+        if not pred.is_cuda:
+            pred = pred.to("cuda:%d" % torch.cuda.current_device())
+        dev = pred.device
+        if self._pool is None:
+            self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="dbpost")
+            self._stream = torch.cuda.Stream(device=dev)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))
+        pred.record_stream(self._stream)
+        shape_list = np.asarray(shape_list).copy()
+
+        def work():
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(self._stream):
+                self._stream.wait_event(ready)
+                return self._run(pred, shape_list, use_padding_resize)
+        return self._pool.submit(work)
+
     def __call__(self, outs_dict, shape_list, use_padding_resize=False):
         pred = outs_dict["maps"]
         if isinstance(pred, np.ndarray):
@@ -107,11 +136,14 @@ class DBPostProcess(object):
         if not pred.is_cuda:
             # host buffers are accepted like the reference does, but the work still happens on the GPU
             pred = pred.to("cuda:%d" % torch.cuda.current_device())
+        return self._run(pred, shape_list, use_padding_resize)
+
+    def _run(self, pred, shape_list, use_padding_resize):
         pred = pred[:, 0, :, :]
         shape_list = np.asarray(shape_list)
         src_wh = np.stack([shape_list[:, 1].astype(np.int64), shape_list[:, 0].astype(np.int64)], axis=1)   # (src_w, src_h)
         boxes, flags = device_boxes(pred, src_wh, self.thresh, self.box_thresh, self.unclip_ratio,
-                                    use_padding_resize=use_padding_resize)
+                                    use_padding_resize=use_padding_resize, ws=self._ws)
         self.last_flags = flags
         return [{"points": b, "scores": [1.0] * len(b)} for b in boxes]
 
