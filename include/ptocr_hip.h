@@ -16,6 +16,8 @@
  *       the ATen conv / BN / ReLU / max_pool / conv_transpose / sigmoid calls issued by
  *       pytocr/modeling/backbones/det_resnet.py:66-82,282-309, necks/fpn.py:102-134,
  *       heads/det_db_head.py:9-17,47-50, backbones/rec_vgg.py:78-120 (BN folded into weights/bias at load).
+ *   ptocr_asf_scale_channel_spatial_f32
+ *       ScaleChannelSpatialAttention.forward + the re-weighted concat of pytocr/modeling/necks/asf.py:63-75,155-162 (DB++).
  *   ptocr_db_postprocess
  *       pybind11 `db_postprocess.db_postprocess(pred, bitmap, box_thresh, det_db_unclip_ratio, src_w, src_h,
  *       use_padding_resize)` = DBProcess, pytocr/postprocess/db_postprocess_fast/src/db_postprocess.cpp:319-370,
@@ -67,6 +69,15 @@ int ptocr_maxpool2d_f32(const float *d_x, float *d_y, int N, int H, int W, int C
  * d_w f32[4][C] (index a*2+b), bias scalar -> d_maps f32[N,2H,2W]. */
 int ptocr_convt2x2_sigmoid_f32(const float *d_x, const float *d_w, float bias, float *d_maps, int N, int H, int W,
                                int C, void *stream);
+
+/* DB++ Adaptive Scale Fusion, attention_type "scale_channel_spatial" (asf.py:32-75,146-162), after its 3x3 conv (+bias) has
+ * produced d_y f32[N,H,W,64] with ptocr_conv2d_f32.  Scales d_fuse f32[N,H,W,256] IN PLACE: channels [64i,64i+64) *= score_i.
+ * d_w_cw1 f32[16][64], d_w_cw2 f32[64][16] (channel_wise.1/.3), d_w_sp3 f32[9], w_sp1 (spatial_wise.0/.2), d_w_att f32[4][64]
+ * (attention_wise.0); d_work: ptocr_asf_work_floats(N,H,W) floats of scratch. */
+int ptocr_asf_scale_channel_spatial_f32(const float *d_y, float *d_fuse, const float *d_w_cw1, const float *d_w_cw2,
+                                        const float *d_w_sp3, float w_sp1, const float *d_w_att, float *d_work,
+                                        int N, int H, int W, void *stream);
+long ptocr_asf_work_floats(int N, int H, int W);
 
 /* ---- DB post-process ------------------------------------------------------------------------------------ */
 typedef struct ptocr_dbpost *ptocr_dbpost_t;

@@ -75,7 +75,24 @@ def fpn_db_forward(sd, feats, prefix="neck."):
     p5 = F.interpolate(p5, scale_factor=8, mode="nearest")
     p4 = F.interpolate(p4, scale_factor=4, mode="nearest")
     p3 = F.interpolate(p3, scale_factor=2, mode="nearest")
-    return torch.cat((p5, p4, p3, p2), dim=1)
+    fuse = torch.cat((p5, p4, p3, p2), dim=1)
+    if (prefix + "concat_attention.conv.weight") in sd:          # DB++ (use_asf=True)
+        fuse = asf_forward(sd, fuse, [p5, p4, p3, p2], prefix + "concat_attention.")
+    return fuse
+
+
+def asf_forward(sd, fuse, feats, prefix="neck.concat_attention."):
+    """ScaleFeatureSelection with scale_channel_spatial (pytocr/modeling/necks/asf.py:63-75,146-162)."""
+    x = F.conv2d(fuse, _t(sd, prefix + "conv.weight"), _t(sd, prefix + "conv.bias"), 1, 1)
+    e = prefix + "enhanced_attention."
+    ca = F.adaptive_avg_pool2d(x, 1)
+    ca = torch.sigmoid(F.conv2d(F.relu(F.conv2d(ca, _t(sd, e + "channel_wise.1.weight"))), _t(sd, e + "channel_wise.3.weight")))
+    g = ca + x
+    s = torch.mean(g, dim=1, keepdim=True)
+    sa = torch.sigmoid(F.conv2d(F.relu(F.conv2d(s, _t(sd, e + "spatial_wise.0.weight"), None, 1, 1)), _t(sd, e + "spatial_wise.2.weight")))
+    g = sa + g
+    score = torch.sigmoid(F.conv2d(g, _t(sd, e + "attention_wise.0.weight")))
+    return torch.cat([score[:, i:i + 1] * feats[i] for i in range(4)], dim=1)
 
 
 def db_head_forward(sd, x, prefix="head.binarize."):

@@ -1,0 +1,151 @@
+// DB++ Adaptive Scale Fusion (attention_type "scale_channel_spatial") around the MFMA conv.
+// Replaces pytocr/modeling/necks/asf.py:32-75 (ScaleChannelSpatialAttention.forward) and :146-162
+// (ScaleFeatureSelection.forward after its 3x3 conv, which runs on conv_mfma).  All four kernels are
+// memory-bound (HBM roofline): y = conv(fuse) is f32[N,H,W,64], fuse is f32[N,H,W,256].
+//   1. asf_pool_kernel      partial sums of y over pixel chunks            (reads y once)
+//   2. asf_channel_kernel   ca = sigmoid(W2 relu(W1 mean(y)))              (one block per image, tiny)
+//   3. asf_mean_kernel      s = mean_c(y + ca)   (the reference ADDS the attention, asf.py:67)  -> f32[N,H,W]
+//   4. asf_apply_kernel     sa = sigmoid(w1 * relu(conv3x3(s))); g = y + ca + sa (asf.py:72, added again);
+//                           score = sigmoid(Wa g) (4 values); fuse[..., 64i:64i+64] *= score_i  (in place)
+#include "common.h"
+
+namespace ptocr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int ASF_C = 64;          // inter channels
+constexpr int ASF_MID = 16;
+constexpr int ASF_F = 4;           // pyramid levels
+constexpr int POOL_PIX = 2048;     // pixels per partial-sum block
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+
+// block (256 threads) = 16 channel-quads x 16 pixel lanes; deterministic tree reduction
+__global__ __launch_bounds__(256) void asf_pool_kernel(const float *__restrict__ y, float *__restrict__ partial, int HW, int nblk) {
+    const int n = blockIdx.y, blk = blockIdx.x;
+    const int cq = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const long base = (long)n * HW;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const int p0 = blk * POOL_PIX, p1 = min(p0 + POOL_PIX, HW);
+    for (int p = p0 + pl; p < p1; p += 16) s += *reinterpret_cast<const f32x4 *>(y + (base + p) * ASF_C + cq * 4);
+    __shared__ f32x4 sh[256];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o >= 16; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x < 16) *reinterpret_cast<f32x4 *>(partial + ((long)n * nblk + blk) * ASF_C + threadIdx.x * 4) = sh[threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void asf_channel_kernel(const float *__restrict__ partial, const float *__restrict__ w1 /*[16][64]*/,
+                                                         const float *__restrict__ w2 /*[64][16]*/, float *__restrict__ ca, int HW, int nblk) {
+    const int n = blockIdx.x, c = threadIdx.x;
+    __shared__ float mean[ASF_C], mid[ASF_MID];
+    float s = 0.f;
+    for (int b = 0; b < nblk; b++) s += partial[((long)n * nblk + b) * ASF_C + c];
+    mean[c] = s / (float)HW;
+    __syncthreads();
+    if (c < ASF_MID) {
+        float a = 0.f;
+        for (int k = 0; k < ASF_C; k++) a += w1[c * ASF_C + k] * mean[k];
+        mid[c] = fmaxf(a, 0.f);
+    }
+    __syncthreads();
+    float a = 0.f;
+    for (int k = 0; k < ASF_MID; k++) a += w2[c * ASF_MID + k] * mid[k];
+    ca[n * ASF_C + c] = sigm(a);
+}
+
+// 16 lanes per pixel
+__global__ __launch_bounds__(256) void asf_mean_kernel(const float *__restrict__ y, const float *__restrict__ ca, float *__restrict__ smean,
+                                                       int HW, long npix) {
+    const int sub = threadIdx.x & 15;
+    const long pix = blockIdx.x * 16L + (threadIdx.x >> 4);
+    float s = 0.f;
+    if (pix < npix) {
+        const int n = (int)(pix / HW);
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(y + pix * ASF_C + sub * 4);
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(ca + n * ASF_C + sub * 4);
+        s = (v[0] + a[0]) + (v[1] + a[1]) + (v[2] + a[2]) + (v[3] + a[3]);
+    }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o, 16);
+    if (pix < npix && sub == 0) smean[pix] = s / (float)ASF_C;
+}
+
+__global__ __launch_bounds__(256) void asf_apply_kernel(const float *__restrict__ y, const float *__restrict__ ca, const float *__restrict__ smean,
+                                                        const float *__restrict__ w3 /*[9]*/, float w1x1, const float *__restrict__ wa /*[4][64]*/,
+                                                        float *__restrict__ fuse, int H, int W, long npix) {
+    const int sub = threadIdx.x & 15;
+    const long pix = blockIdx.x * 16L + (threadIdx.x >> 4);
+    const int HW = H * W;
+    float sc[ASF_F] = {0.f, 0.f, 0.f, 0.f};
+    if (pix < npix) {
+        const int n = (int)(pix / HW);
+        const int rem = (int)(pix - (long)n * HW);
+        const int py = rem / W, px = rem - py * W;
+        float conv = 0.f;
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+            for (int dx = -1; dx <= 1; dx++) {
+                const int yy = py + dy, xx = px + dx;
+                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                    conv += w3[(dy + 1) * 3 + dx + 1] * smean[(long)n * HW + (long)yy * W + xx];
+            }
+        const float sa = sigm(w1x1 * fmaxf(conv, 0.f));
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(y + pix * ASF_C + sub * 4);
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(ca + n * ASF_C + sub * 4);
+        f32x4 g;
+#pragma unroll
+        for (int k = 0; k < 4; k++) g[k] = sa + (a[k] + v[k]);            // spatial_atten + (channel_atten + x)
+#pragma unroll
+        for (int i = 0; i < ASF_F; i++) {
+            const f32x4 w = *reinterpret_cast<const f32x4 *>(wa + i * ASF_C + sub * 4);
+            sc[i] = w[0] * g[0] + w[1] * g[1] + w[2] * g[2] + w[3] * g[3];
+        }
+    }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1)
+#pragma unroll
+        for (int i = 0; i < ASF_F; i++) sc[i] += __shfl_xor(sc[i], o, 16);
+    if (pix < npix) {
+        // lane `sub` scales channels [16*sub, 16*sub+16) of the 256-channel pixel: level = sub / 4
+        const float score = sigm(sc[sub >> 2]);
+        float *f = fuse + pix * (ASF_F * ASF_C) + sub * 16;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            f32x4 t = *reinterpret_cast<f32x4 *>(f + 4 * k);
+            t *= score;
+            *reinterpret_cast<f32x4 *>(f + 4 * k) = t;
+        }
+    }
+}
+
+}  // namespace ptocr
+
+using namespace ptocr;
+
+extern "C" int ptocr_asf_scale_channel_spatial_f32(const float *d_y, float *d_fuse, const float *d_w_cw1, const float *d_w_cw2,
+                                                   const float *d_w_sp3, float w_sp1, const float *d_w_att, float *d_work,
+                                                   int N, int H, int W, void *stream) {
+    PT_CHECK(d_y && d_fuse && d_w_cw1 && d_w_cw2 && d_w_sp3 && d_w_att && d_work && N >= 1 && N <= 65535, "ptocr_asf: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int HW = H * W;
+    const int nblk = cdiv(HW, POOL_PIX);
+    const long npix = (long)N * HW;
+    float *partial = d_work;                                  // [N][nblk][64]
+    float *ca = partial + (long)N * nblk * ASF_C;             // [N][64]
+    float *smean = ca + (long)N * ASF_C;                      // [N][H][W]
+    hipLaunchKernelGGL(asf_pool_kernel, dim3(nblk, N), dim3(256), 0, s, d_y, partial, HW, nblk);
+    hipLaunchKernelGGL(asf_channel_kernel, dim3(N), dim3(64), 0, s, partial, d_w_cw1, d_w_cw2, ca, HW, nblk);
+    hipLaunchKernelGGL(asf_mean_kernel, dim3((unsigned)cdiv((int)((npix + 15) / 16 * 16), 16)), dim3(256), 0, s, d_y, ca, smean, HW, npix);
+    hipLaunchKernelGGL(asf_apply_kernel, dim3((unsigned)cdiv((int)((npix + 15) / 16 * 16), 16)), dim3(256), 0, s, d_y, ca, smean, d_w_sp3, w_sp1,
+                       d_w_att, d_fuse, H, W, npix);
+    return launch_ok("asf kernels");
+}
+
+extern "C" long ptocr_asf_work_floats(int N, int H, int W) {
+    const long HW = (long)H * W;
+    return (long)N * cdiv((int)HW, POOL_PIX) * ASF_C + (long)N * ASF_C + (long)N * HW + 64;
+}

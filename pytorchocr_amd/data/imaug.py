@@ -1,0 +1,195 @@
+"""Inference pre-process operators (host side, numpy).  Mirrors of reference pytocr/data/imaug/operators.py
+(`DecodeImage` :14-38, `ToTensor` :41-72, `Normalize` :75-112, `KeepKeys` :115-124, `DetResizeForTest` :155-252) and
+rec_img_aug.py (`RecResizeImg` :40-53, `resize_norm_img` :108-134).
+
+cv2 is not a dependency here: `resize_bilinear` restates cv2.resize(INTER_LINEAR) for uint8 images in its
+fixed-point form (11-bit coefficients, half-pixel centres).  UNPINNED against OpenCV (absent from the image).
+"""
+import math
+
+import numpy as np
+import torch
+
+
+def resize_bilinear(img, dsize):
+    """cv2.resize(img, (w, h)) with INTER_LINEAR for uint8 (H,W[,C]) images; float images are interpolated in float."""
+    dw, dh = int(dsize[0]), int(dsize[1])
+    src = np.asarray(img)
+    sh, sw = src.shape[:2]
+    if (sh, sw) == (dh, dw):
+        return src.copy()
+
+    def coeffs(dn, sn):
+        scale = sn / float(dn)
+        f = (np.arange(dn, dtype=np.float64) + 0.5) * scale - 0.5
+        s0 = np.floor(f).astype(np.int64)
+        fr = (f - s0).astype(np.float32)
+        lo = s0 < 0
+        fr[lo] = 0
+        s0[lo] = 0
+        hi = s0 >= sn - 1
+        fr[hi] = 0
+        s0[hi] = sn - 1
+        s1 = np.minimum(s0 + 1, sn - 1)
+        return s0, s1, fr
+
+    x0, x1, fx = coeffs(dw, sw)
+    y0, y1, fy = coeffs(dh, sh)
+    if src.dtype == np.uint8:
+        ONE = 2048
+        ax1 = np.rint(fx * ONE).astype(np.int64)           # saturate_cast<short>(fx * INTER_RESIZE_COEF_SCALE)
+        ax0 = ONE - ax1
+        by1 = np.rint(fy * ONE).astype(np.int64)
+        by0 = ONE - by1
+        s = src.astype(np.int64)
+        shp = (1, dw) + (1,) * (s.ndim - 2)
+        rows = s[:, x0] * ax0.reshape(shp) + s[:, x1] * ax1.reshape(shp)            # horizontal pass, scale 2^11
+        shp = (dh, 1) + (1,) * (s.ndim - 2)
+        out = (rows[y0] * by0.reshape(shp) + rows[y1] * by1.reshape(shp) + (1 << 21)) >> 22
+        return np.clip(out, 0, 255).astype(np.uint8)
+    s = src.astype(np.float32)
+    shp = (1, dw) + (1,) * (s.ndim - 2)
+    rows = s[:, x0] * (1 - fx).reshape(shp) + s[:, x1] * fx.reshape(shp)
+    shp = (dh, 1) + (1,) * (s.ndim - 2)
+    return (rows[y0] * (1 - fy).reshape(shp) + rows[y1] * fy.reshape(shp)).astype(src.dtype)
+
+
+def bgr_to_gray(img):
+    """cv2.cvtColor(img, COLOR_BGR2GRAY) for uint8: fixed-point 0.114 B + 0.587 G + 0.299 R (15-bit coefficients)."""
+    b, g, r = (img[..., i].astype(np.int64) for i in range(3))
+    return ((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15).astype(np.uint8)
+
+
+class DecodeImage(object):
+    def __init__(self, img_mode="RGB", channel_first=False, **kwargs):
+        self.img_mode = img_mode
+        self.channel_first = channel_first
+
+    def __call__(self, data):
+        from PIL import Image
+        import io
+        img = data["image"]
+        if isinstance(img, (bytes, bytearray)):
+            img = np.array(Image.open(io.BytesIO(img)).convert("RGB"))[:, :, ::-1]      # BGR like cv2.imdecode
+        if self.img_mode == "GRAY":
+            img = bgr_to_gray(img)
+        elif self.img_mode == "RGB":
+            img = img[:, :, ::-1]
+        if self.channel_first:
+            img = img.transpose((2, 0, 1))
+        data["image"] = np.ascontiguousarray(img)
+        return data
+
+
+class ToTensor(object):
+    """torchvision to_tensor: uint8 HWC -> float32 CHW / 255"""
+
+    def __init__(self, **kwargs):
+        pass
+
+    def __call__(self, data):
+        img = data["image"]
+        if img.ndim == 2:
+            img = img[:, :, None]
+        t = torch.from_numpy(np.ascontiguousarray(img.transpose((2, 0, 1))))
+        data["image"] = t.to(torch.float32).div(255) if t.dtype == torch.uint8 else t
+        return data
+
+
+class Normalize(object):
+    def __init__(self, mean, std, inplace=False, **kwargs):
+        self.mean, self.std, self.inplace = mean, std, inplace
+
+    def __call__(self, data):
+        img = data["image"]
+        mean = torch.as_tensor(self.mean, dtype=img.dtype).view(-1, 1, 1)
+        std = torch.as_tensor(self.std, dtype=img.dtype).view(-1, 1, 1)
+        data["image"] = (img - mean) / std
+        return data
+
+
+class KeepKeys(object):
+    def __init__(self, keep_keys, **kwargs):
+        self.keep_keys = keep_keys
+
+    def __call__(self, data):          # returns a list, not a dict (reference operators.py:119-124)
+        return [data[key] for key in self.keep_keys]
+
+
+class DetResizeForTest(object):
+    def __init__(self, **kwargs):
+        self.resize_type = 0
+        if "image_shape" in kwargs:
+            self.image_shape = kwargs["image_shape"]
+            self.resize_type = 1
+        elif "limit_side_len" in kwargs:
+            self.limit_side_len = kwargs["limit_side_len"]
+            self.limit_type = kwargs.get("limit_type", "min")
+        elif "resize_long" in kwargs:
+            self.resize_type = 2
+            self.resize_long = kwargs.get("resize_long", 960)
+        else:
+            self.limit_side_len = 736
+            self.limit_type = "min"
+
+    def target_size(self, h, w):
+        """(resize_h, resize_w) the reference computes for an h x w image"""
+        if self.resize_type == 1:
+            return int(self.image_shape[0]), int(self.image_shape[1])
+        if self.resize_type == 2:
+            ratio = float(self.resize_long) / max(h, w)
+            rh, rw = int(h * ratio), int(w * ratio)
+            return (rh + 127) // 128 * 128, (rw + 127) // 128 * 128
+        if self.limit_type == "max":
+            ratio = float(self.limit_side_len) / (h if h > w else w)
+        elif self.limit_type == "min":
+            ratio = float(self.limit_side_len) / (h if h < w else w)
+        elif self.limit_type == "resize_long":
+            ratio = float(self.limit_side_len) / max(h, w)
+        else:
+            raise Exception("not support limit type, image ")
+        rh, rw = int(h * ratio), int(w * ratio)
+        return max(int(round(rh / 32) * 32), 32), max(int(round(rw / 32) * 32), 32)
+
+    def __call__(self, data):
+        img = data["image"]
+        src_h, src_w, _ = img.shape
+        rh, rw = self.target_size(src_h, src_w)
+        data["image"] = resize_bilinear(img, (rw, rh))
+        data["shape"] = np.array([src_h, src_w, rh / float(src_h), rw / float(src_w)])
+        return data
+
+
+def resize_norm_img(img, image_shape, resized_w=None, padding=True):
+    imgC, imgH, imgW = image_shape
+    h, w = img.shape[:2]
+    if not padding:
+        resized_image = resize_bilinear(img, (imgW, imgH))
+        resized_w = imgW
+    elif resized_w is not None:
+        resized_image = resize_bilinear(img, (resized_w, imgH))
+    else:
+        ratio = w / float(h)
+        resized_w = imgW if math.ceil(imgH * ratio) > imgW else int(math.ceil(imgH * ratio))
+        resized_image = resize_bilinear(img, (resized_w, imgH))
+    resized_image = resized_image.astype("float32")
+    if image_shape[0] == 1 and len(img.shape) == 2:
+        resized_image = resized_image / 255
+        resized_image = resized_image[np.newaxis, :]
+    else:
+        resized_image = resized_image.transpose((2, 0, 1)) / 255
+    resized_image -= 0.5
+    resized_image /= 0.5
+    padding_im = np.zeros((imgC, imgH, imgW), dtype=np.float32)
+    padding_im[:, :, 0:resized_w] = resized_image
+    return torch.from_numpy(padding_im)
+
+
+class RecResizeImg(object):
+    def __init__(self, image_shape, padding=True, **kwargs):
+        self.image_shape = image_shape
+        self.padding = padding
+
+    def __call__(self, data):
+        data["image"] = resize_norm_img(data["image"], self.image_shape, resized_w=None, padding=self.padding)
+        return data

@@ -1,0 +1,57 @@
+"""DB++ Adaptive Scale Fusion on the HIP engine (attention_type "scale_channel_spatial", the yml default).
+
+Mirror of reference `ScaleFeatureSelection` / `ScaleChannelSpatialAttention` (pytocr/modeling/necks/asf.py:32-75,
+110-162): 3x3 conv 256->64 WITH bias (MFMA), channel gate (avgpool -> 1x1 -> ReLU -> 1x1 -> sigmoid) ADDED to x,
+spatial gate (mean over C -> 3x3(1->1) -> ReLU -> 1x1 -> sigmoid) ADDED again, 1x1 64->4 + sigmoid, and
+out = concat_i(score_i * feat_i).  Parameter names are the reference's.  Because `fuse` already is the
+concatenation of the four (upsampled) features, the re-weighting happens in place on its channel slices.
+"""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from .. import ops
+from ... import _lib
+
+
+class ScaleChannelSpatialAttention(nn.Module):
+    def __init__(self, in_channels, mid_channels, num_features):
+        super().__init__()
+        self.channel_wise = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(in_channels, mid_channels, 1, bias=False), nn.ReLU(),
+                                          nn.Conv2d(mid_channels, in_channels, 1, bias=False), nn.Sigmoid())
+        self.spatial_wise = nn.Sequential(nn.Conv2d(1, 1, 3, padding=1, bias=False), nn.ReLU(), nn.Conv2d(1, 1, 1, bias=False), nn.Sigmoid())
+        self.attention_wise = nn.Sequential(nn.Conv2d(in_channels, num_features, 1, bias=False), nn.Sigmoid())
+
+
+class ScaleFeatureSelection(nn.Module):
+    def __init__(self, in_channels, inter_channels, out_features_num=4, attention_type="scale_spatial"):
+        super().__init__()
+        if attention_type != "scale_channel_spatial":
+            raise NotImplementedError("pytorchocr_amd ASF: only attention_type='scale_channel_spatial' (configs/det/det_r18_db.yml) is built")
+        if (in_channels, inter_channels, out_features_num) != (256, 64, 4):
+            raise NotImplementedError("pytorchocr_amd ASF kernels are specialised for 256 -> 64 channels, 4 levels")
+        self.conv = nn.Conv2d(in_channels, inter_channels, 3, padding=1)
+        self.type = attention_type
+        self.enhanced_attention = ScaleChannelSpatialAttention(inter_channels, inter_channels // 4, out_features_num)
+        self.out_features_num = out_features_num
+
+    def pack(self, dev):
+        a = self.enhanced_attention
+        f = lambda t: t.detach().float().cpu().contiguous()
+        return {"conv": ops.PackedConv(self.conv, None, dev, relu=False),
+                "cw1": f(a.channel_wise[1].weight).reshape(16, 64).to(dev), "cw2": f(a.channel_wise[3].weight).reshape(64, 16).to(dev),
+                "sp3": f(a.spatial_wise[0].weight).reshape(9).to(dev), "sp1": float(a.spatial_wise[2].weight.detach().reshape(-1)[0]),
+                "att": f(a.attention_wise[0].weight).reshape(4, 64).to(dev)}
+
+    @staticmethod
+    def run(p, fuse):
+        N, H, W, _ = fuse.shape
+        y = ops.conv2d(fuse, p["conv"])
+        L = _lib.lib()
+        L.ptocr_asf_work_floats.restype = C.c_long
+        work = torch.empty(L.ptocr_asf_work_floats(N, H, W), dtype=torch.float32, device=fuse.device)
+        _lib.check(L.ptocr_asf_scale_channel_spatial_f32(_lib.ptr(y), _lib.ptr(fuse), _lib.ptr(p["cw1"]), _lib.ptr(p["cw2"]),
+                                                         _lib.ptr(p["sp3"]), C.c_float(p["sp1"]), _lib.ptr(p["att"]), _lib.ptr(work),
+                                                         N, H, W, _lib.cur_stream()), "ptocr_asf_scale_channel_spatial_f32")
+        return fuse

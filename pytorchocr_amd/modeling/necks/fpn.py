@@ -21,8 +21,6 @@ class FPN(ops.PackedModule):
         super().__init__()
         if mode != "DB":
             raise NotImplementedError("pytorchocr_amd FPN: only mode='DB' is on the hot path")
-        if use_asf:
-            raise NotImplementedError("pytorchocr_amd FPN: DB++ ASF (use_asf=True) is not built yet (SURVEY.md 8a M5)")
         if (out_channels // 4) % 64 != 0:
             raise NotImplementedError("pytorchocr_amd FPN: out_channels//4 must be a multiple of 64 on the MFMA path "
                                       "(got out_channels=%d)" % out_channels)
@@ -37,16 +35,24 @@ class FPN(ops.PackedModule):
         self.out4 = _cbr(out_channels, sm, 3, 1)
         self.out3 = _cbr(out_channels, sm, 3, 1)
         self.out2 = _cbr(out_channels, sm, 3, 1)
+        if self.use_asf:    # DB++
+            from .asf import ScaleFeatureSelection
+            self.concat_attention = ScaleFeatureSelection(out_channels, sm, attention_type=attention_type)
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight)
+                if m.bias is not None:
+                    nn.init.normal_(m.bias)
             elif isinstance(m, nn.BatchNorm2d):
                 m.weight.data.fill_(1.)
                 m.bias.data.fill_(1e-4)
 
     def _pack(self, dev):
-        return {k: ops.PackedConv(getattr(self, k)[0], getattr(self, k)[1], dev, relu=True)
-                for k in ("in5", "in4", "in3", "in2", "out5", "out4", "out3", "out2")}
+        p = {k: ops.PackedConv(getattr(self, k)[0], getattr(self, k)[1], dev, relu=True)
+             for k in ("in5", "in4", "in3", "in2", "out5", "out4", "out3", "out2")}
+        if self.use_asf:
+            p["asf"] = self.concat_attention.pack(dev)
+        return p
 
     def forward_nhwc(self, feats):
         self._check_eval()
@@ -63,6 +69,8 @@ class FPN(ops.PackedModule):
         ops.conv2d(out4, p["out4"], out=fuse, out_up=4, out_coff=sm)
         ops.conv2d(out3, p["out3"], out=fuse, out_up=2, out_coff=2 * sm)
         ops.conv2d(out2, p["out2"], out=fuse, out_up=1, out_coff=3 * sm)
+        if self.use_asf:
+            self.concat_attention.run(p["asf"], fuse)          # re-weights the four 64-channel slices in place
         return fuse
 
     def forward(self, x):

@@ -119,7 +119,7 @@ def test_convtranspose_and_head_tail():
     y = ops.conv2d(_nhwc(x).to(dev), pt)
     assert (y.cpu().permute(0, 3, 1, 2) - mid).abs().max().item() <= 2e-5
     w4 = t6.weight.detach()[:, 0].permute(1, 2, 0).reshape(4, -1).contiguous().to(dev)
-    maps = ops.convt2x2_sigmoid(y, w4, float(t6.bias[0]))
+    maps = ops.convt2x2_sigmoid(y, w4, float(t6.bias.detach()[0]))
     assert maps.shape == ref.shape
     assert (maps.cpu() - ref).abs().max().item() <= 1e-5
 

@@ -67,3 +67,25 @@ def test_cpu_input_fails_loudly(contract):
     m = _model(contract)
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 3, 64, 64))
+
+
+def test_dbpp_asf_matches_reference(gold_dir, contract):
+    """DB++ (use_asf=True, scale_channel_spatial): maps vs the reference's own output, and a larger ragged batch vs the oracle."""
+    from oracle import model_oracle
+    from pytorchocr_amd.modeling.architectures import build_model
+    cfg = dict(DET_R18, Neck=dict(DET_R18["Neck"], use_asf=True))
+    m = build_model(cfg)
+    sd = synth_state_dict(contract["detpp_r18_db"])
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.to("cuda:0").eval()
+    g = np.load(os.path.join(gold_dir, "detpp_r18_db_1x3x64x96.npz"))
+    x = torch.from_numpy(synth_images(1, 3, 64, 96, seed=int(g["seed"]))).cuda()
+    with torch.no_grad():
+        y = m(x)["maps"].cpu().numpy()
+    assert np.abs(y - g["maps"]).max() <= 1e-4
+    xs = synth_images(3, 3, 160, 224, seed=21)
+    with torch.no_grad():
+        y = m(torch.from_numpy(xs).cuda())["maps"].cpu().numpy()
+    ref = model_oracle.dbnet_r18_forward(sd, torch.from_numpy(xs))["maps"].numpy()
+    assert np.abs(y - ref).max() <= 1e-4

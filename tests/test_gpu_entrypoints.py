@@ -1,0 +1,76 @@
+"""Entry-point counterparts (Deter / Recer / OCRer) on the GPU against the oracle pipeline on the same preprocessed input."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ctc_oracle, dbpost, model_oracle
+from pytorchocr_amd.utils.synth import synth_state_dict, uniform01
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "pytorchocr_amd", "configs")
+
+
+def _ckpt(tmp_path, contract, name, wrap=False, prefix=""):
+    sd = synth_state_dict(contract[name])
+    t = {prefix + k: torch.from_numpy(v) for k, v in sd.items()}
+    p = os.path.join(str(tmp_path), name + ".pth")
+    torch.save({"state_dict": t} if wrap else t, p)
+    return p, sd
+
+
+def test_deter_matches_oracle_pipeline(tmp_path, contract):
+    from pytorchocr_amd.deploy.infer_det import Deter
+    from pytorchocr_amd.utils.utility import sort_boxes
+    ck, sd = _ckpt(tmp_path, contract, "det_r18_db", wrap=True, prefix="module.")        # DDP-style checkpoint
+    det = Deter(os.path.join(CFG, "det", "det_r18_db.yml"), ck, gpu_id=0)
+    img = (uniform01(200 * 320 * 3, 5).reshape(200, 320, 3) * 255).astype(np.uint8)      # BGR ndarray instead of a path
+    boxes = det.run(img)
+    x, shape = det._prep(img)
+    assert tuple(x.shape) == (3, 736, 1184)
+    maps = model_oracle.dbnet_r18_forward(sd, x[None])["maps"].numpy()[0, 0]
+    with torch.no_grad():
+        got_maps = det.deter(x[None].cuda())["maps"].cpu().numpy()[0, 0]
+    assert np.abs(got_maps - maps).max() <= 1e-4
+    exp = dbpost.boxes_from_bitmap(got_maps, dbpost.binarize(got_maps, 0.3), 0.5, 1.7, 320, 200)
+    exp = sort_boxes(exp.astype(np.int16))
+    assert len(boxes) == len(exp) and all(np.array_equal(a, b) for a, b in zip(boxes, exp))
+    two = det.run_batch([img, img[::-1].copy()])
+    assert len(two) == 2 and all(np.array_equal(a, b) for a, b in zip(two[0], boxes))
+
+
+def test_recer_and_ocrer_batched_equals_per_crop(tmp_path, contract, monkeypatch):
+    from pytorchocr_amd.deploy.infer_rec import Recer
+    from pytorchocr_amd.deploy.run_ocr import OCRer
+    ck, sd = _ckpt(tmp_path, contract, "rec_vgg_bilstm_ctc")
+    rec = Recer(os.path.join(CFG, "rec", "rec_vgg_bilstm_ctc.yml"), ck)
+    rng = np.random.default_rng(3)
+    crops = []
+    for k in range(5):
+        w = 60 + 45 * k
+        base = np.repeat(rng.integers(0, 255, size=(1, (w + 7) // 8, 1)), 8, axis=1)[:, :w]
+        crops.append(np.clip(base + rng.integers(0, 30, size=(24 + 4 * k, w, 3)), 0, 255).astype(np.uint8))
+    single = [rec.run(c) for c in crops]
+    batched = rec.run_batch(crops)
+    assert [t for t, _ in single] == [t for t, _ in batched]
+    assert np.allclose([p for _, p in single], [p for _, p in batched], atol=0.011, equal_nan=True)
+    # oracle on the same preprocessed crops
+    x = torch.stack([rec._prep(c) for c in crops])
+    ref = ctc_oracle.ctc_label_decode(model_oracle.crnn_forward(sd, x).numpy(), ctc_oracle.load_characters(
+        os.path.join(ROOT, "pytorchocr_amd", "utils", "char_dict_6623.txt")))
+    assert [t for t, _ in ref] == [t for t, _ in batched]
+
+    dck, _ = _ckpt(tmp_path, contract, "det_r18_db")
+    ocr = OCRer(os.path.join(CFG, "det", "det_r18_db.yml"), dck, os.path.join(CFG, "rec", "rec_vgg_bilstm_ctc.yml"), ck)
+    img = (uniform01(240 * 400 * 3, 9).reshape(240, 400, 3) * 255).astype(np.uint8)
+    fake = [np.array([[20, 30], [220, 34], [219, 70], [19, 66]], np.int16), np.array([[300, 20], [330, 20], [330, 200], [300, 200]], np.int16)]
+    monkeypatch.setattr(ocr.det, "run", lambda im: fake)
+    res = ocr.run(img)
+    assert len(res) == 2 and all(len(r) == 3 and isinstance(r[1], str) for r in res)
+    from pytorchocr_amd.utils.warp import get_part_img
+    tall = get_part_img(img, fake[1])
+    assert tall.shape[0] >= 1.5 * tall.shape[1]                       # second box is rotated 90 degrees before recognition
+    exp1 = rec.run(np.ascontiguousarray(np.rot90(tall, 1)))
+    assert res[1][1] == exp1[0]

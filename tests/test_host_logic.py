@@ -72,7 +72,8 @@ def test_unsupported_options_raise():
     with pytest.raises(NotImplementedError):
         build_post_process(dict(name="DBPostProcess", cpp_speedup=True, use_dilation=True), {})
     with pytest.raises(NotImplementedError):
-        build_model(dict(DET, Neck=dict(DET["Neck"], use_asf=True)))
+        build_model(dict(DET, Neck=dict(DET["Neck"], use_asf=True, attention_type="scale_spatial")))
+    assert hasattr(build_model(dict(DET, Neck=dict(DET["Neck"], use_asf=True))).neck, "concat_attention")
     with pytest.raises(NotImplementedError):
         build_model(dict(DET, Backbone=dict(name="ResNet", layers=50)))
     with pytest.raises(AssertionError):

@@ -1,0 +1,85 @@
+"""Host-side callers around the path (no GPU): sort_boxes (P8), config loading, inference operators, crop warp."""
+import os
+
+import numpy as np
+import torch
+
+from pytorchocr_amd.data import create_operators, transform
+from pytorchocr_amd.data.imaug import DetResizeForTest, RecResizeImg, bgr_to_gray, resize_bilinear
+from pytorchocr_amd.deploy.common import inference_transforms
+from pytorchocr_amd.utils.config import load_config, merge_config
+from pytorchocr_amd.utils.utility import sort_boxes
+from pytorchocr_amd.utils.warp import get_part_img
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _box(x, y, w=20, h=8):
+    return [[x, y], [x + w, y], [x + w, y + h], [x, y + h]]
+
+
+def test_sort_boxes_known_answers():
+    b = np.array([_box(5, 30), _box(60, 25), _box(10, 5)], np.int16)
+    assert [x[0].tolist() for x in sort_boxes(b)] == [[10, 5], [5, 30], [60, 25]]        # one adjacent swap (|dy| < 10)
+    # only ONE pass: a run of three out-of-order boxes on a line is not fully sorted (reference utility.py:44-49)
+    b = np.array([_box(90, 10), _box(50, 12), _box(10, 14)], np.int16)
+    assert [x[0][0] for x in sort_boxes(b)] == [50, 10, 90]
+    b = np.array([_box(10, 0), _box(5, 10)], np.int16)                                  # |dy| == 10 is not < 10
+    assert [x[0][0] for x in sort_boxes(b)] == [10, 5]
+    assert sort_boxes(np.zeros((0,), np.int16)) == []                                   # K = 0 from DBPostProcess
+    assert all(isinstance(x, np.ndarray) and x.dtype == np.int16 for x in sort_boxes(np.array([_box(1, 1)], np.int16)))
+
+
+def test_load_config_and_dotted_merge():
+    cfg = load_config(os.path.join(ROOT, "pytorchocr_amd", "configs", "det", "det_r18_db.yml"))
+    assert cfg.Architecture["Backbone"]["layers"] == 18 and cfg["Global"]["debug"] is False
+    merge_config({"PostProcess.unclip_ratio": 2.0, "Global": {"seed": 1}}, cfg)
+    assert cfg["PostProcess"]["unclip_ratio"] == 2.0 and cfg["Global"]["seed"] == 1 and cfg["Global"]["use_gpu"] is True
+    t, mode = inference_transforms(cfg, ["image", "shape"])
+    assert mode == "RGB" and [list(o)[0] for o in t] == ["DetResizeForTest", "ToTensor", "Normalize", "KeepKeys"]
+
+
+def test_det_transform_pipeline_shapes():
+    cfg = load_config(os.path.join(ROOT, "pytorchocr_amd", "configs", "det", "det_r18_db.yml"))
+    t, _ = inference_transforms(cfg, ["image", "shape"])
+    ops = create_operators(t, cfg["Global"])
+    img = (np.arange(720 * 1280 * 3) % 251).astype(np.uint8).reshape(720, 1280, 3)
+    out = transform({"image": img}, ops)
+    assert isinstance(out, list) and tuple(out[0].shape) == (3, 736, 1312) and out[0].dtype == torch.float32
+    assert np.allclose(out[1], [720, 1280, 736 / 720, 1312 / 1280])
+    r = DetResizeForTest(limit_side_len=736, limit_type="min")
+    assert r.target_size(960, 1280) == (736, 992)
+    assert r.target_size(736, 1280) == (736, 1280)
+    assert DetResizeForTest(image_shape=[640, 640]).target_size(100, 50) == (640, 640)
+    assert DetResizeForTest(resize_long=960).target_size(500, 1000) == (512, 1024)
+
+
+def test_resize_bilinear_properties():
+    img = (np.random.default_rng(0).random((37, 53, 3)) * 255).astype(np.uint8)
+    assert np.array_equal(resize_bilinear(img, (53, 37)), img)
+    up = resize_bilinear(np.full((4, 4), 77, np.uint8), (9, 7))
+    assert up.shape == (7, 9) and (up == 77).all()
+    ramp = np.tile(np.arange(0, 200, 2, dtype=np.uint8), (8, 1))          # horizontal ramp stays a ramp when halved
+    half = resize_bilinear(ramp, (50, 8))
+    assert np.array_equal(half[0], np.arange(1, 199, 4).astype(np.uint8))
+    g = bgr_to_gray(np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255]]], np.uint8))
+    assert g.tolist() == [[29, 150, 76, 255]]
+
+
+def test_rec_resize_img_pads_right_and_normalises():
+    op = RecResizeImg(image_shape=[1, 32, 320])
+    img = np.full((16, 40), 255, np.uint8)
+    x = op({"image": img})["image"]
+    assert tuple(x.shape) == (1, 32, 320) and x.dtype == torch.float32
+    assert float(x[0, :, :80].min()) == 1.0 and float(x[0, :, 80:].abs().max()) == 0.0
+    wide = np.zeros((10, 400), np.uint8)
+    assert float(RecResizeImg(image_shape=[1, 32, 320])({"image": wide})["image"].max()) == -1.0      # capped at W=320
+
+
+def test_get_part_img_axis_aligned_is_a_plain_crop():
+    img = (np.random.default_rng(1).random((60, 90, 3)) * 255).astype(np.uint8)
+    box = np.array([[10, 20], [50, 20], [50, 40], [10, 40]])
+    crop = get_part_img(img, box)
+    assert crop.shape == (20, 40, 3)
+    # dst corners are (0,0)..(w-1,h-1) for src (0,0)..(w,h): a mild (w/(w-1)) stretch, interior stays close to the source
+    assert np.abs(crop[0, 0].astype(int) - img[20, 10].astype(int)).max() == 0

@@ -39,3 +39,10 @@ def test_crnn_oracle_matches_reference(gold_dir, contract):
     assert np.array_equal(idx, g["idx"])
     assert np.abs(p.transpose(1, 0, 2).max(axis=2) - g["prob"]).max() <= 1e-5
     assert (g["idx"] == 0).any() and (g["idx"] != 0).any()
+
+
+def test_dbpp_oracle_matches_reference(gold_dir, contract):
+    g = np.load(os.path.join(gold_dir, "detpp_r18_db_1x3x64x96.npz"))
+    sd = synth_state_dict(contract["detpp_r18_db"])
+    x = torch.from_numpy(synth_images(1, 3, 64, 96, seed=int(g["seed"])))
+    assert np.abs(model_oracle.dbnet_r18_forward(sd, x)["maps"].numpy() - g["maps"]).max() <= 1e-6
