@@ -48,11 +48,13 @@ typedef struct {
     int Cout, KH, KW;          /* weights packed f32[Cout][Kpad], K index = (kh*KW + kw)*Cin + ci, Kpad = roundup(KH*KW*Cin, 32) */
     int stride, pad_h, pad_w;
     int Ho, Wo;                /* output spatial size (before out_up / convt expansion) */
-    int relu;                  /* 1: ReLU in the epilogue */
+    int relu;                  /* epilogue activation: 0 none, 1 ReLU, 2 Hardswish */
     int res_mode;              /* PTOCR_RES_*: d_res is f32[N,Ho,Wo,Cout] (PRE_RELU) or f32[N,Ho/2,Wo/2,Cout] (UP2_POST_RELU) */
     int out_up;                /* >= 1: every output pixel is stored to an out_up x out_up block (nearest upsample) */
     int out_ldc, out_coff;     /* output tensor channel stride / channel offset (concat-in-place); ldc >= coff + Cout */
     int convt2x2;              /* 1: ConvTranspose2d k=2 s=2: Cout here = 4*Co, column (a*2+b)*Co + co goes to pixel (2y+a, 2x+b) */
+    int cout_store;            /* 0 = all; else only columns < cout_store are written (weights padded to Cout % 64 == 0) */
+    int res_ldc;               /* channel stride of d_res (0 = Cout) */
 } ptocr_conv_desc;
 
 int ptocr_conv2d_f32(const ptocr_conv_desc *d, const float *d_x, const float *d_w, const float *d_bias,
@@ -69,6 +71,15 @@ int ptocr_maxpool2d_f32(const float *d_x, float *d_y, int N, int H, int W, int C
  * d_w f32[4][C] (index a*2+b), bias scalar -> d_maps f32[N,2H,2W]. */
 int ptocr_convt2x2_sigmoid_f32(const float *d_x, const float *d_w, float bias, float *d_maps, int N, int H, int W,
                                int C, void *stream);
+
+/* Depthwise conv (groups == C) + folded BN bias + activation (0 none / 1 ReLU / 2 Hardswish), NHWC, C % 4 == 0.
+ * d_w f32[k*k][C] (tap-major), pad = (k-1)/2.  (MobileNetV3 InvertedResidual.conv2, det_mobilenet_v3.py:123-126) */
+int ptocr_dwconv_f32(const float *d_x, const float *d_w, const float *d_bias, float *d_y, int N, int H, int W, int C, int k,
+                     int stride, int act, void *stream);
+/* Squeeze-Excitation (det_mobilenet_v3.py:67-85): x[n,:,:,c] *= hardsigmoid(fc2(relu(fc1(mean_hw(x))))) in place.
+ * d_w1 f32[S][C], d_b1 f32[S], d_w2 f32[C][S], d_b2 f32[C]; d_work: N*(ceil(H*W/2048)+1)*C floats. C <= 1024, S <= 256. */
+int ptocr_se_scale_f32(float *d_x, const float *d_w1, const float *d_b1, const float *d_w2, const float *d_b2, float *d_work,
+                       int N, int H, int W, int C, int S, void *stream);
 
 /* DB++ Adaptive Scale Fusion, attention_type "scale_channel_spatial" (asf.py:32-75,146-162), after its 3x3 conv (+bias) has
  * produced d_y f32[N,H,W,64] with ptocr_conv2d_f32.  Scales d_fuse f32[N,H,W,256] IN PLACE: channels [64i,64i+64) *= score_i.

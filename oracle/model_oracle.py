@@ -103,6 +103,66 @@ def db_head_forward(sd, x, prefix="head.binarize."):
     return torch.sigmoid(x)
 
 
+def _cba_mb(sd, p, x, stride, groups, act):
+    w = _t(sd, p + ".0.weight")
+    x = F.conv2d(x, w, None, stride, (w.shape[2] - 1) // 2, 1, groups)
+    x = _bn(sd, p + ".1", x, eps=1e-3)
+    return F.hardswish(x) if act == "HS" else F.relu(x) if act == "RE" else x
+
+
+def mobilenetv3_forward(sd, x, prefix="backbone."):
+    """MobileNetV3 (any variant present in sd): pytocr/modeling/backbones/det_mobilenet_v3.py:139-151,270-276."""
+    x = _cba_mb(sd, prefix + "conv1", x, 2, 1, "HS")
+    outs, s = [], 0
+    while (prefix + "stages.%d.0.conv2.0.weight" % s) in sd or (prefix + "stages.%d.0.0.weight" % s) in sd:
+        b = 0
+        while True:
+            p = prefix + "stages.%d.%d" % (s, b)
+            if (p + ".conv2.0.weight") in sd:
+                wd = _t(sd, p + ".conv2.0.weight")
+                exp, k = wd.shape[0], wd.shape[2]
+                cin = x.shape[1]
+                cout = _t(sd, p + ".conv3.0.weight").shape[0]
+                # activation / stride are not in the state_dict: recover them from the architecture table
+                act, stride = _MBV3_ACT_STRIDE[(cin, k, exp, cout)]
+                out = _cba_mb(sd, p + ".conv1", x, 1, 1, act) if (p + ".conv1.0.weight") in sd else x
+                out = _cba_mb(sd, p + ".conv2", out, stride, exp, act)
+                if (p + ".se.fc1.weight") in sd:
+                    sc = F.adaptive_avg_pool2d(out, 1)
+                    sc = F.relu(F.conv2d(sc, _t(sd, p + ".se.fc1.weight"), _t(sd, p + ".se.fc1.bias")))
+                    sc = F.hardsigmoid(F.conv2d(sc, _t(sd, p + ".se.fc2.weight"), _t(sd, p + ".se.fc2.bias")))
+                    out = sc * out
+                out = _cba_mb(sd, p + ".conv3", out, 1, 1, None)
+                x = out + x if (stride == 1 and cin == cout) else out
+            elif (p + ".0.weight") in sd:
+                x = _cba_mb(sd, p, x, 1, 1, "HS")
+            else:
+                break
+            b += 1
+        outs.append(x)
+        s += 1
+    return outs
+
+
+# (in, kernel, expanded, out) -> (activation, stride) for width 1.0 (det_mobilenet_v3.py:282-325)
+_MBV3_ACT_STRIDE = {
+    (16, 3, 16, 16): ("RE", 2), (16, 3, 72, 24): ("RE", 2), (24, 3, 88, 24): ("RE", 1), (24, 5, 96, 40): ("HS", 2),
+    (40, 5, 240, 40): ("HS", 1), (40, 5, 120, 48): ("HS", 1), (48, 5, 144, 48): ("HS", 1), (48, 5, 288, 96): ("HS", 2),
+    (96, 5, 576, 96): ("HS", 1),
+}
+
+
+def dbnet_forward(sd, x, return_feats=False):
+    """DBNet with whichever backbone the state_dict holds (ResNet-18 or MobileNetV3-small x1.0)."""
+    with torch.no_grad():
+        feats = mobilenetv3_forward(sd, x) if "backbone.stages.0.0.conv2.0.weight" in sd else resnet18_forward(sd, x)
+        fuse = fpn_db_forward(sd, feats)
+        maps = db_head_forward(sd, fuse)
+    if return_feats:
+        return {"maps": maps, "backbone_out": feats, "neck_out": fuse}
+    return {"maps": maps}
+
+
 def dbnet_r18_forward(sd, x, return_feats=False):
     """x: f32[N,3,H,W] (H,W multiples of 32) -> {"maps": f32[N,1,H,W]}."""
     with torch.no_grad():

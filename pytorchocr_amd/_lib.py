@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "libptocr_hip.so")
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "N", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad_h", "pad_w", "Ho", "Wo",
-        "relu", "res_mode", "out_up", "out_ldc", "out_coff", "convt2x2")]
+        "relu", "res_mode", "out_up", "out_ldc", "out_coff", "convt2x2", "cout_store", "res_ldc")]
 
 
 RES_NONE, RES_ADD_PRE_RELU, RES_ADD_UP2_POST_RELU = 0, 1, 2
@@ -38,7 +38,7 @@ def lib():
 EXPORTS = [
     "ptocr_last_error", "ptocr_version", "ptocr_device_arch",
     "ptocr_conv2d_f32", "ptocr_nchw_to_nhwc_f32", "ptocr_nhwc_to_nchw_f32", "ptocr_maxpool2d_f32",
-    "ptocr_convt2x2_sigmoid_f32", "ptocr_asf_scale_channel_spatial_f32", "ptocr_asf_work_floats",
+    "ptocr_convt2x2_sigmoid_f32", "ptocr_asf_scale_channel_spatial_f32", "ptocr_asf_work_floats", "ptocr_dwconv_f32", "ptocr_se_scale_f32",
     "ptocr_dbpost_create", "ptocr_dbpost_destroy", "ptocr_db_postprocess", "ptocr_dbpost_debug_results",
     "ptocr_linear_f32", "ptocr_lstm_bidir_f32", "ptocr_ctc_greedy_f32", "ptocr_softmax_rows_f32",
 ]

@@ -23,6 +23,12 @@ namespace ptocr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.f);                                  // ReLU
+    if (act == 2) return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);   // Hardswish: x * relu6(x + 3) / 6
+    return v;
+}
+
 constexpr int BK = 32;
 constexpr int LDT = BK + 4;   // LDS row stride in floats
 
@@ -35,6 +41,8 @@ struct ConvArgs {
     int mtiles;
     long x_bytes, w_bytes;
     int vec_epilogue;
+    int cout_store;                 // columns >= cout_store are not written (channel-padded GEMMs)
+    int res_ldc;                    // channel stride of the residual tensor
 };
 
 __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x16 (&acc)[2][2], int m0, int n0, int wm0, int wn0, int frow, int fh) {
@@ -57,10 +65,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x16 (&acc)[2
             for (int j = 0; j < 2; j++) {
                 const int col = n0 + wn0 + j * 32 + frow;
                 float v = acc[i][j][r] + p.bias[col];
-                if (p.res_mode == PTOCR_RES_ADD_PRE_RELU) v += p.res[(long)m * p.Cout + col];
-                if (p.relu) v = fmaxf(v, 0.f);
+                if (col >= p.cout_store) continue;
+                if (p.res_mode == PTOCR_RES_ADD_PRE_RELU) v += p.res[(long)m * p.res_ldc + col];
+                v = act_apply(v, p.relu);
                 if (p.res_mode == PTOCR_RES_ADD_UP2_POST_RELU)
-                    v += p.res[(((long)n * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * p.Cout + col];
+                    v += p.res[(((long)n * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * p.res_ldc + col];
                 if (p.convt) {
                     const int ab = col / p.co_real, co = col - ab * p.co_real;
                     const int Y = 2 * oy + (ab >> 1), X = 2 * ox + (ab & 1);
@@ -91,7 +100,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs &p, f32x16 (&ac
     const int col = n0 + wn0 + chunk * 4;
     const f32x4 bias4 = *reinterpret_cast<const f32x4 *>(p.bias + col);
     const bool need_pix = p.res_mode == PTOCR_RES_ADD_UP2_POST_RELU || p.out_up > 1 || p.convt;
-    const int ab = (n0 + wn0) / p.co_real;                       // convt: the wave's 64 columns belong to one (a,b)
+    const int ab = col / p.co_real;                              // convt: a 4-column chunk never straddles two (a,b) groups
     const int co = col - ab * p.co_real;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
@@ -107,7 +116,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs &p, f32x16 (&ac
         for (int q = 0; q < 8; q++) {
             const int row = rsub + 4 * q;
             const int m = m0 + wm0 + i * 32 + row;
-            if (m >= p.M) continue;
+            if (m >= p.M || col >= p.cout_store) continue;
             f32x4 v = *reinterpret_cast<const f32x4 *>(wsm + row * EL + chunk * 4);
             v += bias4;
             int n = 0, oy = 0, ox = 0;
@@ -116,10 +125,10 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs &p, f32x16 (&ac
                 const int rem = m - n * HoWo;
                 oy = rem / p.Wo; ox = rem - oy * p.Wo;
             }
-            if (p.res_mode == PTOCR_RES_ADD_PRE_RELU) v += *reinterpret_cast<const f32x4 *>(p.res + (long)m * p.Cout + col);
-            if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            if (p.res_mode == PTOCR_RES_ADD_PRE_RELU) v += *reinterpret_cast<const f32x4 *>(p.res + (long)m * p.res_ldc + col);
+            if (p.relu) { v[0] = act_apply(v[0], p.relu); v[1] = act_apply(v[1], p.relu); v[2] = act_apply(v[2], p.relu); v[3] = act_apply(v[3], p.relu); }
             if (p.res_mode == PTOCR_RES_ADD_UP2_POST_RELU)
-                v += *reinterpret_cast<const f32x4 *>(p.res + (((long)n * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * p.Cout + col);
+                v += *reinterpret_cast<const f32x4 *>(p.res + (((long)n * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * p.res_ldc + col);
             if (p.convt) {
                 const int Y = 2 * oy + (ab >> 1), X = 2 * ox + (ab & 1);
                 *reinterpret_cast<f32x4 *>(p.y + (((long)n * (2 * p.Ho) + Y) * (2 * p.Wo) + X) * p.out_ldc + p.out_coff + co) = v;
@@ -460,7 +469,10 @@ extern "C" int ptocr_conv2d_f32(const ptocr_conv_desc *d, const float *d_x, cons
     PT_CHECK(!(d->convt2x2 && (d->KH != 1 || d->KW != 1 || d->stride != 1 || d->Cout % 4)), "convt2x2 is a 1x1 GEMM with Cout=4*Co");
     PT_CHECK((long)d->N * d->Ho * d->Wo < (1L << 31), "ptocr_conv2d_f32: too many output pixels");
     const int co_real = d->convt2x2 ? d->Cout / 4 : d->Cout;
-    PT_CHECK(d->out_ldc >= d->out_coff + co_real, "ptocr_conv2d_f32: out_ldc too small");
+    PT_CHECK(d->relu >= 0 && d->relu <= 2, "ptocr_conv2d_f32: relu/activation must be 0 (none), 1 (ReLU) or 2 (Hardswish)");
+    PT_CHECK(d->cout_store >= 0 && d->cout_store <= d->Cout && d->cout_store % 4 == 0, "ptocr_conv2d_f32: cout_store must be a multiple of 4, <= Cout");
+    PT_CHECK(!(d->convt2x2 && d->cout_store && d->cout_store != d->Cout), "ptocr_conv2d_f32: cout_store is not used with convt2x2");
+    PT_CHECK(d->out_ldc >= d->out_coff + (d->convt2x2 ? co_real : (d->cout_store ? d->cout_store : co_real)), "ptocr_conv2d_f32: out_ldc too small");
     ConvArgs a;
     a.x = d_x; a.w = d_w; a.bias = d_bias; a.res = d_res; a.y = d_y;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW;
@@ -471,12 +483,14 @@ extern "C" int ptocr_conv2d_f32(const ptocr_conv_desc *d, const float *d_x, cons
     a.nk = a.Kpad / BK;
     a.relu = d->relu; a.res_mode = d->res_mode; a.out_up = d->out_up; a.out_ldc = d->out_ldc; a.out_coff = d->out_coff;
     a.convt = d->convt2x2; a.co_real = co_real;
+    a.cout_store = d->cout_store > 0 ? d->cout_store : d->Cout;
+    a.res_ldc = d->res_ldc > 0 ? d->res_ldc : d->Cout;
     hipStream_t s = (hipStream_t)stream;
     const bool smallc = d->Cin == 4;
     a.x_bytes = (long)d->N * d->H * d->W * d->Cin * 4;
     a.w_bytes = (long)d->Cout * a.Kpad * 4;
     const int impl = conv_impl();
-    a.vec_epilogue = (d->out_ldc % 4 == 0 && d->out_coff % 4 == 0 && co_real % 4 == 0 && !getenv("PTOCR_CONV_SCALAR_EPILOGUE")) ? 1 : 0;
+    a.vec_epilogue = ((d->res_ldc % 4) == 0 && d->out_ldc % 4 == 0 && d->out_coff % 4 == 0 && co_real % 4 == 0 && !getenv("PTOCR_CONV_SCALAR_EPILOGUE")) ? 1 : 0;
     if (impl >= 2 && a.x_bytes < (1L << 31) && a.w_bytes < (1L << 31)) {
         if (d->Cout % 128 == 0 && !smallc) {
             a.mtiles = cdiv(a.M, 128);

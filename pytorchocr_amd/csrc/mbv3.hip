@@ -1,0 +1,123 @@
+// MobileNetV3 pieces that are not GEMMs: depthwise conv and Squeeze-Excitation.  Both are memory-bound (HBM roofline).
+// Replaces nn.Conv2d(groups=C)+BN+act (det_mobilenet_v3.py:123-126) and SqueezeExcitation (:67-85).
+#include "common.h"
+
+namespace ptocr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float act1(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.f);
+    if (act == 2) return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    return v;
+}
+
+// one thread per (output pixel, 4 channels); consecutive threads walk channels, so loads/stores are 16 B coalesced
+__global__ __launch_bounds__(256) void dwconv_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                                                     float *__restrict__ y, int H, int W, int C4, int k, int stride, int Ho, int Wo, int act, long total) {
+    const int pad = (k - 1) / 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long r = i / C4;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const long n = r / Ho;
+        f32x4 acc = *reinterpret_cast<const f32x4 *>(bias + c * 4);
+        for (int a = 0; a < k; a++) {
+            const int iy = oy * stride - pad + a;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            for (int b = 0; b < k; b++) {
+                const int ix = ox * stride - pad + b;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(x + (((n * H + iy) * W + ix) * (long)C4 + c) * 4);
+                const f32x4 ww = *reinterpret_cast<const f32x4 *>(w + ((long)(a * k + b) * C4 + c) * 4);
+                acc += v * ww;
+            }
+        }
+        acc[0] = act1(acc[0], act); acc[1] = act1(acc[1], act); acc[2] = act1(acc[2], act); acc[3] = act1(acc[3], act);
+        *reinterpret_cast<f32x4 *>(y + i * 4) = acc;
+    }
+}
+
+constexpr int SE_PIX = 2048;
+
+// partial sums over pixel chunks: block = (C/4 channel quads) x (256 / (C/4)) pixel lanes, deterministic tree per block
+__global__ __launch_bounds__(256) void se_pool_kernel(const float *__restrict__ x, float *__restrict__ partial, int HW, int C, int nblk) {
+    const int n = blockIdx.y, blk = blockIdx.x;
+    const int C4 = C >> 2;
+    const int p0 = blk * SE_PIX, p1 = min(p0 + SE_PIX, HW);
+    // thread t handles channel quads q = t, t+256, ... (C4 may exceed 256) over all pixels of the chunk: coalesced along channels
+    for (int q = threadIdx.x; q < C4; q += 256) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int p = p0; p < p1; p++) s += *reinterpret_cast<const f32x4 *>(x + ((long)n * HW + p) * C + q * 4);
+        *reinterpret_cast<f32x4 *>(partial + ((long)n * nblk + blk) * C + q * 4) = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void se_fc_kernel(const float *__restrict__ partial, const float *__restrict__ w1, const float *__restrict__ b1,
+                                                    const float *__restrict__ w2, const float *__restrict__ b2, float *__restrict__ scale,
+                                                    int HW, int C, int S, int nblk) {
+    const int n = blockIdx.x;
+    __shared__ float mean[1024], mid[256];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int b = 0; b < nblk; b++) s += partial[((long)n * nblk + b) * C + c];
+        mean[c] = s / (float)HW;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < S; j += 256) {
+        float a = b1[j];
+        for (int c = 0; c < C; c++) a += w1[(long)j * C + c] * mean[c];
+        mid[j] = fmaxf(a, 0.f);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = b2[c];
+        for (int j = 0; j < S; j++) a += w2[(long)c * S + j] * mid[j];
+        scale[(long)n * C + c] = fminf(fmaxf(a + 3.f, 0.f), 6.f) * (1.f / 6.f);       // hardsigmoid
+    }
+}
+
+__global__ __launch_bounds__(256) void se_apply_kernel(float *__restrict__ x, const float *__restrict__ scale, int HW, int C4, long total) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        const long n = i / ((long)HW * C4);
+        f32x4 v = *reinterpret_cast<f32x4 *>(x + i * 4);
+        v *= *reinterpret_cast<const f32x4 *>(scale + (n * C4 + c) * 4);
+        *reinterpret_cast<f32x4 *>(x + i * 4) = v;
+    }
+}
+
+static inline int grid_cap(long total, int block) {
+    long g = (total + block - 1) / block;
+    return (int)(g < 2048 ? (g > 0 ? g : 1) : 2048);
+}
+
+}  // namespace ptocr
+
+using namespace ptocr;
+
+extern "C" int ptocr_dwconv_f32(const float *d_x, const float *d_w, const float *d_bias, float *d_y, int N, int H, int W, int C, int k,
+                                int stride, int act, void *stream) {
+    PT_CHECK(d_x && d_w && d_bias && d_y && C % 4 == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2) && act >= 0 && act <= 2,
+             "ptocr_dwconv_f32: need C %% 4 == 0, k in {3,5}, stride in {1,2}");
+    const int pad = (k - 1) / 2;
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    const long total = (long)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(dwconv_kernel, dim3(grid_cap(total, 256)), dim3(256), 0, (hipStream_t)stream, d_x, d_w, d_bias, d_y, H, W, C / 4, k,
+                       stride, Ho, Wo, act, total);
+    return launch_ok("dwconv_kernel");
+}
+
+extern "C" int ptocr_se_scale_f32(float *d_x, const float *d_w1, const float *d_b1, const float *d_w2, const float *d_b2, float *d_work,
+                                  int N, int H, int W, int C, int S, void *stream) {
+    PT_CHECK(d_x && d_w1 && d_b1 && d_w2 && d_b2 && d_work && C % 4 == 0 && C <= 1024 && S <= 256 && N <= 65535, "ptocr_se_scale_f32: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int HW = H * W, nblk = cdiv(HW, SE_PIX);
+    float *partial = d_work, *scale = d_work + (long)N * nblk * C;
+    hipLaunchKernelGGL(se_pool_kernel, dim3(nblk, N), dim3(256), 0, s, d_x, partial, HW, C, nblk);
+    hipLaunchKernelGGL(se_fc_kernel, dim3(N), dim3(256), 0, s, partial, d_w1, d_b1, d_w2, d_b2, scale, HW, C, S, nblk);
+    const long total = (long)N * HW * (C / 4);
+    hipLaunchKernelGGL(se_apply_kernel, dim3(grid_cap(total, 256)), dim3(256), 0, s, d_x, scale, HW, C / 4, total);
+    return launch_ok("se kernels");
+}

@@ -47,7 +47,7 @@ class BaseModel(nn.Module):
             neck = self.neck.forward_nhwc(feats) if self.use_neck else feats
             out = self.head.forward_nhwc(neck)
             if self.return_all_feats:
-                y["backbone_out"] = [ops.nhwc_to_nchw(f) for f in feats]
+                y["backbone_out"] = [ops.nhwc_to_nchw(f)[:, :c] for f, c in zip(feats, self.backbone.out_channels)]
                 y["neck_out"] = ops.nhwc_to_nchw(neck) if self.use_neck else y["backbone_out"]
         else:
             feats = self.backbone.forward_nhwc(ops.nchw_to_nhwc(x, 4))

@@ -23,8 +23,8 @@ class DBHead(ops.PackedModule):
     def __init__(self, in_channels, k=50, **kwargs):
         super().__init__()
         self.k = k
-        if (in_channels // 4) % 64 != 0:
-            raise NotImplementedError("pytorchocr_amd DBHead: in_channels//4 must be a multiple of 64 (got %d)" % in_channels)
+        if in_channels % 32 != 0 or (in_channels // 4) % 4 != 0:
+            raise NotImplementedError("pytorchocr_amd DBHead: in_channels must be a multiple of 32 (got %d)" % in_channels)
         self.binarize = _branch(in_channels)
         self.thresh = _branch(in_channels)
         for m in self.modules():
@@ -37,7 +37,10 @@ class DBHead(ops.PackedModule):
     def _pack(self, dev):
         b = self.binarize
         w6 = b[6].weight.detach().double().cpu()                       # [C4, 1, 2, 2]
-        w4 = w6[:, 0].permute(1, 2, 0).reshape(4, -1).float().contiguous().to(dev)
+        c4 = w6.shape[0]
+        w4 = torch.zeros(4, ops._rup(c4, 32), dtype=torch.float64)     # channel-padded like the tensor it multiplies
+        w4[:, :c4] = w6[:, 0].permute(1, 2, 0).reshape(4, c4)
+        w4 = w4.float().contiguous().to(dev)
         return {"c0": ops.PackedConv(b[0], b[1], dev, relu=True),
                 "t3": ops.PackedConvT2x2(b[3], b[4], dev, relu=True),
                 "w6": w4, "b6": float(b[6].bias.detach().cpu()[0])}

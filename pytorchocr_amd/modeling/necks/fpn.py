@@ -21,9 +21,8 @@ class FPN(ops.PackedModule):
         super().__init__()
         if mode != "DB":
             raise NotImplementedError("pytorchocr_amd FPN: only mode='DB' is on the hot path")
-        if (out_channels // 4) % 64 != 0:
-            raise NotImplementedError("pytorchocr_amd FPN: out_channels//4 must be a multiple of 64 on the MFMA path "
-                                      "(got out_channels=%d)" % out_channels)
+        if out_channels % 32 != 0 or (out_channels // 4) % 4 != 0:
+            raise NotImplementedError("pytorchocr_amd FPN: out_channels must be a multiple of 32 (got %d)" % out_channels)
         self.mode, self.use_asf = mode, use_asf
         self.in5 = _cbr(in_channels[-1], out_channels, 1, 0)
         self.in4 = _cbr(in_channels[-2], out_channels, 1, 0)
@@ -65,10 +64,10 @@ class FPN(ops.PackedModule):
         N, H4, W4, _ = c2.shape
         sm = self.out_channels // 4
         fuse = torch.empty((N, H4, W4, self.out_channels), dtype=torch.float32, device=c2.device)
-        ops.conv2d(in5, p["out5"], out=fuse, out_up=8, out_coff=0)
-        ops.conv2d(out4, p["out4"], out=fuse, out_up=4, out_coff=sm)
-        ops.conv2d(out3, p["out3"], out=fuse, out_up=2, out_coff=2 * sm)
-        ops.conv2d(out2, p["out2"], out=fuse, out_up=1, out_coff=3 * sm)
+        ops.conv2d(in5, p["out5"], out=fuse, out_up=8, out_coff=0, store=sm)
+        ops.conv2d(out4, p["out4"], out=fuse, out_up=4, out_coff=sm, store=sm)
+        ops.conv2d(out3, p["out3"], out=fuse, out_up=2, out_coff=2 * sm, store=sm)
+        ops.conv2d(out2, p["out2"], out=fuse, out_up=1, out_coff=3 * sm, store=sm)
         if self.use_asf:
             self.concat_attention.run(p["asf"], fuse)          # re-weights the four 64-channel slices in place
         return fuse

@@ -33,57 +33,95 @@ def fold_bn(w, conv_bias, bn, cout_dim=0):
     return w, b
 
 
+def _rup(v, m):
+    return (v + m - 1) // m * m
+
+
+ACT_NONE, ACT_RELU, ACT_HSWISH = 0, 1, 2
+
+
+def _act_code(relu):
+    return int(relu) if not isinstance(relu, bool) else (ACT_RELU if relu else ACT_NONE)
+
+
 class PackedConv:
-    """Weights of one convolution in the kernel's layout: f32[Cout][Kpad], K = (kh*KW+kw)*Cin_pad + ci."""
+    """Weights of one convolution in the kernel's layout: f32[Cout_k][Kpad], K = (kh*KW+kw)*Cin_pad + ci.
+
+    Channel counts that are not multiples of 32 (MobileNetV3: 16, 24, 40, 72, ...) are handled by zero padding: the
+    input tensor carries `cin` = roundup(Cin, 32) channels (4 for 1/3-channel images), the output tensor carries
+    `c_tensor` = roundup(Cout, 32) channels, the weight matrix has roundup(c_tensor, 64) rows.  Padded rows/columns and
+    their bias are zero, and every activation used here maps 0 to 0, so padding channels stay exactly zero."""
 
     def __init__(self, conv, bn, device, relu, cin_pad=None):
         w, b = fold_bn(conv.weight, conv.bias, bn)
         cout, cin, kh, kw = w.shape
-        cin_pad = cin_pad or cin
-        wk = torch.zeros(cout, kh, kw, cin_pad, dtype=torch.float64)
-        wk[..., :cin] = w.permute(0, 2, 3, 1)
+        cin_pad = cin_pad or (4 if cin in (1, 3) else _rup(cin, 32))
+        c_tensor = _rup(cout, 32)
+        cout_k = _rup(c_tensor, 64)
+        wk = torch.zeros(cout_k, kh, kw, cin_pad, dtype=torch.float64)
+        wk[:cout, :, :, :cin] = w.permute(0, 2, 3, 1)
         k = kh * kw * cin_pad
         kpad = (k + 31) // 32 * 32
-        wp = torch.zeros(cout, kpad, dtype=torch.float64)
-        wp[:, :k] = wk.reshape(cout, k)
+        wp = torch.zeros(cout_k, kpad, dtype=torch.float64)
+        wp[:, :k] = wk.reshape(cout_k, k)
+        bp = torch.zeros(cout_k, dtype=torch.float64)
+        bp[:cout] = b
         self.w = wp.float().contiguous().to(device)
-        self.b = b.float().contiguous().to(device)
-        self.cin, self.cout, self.kh, self.kw = cin_pad, cout, kh, kw
+        self.b = bp.float().contiguous().to(device)
+        self.cin, self.cout, self.kh, self.kw = cin_pad, cout_k, kh, kw
+        self.cout_real, self.c_tensor = cout, c_tensor
         self.stride = conv.stride[0]
         self.pad_h, self.pad_w = conv.padding
-        self.relu = relu
+        self.relu = _act_code(relu)
         self.convt = False
 
 
 class PackedConvT2x2:
-    """ConvTranspose2d(k=2, s=2) as a 1x1 GEMM with 4*Co columns: column (a*2+b)*Co + co."""
+    """ConvTranspose2d(k=2, s=2) as a 1x1 GEMM with 4*Cp columns: column (a*2+b)*Cp + co, Cp = roundup(Co, 32)."""
 
     def __init__(self, convt, bn, device, relu):
         w, b = fold_bn(convt.weight, convt.bias, bn, cout_dim=1)       # [Cin, Co, 2, 2]
         cin, co = w.shape[0], w.shape[1]
-        wp = w.permute(2, 3, 1, 0).reshape(4 * co, cin)               # [(a,b,co), ci]
+        cin_pad, cp = _rup(cin, 32), _rup(co, 32)
+        cout_k = _rup(4 * cp, 64)
+        wp = torch.zeros(cout_k, cin_pad, dtype=torch.float64)
+        bp = torch.zeros(cout_k, dtype=torch.float64)
+        for a in range(2):
+            for bb in range(2):
+                g = (a * 2 + bb) * cp
+                wp[g:g + co, :cin] = w[:, :, a, bb].t()
+                bp[g:g + co] = b
         self.w = wp.float().contiguous().to(device)
-        self.b = b.repeat(4).float().contiguous().to(device)
-        self.cin, self.cout, self.kh, self.kw = cin, 4 * co, 1, 1
+        self.b = bp.float().contiguous().to(device)
+        self.cin, self.cout, self.kh, self.kw = cin_pad, cout_k, 1, 1
         self.stride, self.pad_h, self.pad_w = 1, 0, 0
-        self.relu = relu
+        self.relu = _act_code(relu)
         self.convt = True
-        self.co = co
+        self.co = cp
+        self.cout_real, self.c_tensor = co, cp
 
 
-def conv2d(x, pc, res=None, res_mode=RES_NONE, out=None, out_up=1, out_coff=0):
-    """x f32[N,H,W,Cin] -> f32[N,Ho*,Wo*,C] (new tensor unless `out` is given for in-place concat)."""
+def conv2d(x, pc, res=None, res_mode=RES_NONE, out=None, out_up=1, out_coff=0, store=None):
+    """x f32[N,H,W,Cin] -> f32[N,Ho*,Wo*,C] (new tensor unless `out` is given for in-place concat; `store` = number of
+    columns written, default the padded tensor width, pass the real channel count for exact concat slices)."""
     _require_cuda(x, "conv2d")
     N, H, W, Cin = x.shape
     assert Cin == pc.cin, (Cin, pc.cin)
     Ho = (H + 2 * pc.pad_h - pc.kh) // pc.stride + 1
     Wo = (W + 2 * pc.pad_w - pc.kw) // pc.stride + 1
-    co_real = pc.co if pc.convt else pc.cout
     scale = 2 if pc.convt else out_up
     if out is None:
-        out = torch.empty((N, Ho * scale, Wo * scale, co_real), dtype=torch.float32, device=x.device)
-    d = ConvDesc(N, H, W, Cin, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad_h, pc.pad_w, Ho, Wo,
-                 int(pc.relu), res_mode, out_up, out.shape[3], out_coff, int(pc.convt))
+        out = torch.empty((N, Ho * scale, Wo * scale, pc.c_tensor), dtype=torch.float32, device=x.device)
+    if pc.convt:
+        cout_k, cstore = 4 * pc.co, 0
+        assert 4 * pc.co == pc.cout, "transposed-conv column groups must fill the GEMM width"
+    else:
+        cout_k = pc.cout
+        cstore = store if store is not None else pc.c_tensor
+        cstore = 0 if cstore == cout_k else cstore
+    d = ConvDesc(N, H, W, Cin, cout_k, pc.kh, pc.kw, pc.stride, pc.pad_h, pc.pad_w, Ho, Wo,
+                 int(pc.relu), res_mode, out_up, out.shape[3], out_coff, int(pc.convt), cstore,
+                 res.shape[3] if res is not None else 0)
     L = _lib.lib()
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -95,6 +133,58 @@ def conv2d(x, pc, res=None, res_mode=RES_NONE, out=None, out_up=1, out_coff=0):
         e1.record()
         PROFILE.append((e0, e1))
     return out
+
+
+class PackedDW:
+    """Depthwise conv + BN (+act): weights f32[k*k][Cp] tap-major, channels zero-padded to a multiple of 32."""
+
+    def __init__(self, conv, bn, device, act):
+        w, b = fold_bn(conv.weight, conv.bias, bn)                      # [C, 1, k, k]
+        c, _, k, _ = w.shape
+        cp = _rup(c, 32)
+        wp = torch.zeros(k * k, cp, dtype=torch.float64)
+        wp[:, :c] = w[:, 0].reshape(c, k * k).t()
+        bp = torch.zeros(cp, dtype=torch.float64)
+        bp[:c] = b
+        self.w, self.b = wp.float().contiguous().to(device), bp.float().contiguous().to(device)
+        self.k, self.stride, self.act, self.c = k, conv.stride[0], _act_code(act), cp
+
+
+def dwconv(x, pd):
+    _require_cuda(x, "dwconv")
+    N, H, W, Cc = x.shape
+    assert Cc == pd.c
+    pad = (pd.k - 1) // 2
+    Ho, Wo = (H + 2 * pad - pd.k) // pd.stride + 1, (W + 2 * pad - pd.k) // pd.stride + 1
+    y = torch.empty((N, Ho, Wo, Cc), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().ptocr_dwconv_f32(_lib.ptr(x), _lib.ptr(pd.w), _lib.ptr(pd.b), _lib.ptr(y), N, H, W, Cc, pd.k, pd.stride,
+                                           pd.act, _lib.cur_stream()), "ptocr_dwconv_f32")
+    return y
+
+
+class PackedSE:
+    def __init__(self, se, device):
+        w1 = se.fc1.weight.detach().float().cpu()[:, :, 0, 0]            # [S, C]
+        w2 = se.fc2.weight.detach().float().cpu()[:, :, 0, 0]            # [C, S]
+        S, Cc = w1.shape
+        cp = _rup(Cc, 32)
+        w1p = torch.zeros(S, cp); w1p[:, :Cc] = w1
+        w2p = torch.zeros(cp, S); w2p[:Cc] = w2
+        b2p = torch.full((cp,), -3.0); b2p[:Cc] = se.fc2.bias.detach().float().cpu()      # hardsigmoid(-3) = 0 keeps pad channels 0
+        self.w1, self.b1 = w1p.contiguous().to(device), se.fc1.bias.detach().float().cpu().contiguous().to(device)
+        self.w2, self.b2 = w2p.contiguous().to(device), b2p.contiguous().to(device)
+        self.S, self.c = S, cp
+
+
+def se_scale_(x, ps):
+    """in place: x[n,:,:,c] *= hardsigmoid(fc2(relu(fc1(mean(x)))))"""
+    _require_cuda(x, "se_scale_")
+    N, H, W, Cc = x.shape
+    assert Cc == ps.c
+    work = torch.empty(N * ((H * W + 2047) // 2048 + 1) * Cc, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().ptocr_se_scale_f32(_lib.ptr(x), _lib.ptr(ps.w1), _lib.ptr(ps.b1), _lib.ptr(ps.w2), _lib.ptr(ps.b2),
+                                             _lib.ptr(work), N, H, W, Cc, ps.S, _lib.cur_stream()), "ptocr_se_scale_f32")
+    return x
 
 
 def nchw_to_nhwc(x, cpad):

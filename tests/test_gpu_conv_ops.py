@@ -142,3 +142,70 @@ def test_layout_roundtrip():
     assert torch.equal(y[..., :70].permute(0, 3, 1, 2), x)
     z = ops.nhwc_to_nchw(y)
     assert torch.equal(z[:, :70], x)
+
+
+def test_padded_channels_hardswish_and_masked_store():
+    """MobileNetV3-style conv: Cin 72 (tensor 96), Cout 24 (tensor 32), Hardswish, residual with its own channel stride."""
+    from pytorchocr_amd.modeling import ops
+    dev = _dev()
+    conv = nn.Conv2d(72, 24, 1, bias=False)
+    bn = nn.BatchNorm2d(24, eps=1e-3).eval()
+    with torch.no_grad():
+        conv.weight.copy_(_rand(24, 72, 1, 1, seed=1) * 0.3)
+        bn.running_mean.copy_(_rand(24, seed=5) * 0.2); bn.running_var.copy_(_rand(24, seed=6) * 0.5 + 1)
+    x = _rand(2, 72, 11, 13, seed=7) * 3
+    res = _rand(2, 24, 11, 13, seed=8)
+    with torch.no_grad():
+        ref_hs = F.hardswish(bn(conv(x)))
+        ref_res = bn(conv(x)) + res
+    xp = torch.zeros(2, 11, 13, 96); xp[..., :72] = _nhwc(x)
+    rp = torch.zeros(2, 11, 13, 32); rp[..., :24] = _nhwc(res)
+    y = ops.conv2d(xp.to(dev), ops.PackedConv(conv, bn, dev, relu=ops.ACT_HSWISH)).cpu()
+    assert y.shape == (2, 11, 13, 32) and float(y[..., 24:].abs().max()) == 0.0
+    assert (y[..., :24].permute(0, 3, 1, 2) - ref_hs).abs().max().item() <= 2e-5
+    y = ops.conv2d(xp.to(dev), ops.PackedConv(conv, bn, dev, relu=ops.ACT_NONE), res=rp.to(dev), res_mode=ops.RES_ADD_PRE_RELU).cpu()
+    assert (y[..., :24].permute(0, 3, 1, 2) - ref_res).abs().max().item() <= 2e-5
+    # exact concat slice: 24 columns at offset 48 of a 96-channel tensor, neighbours untouched
+    big = torch.full((2, 11, 13, 96), 5.0, device=dev)
+    ops.conv2d(xp.to(dev), ops.PackedConv(conv, bn, dev, relu=ops.ACT_HSWISH), out=big, out_coff=48, store=24)
+    big = big.cpu()
+    assert (big[..., 48:72].permute(0, 3, 1, 2) - ref_hs).abs().max().item() <= 2e-5
+    assert float((big[..., :48] - 5).abs().max()) == 0 and float((big[..., 72:] - 5).abs().max()) == 0
+
+
+@pytest.mark.parametrize("k,s,act", [(3, 1, 1), (3, 2, 2), (5, 1, 2), (5, 2, 1)])
+def test_depthwise_conv(k, s, act):
+    from pytorchocr_amd.modeling import ops
+    dev = _dev()
+    Cc = 88
+    conv = nn.Conv2d(Cc, Cc, k, s, (k - 1) // 2, groups=Cc, bias=False)
+    bn = nn.BatchNorm2d(Cc, eps=1e-3).eval()
+    with torch.no_grad():
+        conv.weight.copy_(_rand(Cc, 1, k, k, seed=1) * 0.4)
+        bn.running_mean.copy_(_rand(Cc, seed=5) * 0.2); bn.running_var.copy_(_rand(Cc, seed=6) * 0.5 + 1)
+    x = _rand(2, Cc, 17, 23, seed=2) * 2
+    with torch.no_grad():
+        ref = bn(conv(x))
+        ref = F.relu(ref) if act == 1 else F.hardswish(ref)
+    xp = torch.zeros(2, 17, 23, 96); xp[..., :Cc] = _nhwc(x)
+    y = ops.dwconv(xp.to(dev), ops.PackedDW(conv, bn, dev, act)).cpu()
+    assert float(y[..., Cc:].abs().max()) == 0.0
+    assert (y[..., :Cc].permute(0, 3, 1, 2) - ref).abs().max().item() <= 2e-5
+
+
+def test_squeeze_excitation():
+    from pytorchocr_amd.modeling import ops
+    from pytorchocr_amd.modeling.backbones.det_mobilenet_v3 import SqueezeExcitation
+    dev = _dev()
+    se = SqueezeExcitation(240)
+    with torch.no_grad():
+        for prm in se.parameters():
+            prm.copy_(_rand(*prm.shape, seed=prm.numel()) * 0.3)
+    x = _rand(3, 240, 50, 70, seed=3)
+    with torch.no_grad():
+        sc = F.hardsigmoid(se.fc2(F.relu(se.fc1(F.adaptive_avg_pool2d(x, 1)))))
+        ref = sc * x
+    xp = torch.zeros(3, 50, 70, 256); xp[..., :240] = _nhwc(x)
+    y = ops.se_scale_(xp.to(dev), ops.PackedSE(se, dev)).cpu()
+    assert float(y[..., 240:].abs().max()) == 0.0
+    assert (y[..., :240].permute(0, 3, 1, 2) - ref).abs().max().item() <= 2e-5

@@ -89,3 +89,30 @@ def test_dbpp_asf_matches_reference(gold_dir, contract):
         y = m(torch.from_numpy(xs).cuda())["maps"].cpu().numpy()
     ref = model_oracle.dbnet_r18_forward(sd, torch.from_numpy(xs))["maps"].numpy()
     assert np.abs(y - ref).max() <= 1e-4
+
+
+def test_mobilenetv3_small_db_matches_reference(gold_dir, contract):
+    """DB with the MobileNetV3-small x1.0 backbone (FPN 96): maps vs the reference's own output and vs the oracle."""
+    from oracle import model_oracle
+    from pytorchocr_amd.modeling.architectures import build_model
+    cfg = dict(model_type="det", algorithm="DB", Transform=None,
+               Backbone=dict(name="MobileNetV3", model_name="small", scale=1.0, pretrained=False),
+               Neck=dict(name="FPN", out_channels=96, mode="DB", use_asf=False), Head=dict(name="DBHead", k=50), return_all_feats=True)
+    m = build_model(cfg)
+    sd = synth_state_dict(contract["det_mbv3s_db"])
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.to("cuda:0").eval()
+    g = np.load(os.path.join(gold_dir, "det_mbv3s_db_1x3x64x96.npz"))
+    x = torch.from_numpy(synth_images(1, 3, 64, 96, seed=int(g["seed"]))).cuda()
+    with torch.no_grad():
+        y = m(x)
+    assert [f.shape[1] for f in y["backbone_out"]] == [16, 24, 48, 576]
+    assert np.abs(y["maps"].cpu().numpy() - g["maps"]).max() <= 1e-4
+    xs = synth_images(2, 3, 224, 320, seed=31)
+    ref = model_oracle.dbnet_forward(sd, torch.from_numpy(xs), return_feats=True)
+    with torch.no_grad():
+        y = m(torch.from_numpy(xs).cuda())
+    for a, b in zip(y["backbone_out"], ref["backbone_out"]):
+        assert (a.cpu() - b).abs().max().item() <= 1e-4 * max(1.0, b.abs().max().item())
+    assert np.abs(y["maps"].cpu().numpy() - ref["maps"].numpy()).max() <= 1e-4

@@ -23,7 +23,12 @@ REC = dict(model_type="rec", algorithm="CRNN", in_channels=1, Transform=None,
            Head=dict(name="CTCHead", out_channels=6624))
 
 
-@pytest.mark.parametrize("cfg,name", [(DET, "det_r18_db"), (REC, "rec_vgg_bilstm_ctc")])
+MBV3 = dict(model_type="det", algorithm="DB", Transform=None,
+            Backbone=dict(name="MobileNetV3", model_name="small", scale=1.0, pretrained=False),
+            Neck=dict(name="FPN", out_channels=96, mode="DB", use_asf=False), Head=dict(name="DBHead", k=50))
+
+
+@pytest.mark.parametrize("cfg,name", [(DET, "det_r18_db"), (REC, "rec_vgg_bilstm_ctc"), (MBV3, "det_mbv3s_db")])
 def test_state_dict_contract_and_strict_load(contract, cfg, name):
     m = build_model(cfg)                      # stock yml: pretrained=True with a placeholder path must NOT fetch a URL
     ref = contract[name]
@@ -41,8 +46,8 @@ def test_bn_fold_and_pack_reproduce_conv_bn():
     bn = nn.BatchNorm2d(64).eval()
     with torch.no_grad():
         bn.running_mean.uniform_(-0.3, 0.3); bn.running_var.uniform_(0.5, 2); bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.2, 0.2)
-    pc = ops.PackedConv(conv, bn, torch.device("cpu"), relu=False, cin_pad=32)
-    assert pc.w.shape == (64, 288) and pc.cin == 32
+    pc = ops.PackedConv(conv, bn, torch.device("cpu"), relu=False)
+    assert pc.w.shape == (64, 288) and pc.cin == 32 and pc.c_tensor == 64 and pc.cout_real == 64
     wk = pc.w.reshape(64, 3, 3, 32)[..., :8].permute(0, 3, 1, 2)
     x = torch.randn(2, 8, 9, 11)
     with torch.no_grad():
@@ -50,6 +55,20 @@ def test_bn_fold_and_pack_reproduce_conv_bn():
         got = F.conv2d(x, wk, pc.b, 2, 1)
     assert (ref - got).abs().max() < 1e-5
     assert float(pc.w.reshape(64, 3, 3, 32)[..., 8:].abs().max()) == 0.0
+
+
+def test_channel_padding_rules():
+    dev = torch.device("cpu")
+    pc = ops.PackedConv(nn.Conv2d(3, 16, 3, 2, 1, bias=False), None, dev, relu=ops.ACT_HSWISH)        # mbv3 stem
+    assert (pc.cin, pc.cout, pc.c_tensor, pc.cout_real, pc.relu) == (4, 64, 32, 16, 2) and pc.w.shape == (64, 64)
+    assert float(pc.w[16:].abs().max()) == 0 and float(pc.b[16:].abs().max()) == 0
+    pc = ops.PackedConv(nn.Conv2d(72, 24, 1, bias=False), nn.BatchNorm2d(24, eps=1e-3).eval(), dev, relu=False)
+    assert (pc.cin, pc.cout, pc.c_tensor) == (96, 64, 32) and pc.w.shape == (64, 96)
+    pt = ops.PackedConvT2x2(nn.ConvTranspose2d(24, 24, 2, 2), None, dev, relu=True)
+    assert (pt.cin, pt.cout, pt.co) == (32, 128, 32)
+    assert float(pt.w[24:32].abs().max()) == 0 and float(pt.w[:, 24:].abs().max()) == 0
+    pd = ops.PackedDW(nn.Conv2d(88, 88, 5, 2, 2, groups=88, bias=False), nn.BatchNorm2d(88).eval(), dev, ops.ACT_RELU)
+    assert pd.w.shape == (25, 96) and pd.c == 96 and pd.k == 5 and pd.stride == 2
 
 
 def test_convtranspose_pack_layout():
@@ -77,7 +96,7 @@ def test_unsupported_options_raise():
     with pytest.raises(NotImplementedError):
         build_model(dict(DET, Backbone=dict(name="ResNet", layers=50)))
     with pytest.raises(AssertionError):
-        build_model(dict(DET, Backbone=dict(name="MobileNetV3", model_name="small")))
+        build_model(dict(DET, Backbone=dict(name="ShuffleNetV2")))
     m = build_model(DET)
     with pytest.raises(RuntimeError):
         m.eval()(torch.zeros(1, 3, 32, 32))                    # CPU tensor: no fallback

@@ -46,3 +46,10 @@ def test_dbpp_oracle_matches_reference(gold_dir, contract):
     sd = synth_state_dict(contract["detpp_r18_db"])
     x = torch.from_numpy(synth_images(1, 3, 64, 96, seed=int(g["seed"])))
     assert np.abs(model_oracle.dbnet_r18_forward(sd, x)["maps"].numpy() - g["maps"]).max() <= 1e-6
+
+
+def test_mbv3_small_oracle_matches_reference(gold_dir, contract):
+    g = np.load(os.path.join(gold_dir, "det_mbv3s_db_1x3x64x96.npz"))
+    sd = synth_state_dict(contract["det_mbv3s_db"])
+    x = torch.from_numpy(synth_images(1, 3, 64, 96, seed=int(g["seed"])))
+    assert np.abs(model_oracle.dbnet_forward(sd, x)["maps"].numpy() - g["maps"]).max() <= 1e-6
