@@ -18,6 +18,9 @@
  *       heads/det_db_head.py:9-17,47-50, backbones/rec_vgg.py:78-120 (BN folded into weights/bias at load).
  *   ptocr_asf_scale_channel_spatial_f32
  *       ScaleChannelSpatialAttention.forward + the re-weighted concat of pytocr/modeling/necks/asf.py:63-75,155-162 (DB++).
+ *   ptocr_preprocess_u8_f32, ptocr_warp_crops_u8
+ *       cv2.resize / to_tensor / normalize of pytocr/data/imaug/operators.py:41-112,155-252 and rec_img_aug.py:108-134
+ *       (the reference's own CUDA analogue: deploy/trt_utils.py:43-52); get_part_img of pytocr/utils/utility.py:53-78.
  *   ptocr_db_postprocess
  *       pybind11 `db_postprocess.db_postprocess(pred, bitmap, box_thresh, det_db_unclip_ratio, src_w, src_h,
  *       use_padding_resize)` = DBProcess, pytocr/postprocess/db_postprocess_fast/src/db_postprocess.cpp:319-370,
@@ -115,6 +118,20 @@ int ptocr_db_postprocess(ptocr_dbpost_t h, const float *d_maps, const uint8_t *d
  * float distance;}  h_cands: 1000 x {int trigger_pixel; int is_hole;}  h_info: 1000 x {int npts; int off;
  * short xmin, xmax, ymin, ymax;}  status: 0 box, 1 <=2 points, 2 ssid<3, 3 score<box_thresh, 4 unclip<1.001, 5 ssid<5. */
 int ptocr_dbpost_debug_results(ptocr_dbpost_t h, int img, int32_t *h_total, void *h_results, void *h_cands, void *h_info);
+
+/* ---- pre-process next to the path --------------------------------------------------------------
+ * Item descriptors live in device memory (arrays of the structs below, natural C layout). */
+typedef struct { long src_off; int sh, sw; int rh, rw; long dst_off; int dh, dw; } ptocr_pre_item;
+/* Batched u8 HxWx3 (BGR) -> cv2.resize(INTER_LINEAR) to rh x rw -> fp32 f32[dh][dw][cpad], zero beyond (rh, rw).
+ * mode 0: 3 channels (RGB order if swap_rb) as (x/255 - mean)/std  (DetResizeForTest+ToTensor+Normalize, operators.py:41-112,155-252)
+ * mode 1: BGR2GRAY then (x/255 - 0.5)/0.5 in channel 0                (resize_norm_img, rec_img_aug.py:108-134) */
+int ptocr_preprocess_u8_f32(const uint8_t *d_src, float *d_dst, const void *d_items, int n_items, int max_dst_pixels,
+                            int mode, int swap_rb, int cpad, const float *h_mean3, const float *h_std3, void *stream);
+typedef struct { double minv[9]; int left, top; int cw, ch; int rot90; long dst_off; } ptocr_warp_item;
+/* Batched get_part_img (utils/utility.py:53-78): perspective warp (INTER_LINEAR, BORDER_REPLICATE) of n text boxes of one
+ * u8 HxWx3 image into packed u8 crops; rot90 = np.rot90(crop, 1) when h >= 1.5 w (run_ocr.py:189-191). */
+int ptocr_warp_crops_u8(const uint8_t *d_img, int H, int W, uint8_t *d_dst, const void *d_items, int n_items,
+                        int max_crop_pixels, void *stream);
 
 /* ---- recognition ----------------------------------------------------------------------------------------
  * Sequences are batch-major: row = b*T + t (no Im2Seq permute, no decode transpose). */

@@ -21,9 +21,9 @@ def resize_bilinear(img, dsize):
 
     def coeffs(dn, sn):
         scale = sn / float(dn)
-        f = (np.arange(dn, dtype=np.float64) + 0.5) * scale - 0.5
+        f = ((np.arange(dn, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)    # cv2: fx = (float)((dx+0.5)*scale_x - 0.5)
         s0 = np.floor(f).astype(np.int64)
-        fr = (f - s0).astype(np.float32)
+        fr = (f - s0.astype(np.float32)).astype(np.float32)
         lo = s0 < 0
         fr[lo] = 0
         s0[lo] = 0
@@ -37,9 +37,9 @@ def resize_bilinear(img, dsize):
     y0, y1, fy = coeffs(dh, sh)
     if src.dtype == np.uint8:
         ONE = 2048
-        ax1 = np.rint(fx * ONE).astype(np.int64)           # saturate_cast<short>(fx * INTER_RESIZE_COEF_SCALE)
+        ax1 = np.rint(fx * np.float32(ONE)).astype(np.int64)           # saturate_cast<short>(fx * INTER_RESIZE_COEF_SCALE)
         ax0 = ONE - ax1
-        by1 = np.rint(fy * ONE).astype(np.int64)
+        by1 = np.rint(fy * np.float32(ONE)).astype(np.int64)
         by0 = ONE - by1
         s = src.astype(np.int64)
         shp = (1, dw) + (1,) * (s.ndim - 2)

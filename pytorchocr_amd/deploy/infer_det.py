@@ -22,7 +22,8 @@ from .common import inference_transforms, read_image_bgr
 
 
 class Deter(object):
-    def __init__(self, det_cfg, det_ckpt=None, gpu_id=0) -> None:
+    def __init__(self, det_cfg, det_ckpt=None, gpu_id=0, gpu_preprocess=False) -> None:
+        self.gpu_preprocess = gpu_preprocess
         det_cfg = load_config(det_cfg) if isinstance(det_cfg, (str, os.PathLike)) else det_cfg
         det_cfg["Global"]["distributed"] = False
         deter = build_model(det_cfg["Architecture"])
@@ -42,8 +43,31 @@ class Deter(object):
         det_img = img[:, :, ::-1] if self.det_img_mode == "RGB" else img.copy()
         return transform({"image": np.ascontiguousarray(det_img)}, self.det_ops)
 
+    def _gpu_ops(self):
+        from ..data.imaug import DetResizeForTest, Normalize
+        rs = [o for o in self.det_ops if isinstance(o, DetResizeForTest)]
+        nm = [o for o in self.det_ops if isinstance(o, Normalize)]
+        if len(rs) != 1 or len(nm) != 1:
+            raise NotImplementedError("gpu_preprocess needs exactly DetResizeForTest + ToTensor + Normalize in the transform list")
+        return rs[0], nm[0]
+
+    @torch.no_grad()
+    def run_gpu(self, img_path):
+        """same result as run(), with resize / normalise / layout on the GPU (only the u8 image crosses PCIe)"""
+        from ..data.gpu_preprocess import det_preprocess
+        img = read_image_bgr(img_path)
+        rs, nm = self._gpu_ops()
+        src_h, src_w = img.shape[:2]
+        rh, rw = rs.target_size(src_h, src_w)
+        x4 = det_preprocess(img, (rh, rw), nm.mean, nm.std, self.det_device, swap_rb=self.det_img_mode == "RGB")
+        shape = np.array([[src_h, src_w, rh / float(src_h), rw / float(src_w)]])
+        res = self.det_post_process_class(self.deter.forward_nhwc4(x4), shape)
+        return sort_boxes(res[0]["points"])
+
     @torch.no_grad()
     def run(self, img_path):
+        if self.gpu_preprocess:
+            return self.run_gpu(img_path)
         img = read_image_bgr(img_path)
         det_batch = self._prep(img)
         det_img = det_batch[0].unsqueeze(dim=0).to(self.det_device)

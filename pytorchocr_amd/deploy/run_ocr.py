@@ -16,14 +16,37 @@ from .infer_rec import Recer
 
 
 class OCRer(object):
-    def __init__(self, det_cfg, det_ckpt, rec_cfg, rec_ckpt, cls_cfg=None, cls_ckpt=None, character_dict_path=None, gpu_id=0) -> None:
+    def __init__(self, det_cfg, det_ckpt, rec_cfg, rec_ckpt, cls_cfg=None, cls_ckpt=None, character_dict_path=None, gpu_id=0,
+                 gpu_preprocess=False) -> None:
+        self.gpu_preprocess = gpu_preprocess
         if cls_cfg is not None and cls_ckpt is not None:
             raise NotImplementedError("pytorchocr_amd run_ocr: the optional direction classifier is outside the built hot path")
-        self.det = Deter(det_cfg, det_ckpt, gpu_id)
+        self.det = Deter(det_cfg, det_ckpt, gpu_id, gpu_preprocess=gpu_preprocess)
         self.rec = Recer(rec_cfg, rec_ckpt, character_dict_path, gpu_id)
 
     @torch.no_grad()
+    def run_gpu(self, img_path):
+        """detect, crop (batched perspective warp), resize/normalise the crops and recognise, all on the GPU"""
+        from ..data.gpu_preprocess import rec_preprocess, warp_crops
+        from ..data.imaug import RecResizeImg
+        img = read_image_bgr(img_path)
+        boxes = self.det.run(img)
+        if len(boxes) == 0:
+            return []
+        if self.rec.rec_img_mode != "GRAY":
+            raise NotImplementedError("the GPU recognition pre-process implements the GRAY CRNN input")
+        shape = [o for o in self.rec.rec_ops if isinstance(o, RecResizeImg)][0].image_shape
+        img_dev = torch.from_numpy(np.ascontiguousarray(img)).to(self.rec.rec_device)
+        buf, metas = warp_crops(img_dev, boxes)
+        x4 = rec_preprocess(buf, metas, shape, self.rec.rec_device)
+        keep = [b for b, m in zip(boxes, metas) if m is not None]
+        res = self.rec.rec_post_process_class(self.rec.recer.forward_greedy_nhwc4(x4)) if len(keep) else []
+        return [[box, t, round(p, 2)] for box, (t, p) in zip(keep, res)]
+
+    @torch.no_grad()
     def run(self, img_path):
+        if self.gpu_preprocess:
+            return self.run_gpu(img_path)
         img = read_image_bgr(img_path)
         boxes = self.det.run(img)
         crops = []

@@ -38,6 +38,11 @@ class BaseModel(nn.Module):
         self.head = build_head(config["Head"])
         self.return_all_feats = config.get("return_all_feats", False)
 
+    def forward_nhwc4(self, x4):
+        """det models: f32[N,H,W,4] (the GPU pre-process output: RGB + zero channel, NHWC) -> {"maps": f32[N,1,H,W]}"""
+        feats = self.backbone.forward_nhwc(x4)
+        return self.head.forward_nhwc(self.neck.forward_nhwc(feats) if self.use_neck else feats)
+
     def forward(self, x, data=None):
         if not x.is_cuda:
             raise RuntimeError("pytorchocr_amd BaseModel.forward: input is on %s; the HIP path has no CPU fallback" % x.device)
@@ -66,8 +71,11 @@ class BaseModel(nn.Module):
             raise NotImplementedError("forward_greedy is the recognition fast path")
         if not x.is_cuda:
             raise RuntimeError("pytorchocr_amd BaseModel.forward_greedy: input is on %s; no CPU fallback" % x.device)
-        feats = self.backbone.forward_nhwc(ops.nchw_to_nhwc(x, 4))
-        return self.head.greedy(self.neck.forward_seq(feats))
+        return self.forward_greedy_nhwc4(ops.nchw_to_nhwc(x, 4))
+
+    def forward_greedy_nhwc4(self, x4):
+        """same from the GPU pre-process output f32[B,32,W,4] (gray in channel 0)"""
+        return self.head.greedy(self.neck.forward_seq(self.backbone.forward_nhwc(x4)))
 
     def _finish(self, y, out):
         if isinstance(out, dict):

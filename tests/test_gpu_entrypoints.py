@@ -74,3 +74,56 @@ def test_recer_and_ocrer_batched_equals_per_crop(tmp_path, contract, monkeypatch
     assert tall.shape[0] >= 1.5 * tall.shape[1]                       # second box is rotated 90 degrees before recognition
     exp1 = rec.run(np.ascontiguousarray(np.rot90(tall, 1)))
     assert res[1][1] == exp1[0]
+
+
+def test_gpu_preprocess_is_bit_exact_with_the_host_operators(tmp_path, contract):
+    """ptocr_preprocess_u8_f32 == DetResizeForTest + ToTensor + Normalize (numpy/torch on the host), bit for bit."""
+    from pytorchocr_amd.data.gpu_preprocess import det_preprocess
+    from pytorchocr_amd.deploy.infer_det import Deter
+    ck, _ = _ckpt(tmp_path, contract, "det_r18_db")
+    det = Deter(os.path.join(CFG, "det", "det_r18_db.yml"), ck, gpu_id=0)
+    for (h, w), seed in (((200, 320), 5), ((97, 131), 6), ((736, 1280), 7), ((64, 64), 8)):
+        img = (uniform01(h * w * 3, seed).reshape(h, w, 3) * 255).astype(np.uint8)
+        x, shape = det._prep(img)
+        rs, nm = det._gpu_ops()
+        rh, rw = rs.target_size(h, w)
+        x4 = det_preprocess(img, (rh, rw), nm.mean, nm.std, det.det_device, swap_rb=True).cpu()
+        assert tuple(x4.shape) == (1, rh, rw, 4) and float(x4[..., 3].abs().max()) == 0
+        assert torch.equal(x4[0, :, :, :3].permute(2, 0, 1), x), (h, w)
+    img = (uniform01(200 * 320 * 3, 5).reshape(200, 320, 3) * 255).astype(np.uint8)
+    a, b = det.run(img), det.run_gpu(img)
+    assert len(a) == len(b) and all(np.array_equal(p, q) for p, q in zip(a, b))
+
+
+def test_gpu_crops_and_rec_preprocess_match_host(tmp_path, contract, monkeypatch):
+    from pytorchocr_amd.data.gpu_preprocess import rec_preprocess, warp_crops
+    from pytorchocr_amd.deploy.infer_rec import Recer
+    from pytorchocr_amd.deploy.run_ocr import OCRer
+    from pytorchocr_amd.utils.warp import get_part_img
+    ck, _ = _ckpt(tmp_path, contract, "rec_vgg_bilstm_ctc")
+    dck, _ = _ckpt(tmp_path, contract, "det_r18_db")
+    img = (uniform01(240 * 400 * 3, 9).reshape(240, 400, 3) * 255).astype(np.uint8)
+    yy, xx = np.mgrid[0:240, 0:400]
+    img = np.clip(img * 0.3 + ((xx // 8 * 37) % 200)[..., None], 0, 255).astype(np.uint8)
+    boxes = [np.array([[20, 30], [220, 34], [219, 70], [19, 66]], np.int16), np.array([[300, 20], [330, 20], [330, 200], [300, 200]], np.int16),
+             np.array([[50, 100], [150, 120], [140, 160], [40, 140]], np.int16)]
+    dev = torch.device("cuda:0")
+    buf, metas = warp_crops(torch.from_numpy(img).to(dev), boxes)
+    host = []
+    for b, (off, h, w) in zip(boxes, metas):
+        c = get_part_img(img, b)
+        if c.shape[0] >= 1.5 * c.shape[1]:
+            c = np.rot90(c, 1)
+        host.append(np.ascontiguousarray(c))
+        got = buf[off:off + h * w * 3].cpu().numpy().reshape(h, w, 3)
+        assert got.shape == c.shape and np.array_equal(got, c)
+    rec = Recer(os.path.join(CFG, "rec", "rec_vgg_bilstm_ctc.yml"), ck)
+    x4 = rec_preprocess(buf, metas, [1, 32, 320], dev).cpu()
+    for i, c in enumerate(host):
+        assert torch.equal(x4[i, :, :, 0], rec._prep(c)[0])
+    ocr_h = OCRer(os.path.join(CFG, "det", "det_r18_db.yml"), dck, os.path.join(CFG, "rec", "rec_vgg_bilstm_ctc.yml"), ck)
+    ocr_g = OCRer(os.path.join(CFG, "det", "det_r18_db.yml"), dck, os.path.join(CFG, "rec", "rec_vgg_bilstm_ctc.yml"), ck, gpu_preprocess=True)
+    for o in (ocr_h, ocr_g):
+        monkeypatch.setattr(o.det, "run", lambda im: boxes)
+    rh, rg = ocr_h.run(img), ocr_g.run(img)
+    assert [r[1] for r in rh] == [r[1] for r in rg] and len(rg) == 3
