@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
 DET_GFLOP_PER_IMG = 114.195        # SURVEY.md 8d / BASELINE.md: DBNet-r18 @ 3x736x1280 (2*MAC over conv/deconv)
-DET_TAIL_GFLOP_PER_IMG = 0.12      # last ConvTranspose (64->1) runs in the memory-bound head-tail kernel, not on MFMA
+DET_TAIL_GFLOP_PER_IMG = 2.05      # ConvT 64->64 (1.93) + ConvT 64->1 (0.12) run in db_head_tail_kernel, not in conv_mfma
 CRNN_GFLOP_PER_LINE = 4.980
 
 DET_R18 = dict(model_type="det", algorithm="DB", Transform=None,

@@ -75,6 +75,10 @@ int ptocr_maxpool2d_f32(const float *d_x, float *d_y, int N, int H, int W, int C
 int ptocr_convt2x2_sigmoid_f32(const float *d_x, const float *d_w, float bias, float *d_maps, int N, int H, int W,
                                int C, void *stream);
 
+/* Fused DB head tail (det_db_head.py:13-17): ConvT(64,64,2,2)+BN+ReLU -> ConvT(64,1,2,2)+bias -> sigmoid.
+ * d_x f32[N,H,W,64]; d_w1 f32[256][64] (row (a*2+b)*64+co, BN folded), d_b1 f32[256]; d_w2 f32[4][64], b2 -> d_maps f32[N,4H,4W]. */
+int ptocr_db_head_tail_f32(const float *d_x, const float *d_w1, const float *d_b1, const float *d_w2, float b2, float *d_maps,
+                           int N, int H, int W, int C, void *stream);
 /* Depthwise conv (groups == C) + folded BN bias + activation (0 none / 1 ReLU / 2 Hardswish), NHWC, C % 4 == 0.
  * d_w f32[k*k][C] (tap-major), pad = (k-1)/2.  (MobileNetV3 InvertedResidual.conv2, det_mobilenet_v3.py:123-126) */
 int ptocr_dwconv_f32(const float *d_x, const float *d_w, const float *d_bias, float *d_y, int N, int H, int W, int C, int k,

@@ -1,0 +1,122 @@
+// Fused DB head tail: ConvTranspose2d(64,64,2,2)+BN+ReLU -> ConvTranspose2d(64,1,2,2)+bias -> sigmoid in ONE kernel.
+// Replaces det_db_head.py:13-17 (binarize[3..7]).  The 64-channel half-resolution tensor (1.9 GB at 32x736x1280) is never
+// written: each input pixel (1/4 resolution) yields its 4x4 patch of probabilities directly.
+//
+// GEMM 1 runs on v_mfma_f32_32x32x2_f32 with the roles swapped (A = weights, B = pixels) so the result tile D[co][pixel]
+// keeps the pixel on the lane and the 32 mid channels of a tile in registers: the second contraction (over co, only 4 outputs)
+// is then register-local FMAs plus one lane^32 exchange -- no LDS round trip for the intermediate.
+// Bound: fp32 MFMA for GEMM 1 (1.93 GFLOP/image), HBM for the input read (60 MB/image) and the map write (3.8 MB/image).
+#include "common.h"
+
+namespace ptocr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int HT_C = 64;                 // channels in and mid
+constexpr int HT_LD = HT_C + 4;          // LDS row stride (floats)
+constexpr int HT_PIX = 128;              // pixels per tile (4 waves x 32)
+constexpr int HT_TILES = 8;              // tiles per block (weights staged once per block)
+
+// w1: f32[256][64] (row (a*2+b)*64 + co, BN folded), b1: f32[256]; w2: f32[4][64] (a'*2+b'), b2 scalar
+__global__ __launch_bounds__(256) void db_head_tail_kernel(const float *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1,
+                                                           const float *__restrict__ w2, float b2, float *__restrict__ maps, int H, int W, long npix) {
+    __shared__ __attribute__((aligned(16))) float xs[HT_PIX * HT_LD];        // [pixel][ci]
+    __shared__ __attribute__((aligned(16))) float ws[256 * HT_LD];           // [col][ci]
+    __shared__ float w2s[4 * HT_C], b1s[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the 256 x 64 weights are staged once per block; the block then walks HT_TILES consecutive 128-pixel tiles
+    for (int i = tid; i < 256 * 16; i += 256) {
+        const int r = i >> 4, c4 = i & 15;
+        *reinterpret_cast<f32x4 *>(&ws[r * HT_LD + c4 * 4]) = *reinterpret_cast<const f32x4 *>(w1 + (long)r * HT_C + c4 * 4);
+    }
+    w2s[tid] = w2[tid];
+    b1s[tid] = b1[tid];
+    const int j = lane & 31, h = lane >> 5;                  // pixel within the wave's 32, k half
+  for (int tile = 0; tile < HT_TILES; tile++) {
+    const long p0 = ((long)blockIdx.x * HT_TILES + tile) * HT_PIX;
+    if (p0 >= npix) break;
+    __syncthreads();                                         // previous tile's reads of xs are done
+    for (int i = tid; i < HT_PIX * 16; i += 256) {
+        const int r = i >> 4, c4 = i & 15;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (p0 + r < npix) v = *reinterpret_cast<const f32x4 *>(x + (p0 + r) * HT_C + c4 * 4);
+        *reinterpret_cast<f32x4 *>(&xs[r * HT_LD + c4 * 4]) = v;
+    }
+    __syncthreads();
+
+    const float *bx = xs + (wave * 32 + j) * HT_LD + 4 * h;  // B operand: pixel j, k = 8kk + 4h + t
+    float outv[4][4];                                        // [ab][a'b'] partial sums of this lane
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int o = 0; o < 4; o++) outv[g][o] = 0.f;
+
+#pragma unroll
+    for (int g = 0; g < 4; g++) {                            // (a, b) group: 64 mid channels = two 32-row tiles
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        const float *aw0 = ws + (g * 64 + j) * HT_LD + 4 * h;        // A operand: row (co) j of tile 0
+        const float *aw1 = aw0 + 32 * HT_LD;
+#pragma unroll
+        for (int kk = 0; kk < HT_C / 8; kk++) {
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(bx + kk * 8);
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(aw0 + kk * 8);
+            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(aw1 + kk * 8);
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b[t], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b[t], acc1, 0, 0, 0);
+            }
+        }
+        // D[row = co][col = pixel j]: register r holds co = (r&3) + 8*(r>>2) + 4*h (+32 for tile 1)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int co0 = (r & 3) + 8 * (r >> 2) + 4 * h, co1 = co0 + 32;
+            const float m0 = fmaxf(acc0[r] + b1s[g * 64 + co0], 0.f);
+            const float m1 = fmaxf(acc1[r] + b1s[g * 64 + co1], 0.f);
+#pragma unroll
+            for (int o = 0; o < 4; o++) outv[g][o] += m0 * w2s[o * HT_C + co0] + m1 * w2s[o * HT_C + co1];
+        }
+    }
+    // the other half of the mid channels lives in lane ^ 32
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int o = 0; o < 4; o++) outv[g][o] += __shfl_xor(outv[g][o], 32);
+    const long pix = p0 + wave * 32 + j;
+    if (h == 0 && pix < npix) {
+        const long n = pix / ((long)H * W);
+        const int rem = (int)(pix - n * (long)H * W);
+        const int y = rem / W, xx = rem - y * W;
+        float *o = maps + (n * 4 * H + 4 * y) * (long)(4 * W) + 4 * xx;
+        // output pixel (4y + 2a + a', 4x + 2b + b')
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int ap = 0; ap < 2; ap++) {
+                f32x4 row;
+                row[0] = 1.f / (1.f + expf(-(outv[a * 2 + 0][ap * 2 + 0] + b2)));
+                row[1] = 1.f / (1.f + expf(-(outv[a * 2 + 0][ap * 2 + 1] + b2)));
+                row[2] = 1.f / (1.f + expf(-(outv[a * 2 + 1][ap * 2 + 0] + b2)));
+                row[3] = 1.f / (1.f + expf(-(outv[a * 2 + 1][ap * 2 + 1] + b2)));
+                *reinterpret_cast<f32x4 *>(o + (long)(2 * a + ap) * (4 * W)) = row;
+            }
+    }
+  }
+}
+
+}  // namespace ptocr
+
+using namespace ptocr;
+
+extern "C" int ptocr_db_head_tail_f32(const float *d_x, const float *d_w1, const float *d_b1, const float *d_w2, float b2, float *d_maps,
+                                      int N, int H, int W, int C, void *stream) {
+    PT_CHECK(d_x && d_w1 && d_b1 && d_w2 && d_maps && N >= 1, "ptocr_db_head_tail_f32: bad arguments");
+    PT_CHECK(C == HT_C, "ptocr_db_head_tail_f32: the fused tail is specialised for 64 channels (got %d)", C);
+    const long npix = (long)N * H * W;
+    hipLaunchKernelGGL(db_head_tail_kernel, dim3((unsigned)((npix + (long)HT_PIX * HT_TILES - 1) / ((long)HT_PIX * HT_TILES))), dim3(256), 0, (hipStream_t)stream, d_x, d_w1, d_b1,
+                       d_w2, b2, d_maps, H, W, npix);
+    return launch_ok("db_head_tail_kernel");
+}

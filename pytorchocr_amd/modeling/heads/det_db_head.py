@@ -23,6 +23,7 @@ class DBHead(ops.PackedModule):
     def __init__(self, in_channels, k=50, **kwargs):
         super().__init__()
         self.k = k
+        self.fused_tail = True          # False: run the two transposed convs as separate kernels (A/B and fallback shapes)
         if in_channels % 32 != 0 or (in_channels // 4) % 4 != 0:
             raise NotImplementedError("pytorchocr_amd DBHead: in_channels must be a multiple of 32 (got %d)" % in_channels)
         self.binarize = _branch(in_channels)
@@ -49,6 +50,9 @@ class DBHead(ops.PackedModule):
         self._check_eval()
         p = self.packed()
         x = ops.conv2d(fuse, p["c0"])
+        if p["t3"].co == 64 and p["t3"].cin == 64 and self.fused_tail:
+            # ConvT+BN+ReLU -> ConvT -> sigmoid in one kernel: the half-resolution 64-channel tensor never exists
+            return {"maps": ops.db_head_tail(x, p["t3"].w, p["t3"].b, p["w6"], p["b6"])}
         x = ops.conv2d(x, p["t3"])
         return {"maps": ops.convt2x2_sigmoid(x, p["w6"], p["b6"])}
 

@@ -269,6 +269,16 @@ def softmax_rows(x, C):
     return y
 
 
+def db_head_tail(x, w1, b1, w2, b2):
+    """x f32[N,H,W,64] -> maps f32[N,1,4H,4W]: both transposed convs of the DB head + sigmoid in one kernel"""
+    _require_cuda(x, "db_head_tail")
+    N, H, W, Cc = x.shape
+    y = torch.empty((N, 1, 4 * H, 4 * W), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().ptocr_db_head_tail_f32(_lib.ptr(x), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), C.c_float(b2), _lib.ptr(y),
+                                                 N, H, W, Cc, _lib.cur_stream()), "ptocr_db_head_tail_f32")
+    return y
+
+
 class PackedModule(torch.nn.Module):
     """Mixin: packed (BN-folded, kernel-layout) weights are rebuilt whenever a parameter/buffer changed
     (load_state_dict, .to(device), in-place edits) -- detected through tensor versions and device."""
