@@ -117,6 +117,14 @@ int ptocr_db_postprocess(ptocr_dbpost_t h, const float *d_maps, const uint8_t *d
                          int use_padding_resize, int16_t *h_boxes, int max_boxes, int32_t *h_counts,
                          int32_t *h_flags, void *stream);
 
+/* Same with the two remaining options of the reference: use_dilation = cv2.dilate(mask, 2x2 ones) before the extraction
+ * (db_postprocess.py:52-55), use_padding_resize = map boxes back through get_affine_transform / transform_preds
+ * (db_postprocess.cpp:111-145,289-301; needs H == W). */
+int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, const uint8_t *d_bitmap, int N, int H, int W,
+                            float thresh, float box_thresh, float unclip_ratio, const int *h_src_wh,
+                            int use_padding_resize, int use_dilation, int16_t *h_boxes, int max_boxes, int32_t *h_counts,
+                            int32_t *h_flags, void *stream);
+
 /* Inspection hook for the parity tests: per-candidate records of the LAST ptocr_db_postprocess call for image `img`
  * (synchronises the device).  h_results: 1000 x {int status; int box[8]; float score; float rect[5]; int npix;
  * float distance;}  h_cands: 1000 x {int trigger_pixel; int is_hole;}  h_info: 1000 x {int npts; int off;

@@ -78,7 +78,14 @@ def binarize(pred, thresh):
     return out
 
 
-def boxes_from_bitmap(pred, bitmap, box_thresh, unclip_ratio, src_w, src_h, with_debug=False):
+def dilate2x2(bitmap):
+    bitmap = np.ascontiguousarray(bitmap, np.uint8)
+    out = np.empty_like(bitmap)
+    lib().dbpost_oracle_dilate2x2(_p(bitmap, C.c_uint8), bitmap.shape[0], bitmap.shape[1], _p(out, C.c_uint8))
+    return out
+
+
+def boxes_from_bitmap(pred, bitmap, box_thresh, unclip_ratio, src_w, src_h, with_debug=False, use_padding_resize=False):
     """Same contract as the reference pybind `db_postprocess` (use_padding_resize=False):
     pred f32[H,W], bitmap u8[H,W] -> int[K,4,2] (+ per-contour debug records)."""
     pred = np.ascontiguousarray(pred, np.float32)
@@ -87,9 +94,11 @@ def boxes_from_bitmap(pred, bitmap, box_thresh, unclip_ratio, src_w, src_h, with
     boxes = np.zeros((1000, 8), np.int32)
     dbg = (Dbg * 1000)()
     ncont = C.c_int(0)
+    lib().dbpost_oracle_set_padding_resize(int(bool(use_padding_resize)))
     k = lib().dbpost_oracle_run(_p(pred, C.c_float), _p(bitmap, C.c_uint8), H, W, C.c_float(box_thresh),
                                 C.c_float(unclip_ratio), int(src_w), int(src_h), _p(boxes, C.c_int), 1000,
                                 dbg, 1000, C.byref(ncont))
+    lib().dbpost_oracle_set_padding_resize(0)
     out = boxes[:k].reshape(k, 4, 2).copy()
     if with_debug:
         return out, [dbg[i] for i in range(min(ncont.value, 1000))], ncont.value

@@ -661,7 +661,37 @@ static rrect unclip_rect(float box[4][2], float unclip_ratio, float *distance_ou
 
 static float clampf(float x, float lo, float hi) { if (x > hi) return hi; if (x < lo) return lo; return x; }
 
-/* db_postprocess.cpp:231-317 (use_padding_resize == false branch) */
+/* db_postprocess.cpp:111-145 get_affine_transform(center, img_maxsize, target_size, inv=1).t() + transform_preds.
+ * The three point pairs describe a uniform scale about the centres (the third pair is consistent with it), so
+ * cv::getAffineTransform's 6x6 LU solve is restated in closed form, in double on the float32 triangle coordinates. */
+static void padding_resize_point(float x, float y, int src_w, int src_h, int target, float *ox, float *oy) {
+    const float cx = (float)(src_w / 2.0), cy = (float)(src_h / 2.0);
+    const int img_maxsize = src_w > src_h ? src_w : src_h;
+    const float s0y = cy, s1y = cy + (float)((float)img_maxsize / 2.0);          /* srcTriangle[0].y, [1].y */
+    const float d0 = (float)((float)target / 2.0), d1y = d0 + (float)((float)target / 2.0);
+    const double scale = ((double)s1y - (double)s0y) / ((double)d1y - (double)d0);
+    *ox = (float)(scale * ((double)x - (double)d0) + (double)cx);
+    *oy = (float)(scale * ((double)y - (double)d0) + (double)cy);
+}
+
+static int g_use_padding_resize = 0;
+void dbpost_oracle_set_padding_resize(int on) { g_use_padding_resize = on; }
+
+/* cv2.dilate(mask, [[1,1],[1,1]]) of db_postprocess.py:52-55: anchor (1,1) => OR of the pixel with its left, upper and
+ * upper-left neighbours (BORDER_CONSTANT with the neutral value). */
+void dbpost_oracle_dilate2x2(const uint8_t *in, int H, int W, uint8_t *out) {
+    int x, y;
+    for (y = 0; y < H; y++)
+        for (x = 0; x < W; x++) {
+            int v = in[(size_t)y * W + x];
+            if (x > 0) v |= in[(size_t)y * W + x - 1];
+            if (y > 0) v |= in[(size_t)(y - 1) * W + x];
+            if (x > 0 && y > 0) v |= in[(size_t)(y - 1) * W + x - 1];
+            out[(size_t)y * W + x] = v ? 1 : 0;
+        }
+}
+
+/* db_postprocess.cpp:231-317 */
 int dbpost_oracle_run(const float *pred, const uint8_t *bitmap, int H, int W, float box_thresh,
                       float unclip_ratio, int src_w, int src_h, int *boxes_out, int max_boxes,
                       dbpost_oracle_dbg *dbg, int dbg_cap, int *n_contours_out) {
@@ -692,8 +722,15 @@ int dbpost_oracle_run(const float *pred, const uint8_t *bitmap, int H, int W, fl
             get_mini_boxes(ub, clip, &ssid);
             if (ssid < min_size + 2) { d.status = DBPO_SKIP_SSID2; break; }
             for (j = 0; j < 4; j++) {
-                d.box[2 * j]     = (int)clampf(roundf(clip[j][0] / (float)W * (float)src_w), 0, (float)src_w);
-                d.box[2 * j + 1] = (int)clampf(roundf(clip[j][1] / (float)H * (float)src_h), 0, (float)src_h);
+                if (g_use_padding_resize) {
+                    float tx, ty;
+                    padding_resize_point(clip[j][0], clip[j][1], src_w, src_h, H, &tx, &ty);
+                    d.box[2 * j]     = (int)clampf(roundf(tx), 0, (float)src_w);
+                    d.box[2 * j + 1] = (int)clampf(roundf(ty), 0, (float)src_h);
+                } else {
+                    d.box[2 * j]     = (int)clampf(roundf(clip[j][0] / (float)W * (float)src_w), 0, (float)src_w);
+                    d.box[2 * j + 1] = (int)clampf(roundf(clip[j][1] / (float)H * (float)src_h), 0, (float)src_h);
+                }
             }
             if (nboxes < max_boxes) memcpy(boxes_out + 8 * nboxes, d.box, 8 * sizeof(int));
             nboxes++;

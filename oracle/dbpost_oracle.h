@@ -27,6 +27,8 @@ int dbpost_oracle_contours(const uint8_t *bitmap, int H, int W, int *npts, int *
 void dbpost_oracle_min_area_rect(const float *pts_xy, int n, float *rect5, float *minibox8, float *ssid);
 int dbpost_oracle_clipper_offset(const long long *path_xy, int npts, double delta, long long *out_xy, int out_cap);
 void dbpost_oracle_set_clipper_ref(void *fn);
+void dbpost_oracle_set_padding_resize(int on);
+void dbpost_oracle_dilate2x2(const uint8_t *in, int H, int W, uint8_t *out);
 void dbpost_oracle_binarize(const float *pred, size_t n, float thresh, uint8_t *bitmap);
 
 #ifdef __cplusplus

@@ -74,6 +74,22 @@ __global__ __launch_bounds__(256) void pack_u8_kernel(const uint8_t *__restrict_
     if ((threadIdx.x & 7) == 0 && wi < d.WW) bits[((long)img * d.H + y) * d.WW + wi] = v;
 }
 
+// cv2.dilate(mask, [[1,1],[1,1]]) (db_postprocess.py:52-55): anchor (1,1) => pixel |= left | up | up-left, on packed words
+__global__ __launch_bounds__(256) void dilate2x2_kernel(const unsigned *__restrict__ in, unsigned *__restrict__ out, DbpostDims d) {
+    const int img = blockIdx.z, y = blockIdx.y;
+    const int wi = blockIdx.x * 256 + threadIdx.x;
+    if (wi >= d.WW) return;
+    const unsigned *row = in + ((long)img * d.H + y) * d.WW;
+    unsigned v = row[wi], c = wi ? row[wi - 1] >> 31 : 0u;
+    v |= (v << 1) | c;
+    if (y > 0) {
+        const unsigned u = row[wi - d.WW], cu = wi ? row[wi - d.WW - 1] >> 31 : 0u;
+        v |= u | (u << 1) | cu;
+    }
+    if (wi == d.WW - 1 && (d.W & 31)) v &= (1u << (d.W & 31)) - 1;      // keep the tail bits beyond W clear
+    out[((long)img * d.H + y) * d.WW + wi] = v;
+}
+
 // ------------------------------------------------------------------------------------------ CC labelling
 __device__ __forceinline__ int pix(const unsigned *rowbits, int x) { return (rowbits[x >> 5] >> (x & 31)) & 1; }
 
@@ -795,7 +811,8 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const float *__rest
                                                              const unsigned *__restrict__ pool, unsigned *__restrict__ gslots,
                                                              int *__restrict__ slot_locks, Result *__restrict__ results,
                                                              int *__restrict__ flags, const int *__restrict__ src_wh,
-                                                             float box_thresh, float unclip_ratio, long slot_words, DbpostDims d) {
+                                                             float box_thresh, float unclip_ratio, long slot_words, int use_padding_resize,
+                                                             DbpostDims d) {
     const int img = blockIdx.y, k = blockIdx.x, tid = threadIdx.x;
     const int num = min(totals[img], MAX_CAND);
     if (k >= num) return;
@@ -967,8 +984,22 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const float *__rest
     if (ssid < 5) { res->status = ST_SKIP_SSID2; return; }                        // min_size + 2
     const int src_w = src_wh[2 * img], src_h = src_wh[2 * img + 1];
     for (int j = 0; j < 4; j++) {
-        res->box[2 * j]     = (int)clampf(roundf(clip[j][0] / (float)d.W * (float)src_w), 0, (float)src_w);
-        res->box[2 * j + 1] = (int)clampf(roundf(clip[j][1] / (float)d.H * (float)src_h), 0, (float)src_h);
+        if (use_padding_resize) {
+            // get_affine_transform(center, max(src_w, src_h), H, inv=1) + transform_preds (db_postprocess.cpp:111-145, 289-301):
+            // a uniform scale about the centres, evaluated in double on the float32 triangle coordinates
+            const float cx = (float)(src_w / 2.0), cy = (float)(src_h / 2.0);
+            const int img_maxsize = src_w > src_h ? src_w : src_h;
+            const float s1y = cy + (float)((float)img_maxsize / 2.0);
+            const float d0 = (float)((float)d.H / 2.0), d1y = d0 + (float)((float)d.H / 2.0);
+            const double scale = ((double)s1y - (double)cy) / ((double)d1y - (double)d0);
+            const float tx = (float)(scale * ((double)clip[j][0] - (double)d0) + (double)cx);
+            const float ty = (float)(scale * ((double)clip[j][1] - (double)d0) + (double)cy);
+            res->box[2 * j]     = (int)clampf(roundf(tx), 0, (float)src_w);
+            res->box[2 * j + 1] = (int)clampf(roundf(ty), 0, (float)src_h);
+        } else {
+            res->box[2 * j]     = (int)clampf(roundf(clip[j][0] / (float)d.W * (float)src_w), 0, (float)src_w);
+            res->box[2 * j + 1] = (int)clampf(roundf(clip[j][1] / (float)d.H * (float)src_h), 0, (float)src_h);
+        }
     }
     res->status = ST_OK;
 }
@@ -1002,7 +1033,7 @@ using namespace ptocr;
 
 struct ptocr_dbpost {
     int max_n, max_h, max_w;
-    unsigned *bits; int *labels; int *chunk_cnt; int *totals; Cand *cands; CandInfo *info; unsigned *pool;
+    unsigned *bits; unsigned *bits2; int *labels; int *chunk_cnt; int *totals; Cand *cands; CandInfo *info; unsigned *pool;
     unsigned *gslots; int *slot_locks; long slot_words; Result *results; int *flags; int *src_wh; short *boxes; int *counts;
     int boxes_cap;
     long pool_cap;
@@ -1019,6 +1050,7 @@ extern "C" int ptocr_dbpost_create(ptocr_dbpost_t *out, int max_n, int max_h, in
     h->boxes_cap = MAX_CAND;
     const long nch = (hw + CHUNK - 1) / CHUNK;
     PT_HIP(hipMalloc(&h->bits, sizeof(unsigned) * max_n * max_h * ww));
+    PT_HIP(hipMalloc(&h->bits2, sizeof(unsigned) * max_n * max_h * ww));
     PT_HIP(hipMalloc(&h->labels, sizeof(int) * max_n * hw));
     PT_HIP(hipMalloc(&h->chunk_cnt, sizeof(int) * max_n * nch));
     PT_HIP(hipMalloc(&h->totals, sizeof(int) * max_n));
@@ -1040,7 +1072,7 @@ extern "C" int ptocr_dbpost_create(ptocr_dbpost_t *out, int max_n, int max_h, in
 
 extern "C" int ptocr_dbpost_destroy(ptocr_dbpost_t h) {
     if (!h) return 0;
-    void *bufs[] = {h->bits, h->labels, h->chunk_cnt, h->totals, h->cands, h->info, h->pool, h->gslots, h->slot_locks,
+    void *bufs[] = {h->bits, h->bits2, h->labels, h->chunk_cnt, h->totals, h->cands, h->info, h->pool, h->gslots, h->slot_locks,
                     h->results, h->flags, h->src_wh, h->boxes, h->counts};
     for (void *b : bufs) (void)hipFree(b);
     delete h;
@@ -1063,11 +1095,18 @@ extern "C" int ptocr_db_postprocess(ptocr_dbpost_t h, const float *d_maps, const
                                     float thresh, float box_thresh, float unclip_ratio, const int *h_src_wh,
                                     int use_padding_resize, int16_t *h_boxes, int max_boxes, int32_t *h_counts,
                                     int32_t *h_flags, void *stream) {
+    return ptocr_db_postprocess_ex(h, d_maps, d_bitmap, N, H, W, thresh, box_thresh, unclip_ratio, h_src_wh, use_padding_resize, 0,
+                                   h_boxes, max_boxes, h_counts, h_flags, stream);
+}
+
+extern "C" int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, const uint8_t *d_bitmap, int N, int H, int W,
+                                       float thresh, float box_thresh, float unclip_ratio, const int *h_src_wh,
+                                       int use_padding_resize, int use_dilation, int16_t *h_boxes, int max_boxes,
+                                       int32_t *h_counts, int32_t *h_flags, void *stream) {
     PT_CHECK(h && d_maps && h_src_wh && h_boxes && h_counts && h_flags, "ptocr_db_postprocess: null argument");
     PT_CHECK(N >= 1 && N <= h->max_n && H >= 1 && W >= 1 && H <= h->max_h && W <= h->max_w && (long)H * W <= (long)h->max_h * h->max_w,
              "ptocr_db_postprocess: batch %dx%dx%d exceeds the workspace (%dx%dx%d)", N, H, W, h->max_n, h->max_h, h->max_w);
-    PT_CHECK(!use_padding_resize, "ptocr_db_postprocess: use_padding_resize=True (cv::getAffineTransform path, never taken by the "
-                                  "reference deploy scripts) is not implemented");
+    PT_CHECK(!use_padding_resize || H == W, "ptocr_db_postprocess: use_padding_resize expects the square padded map the reference uses");
     PT_CHECK(max_boxes >= 1 && max_boxes <= MAX_CAND, "ptocr_db_postprocess: max_boxes must be in [1, %d]", MAX_CAND);
     hipStream_t s = (hipStream_t)stream;
     DbpostDims d;
@@ -1079,17 +1118,22 @@ extern "C" int ptocr_db_postprocess(ptocr_dbpost_t h, const float *d_maps, const
     const dim3 row_grid(cdiv(W, 1024), H, N), px_grid(cdiv(W, 256), H, N);
     if (d_bitmap) hipLaunchKernelGGL(pack_u8_kernel, row_grid, dim3(256), 0, s, d_bitmap, h->bits, d);
     else hipLaunchKernelGGL(binarize_kernel, row_grid, dim3(256), 0, s, d_maps, h->bits, d, thresh);
-    hipLaunchKernelGGL(ccl_init_kernel, px_grid, dim3(256), 0, s, h->bits, h->labels, d);
-    hipLaunchKernelGGL(ccl_merge_kernel, px_grid, dim3(256), 0, s, h->bits, h->labels, d);
-    hipLaunchKernelGGL(ccl_flatten_kernel, dim3(d.nchunks, N), dim3(256), 0, s, h->bits, h->labels, h->chunk_cnt, d);
+    unsigned *bits = h->bits;
+    if (use_dilation) {
+        hipLaunchKernelGGL(dilate2x2_kernel, dim3(cdiv(d.WW, 256), H, N), dim3(256), 0, s, h->bits, h->bits2, d);
+        bits = h->bits2;
+    }
+    hipLaunchKernelGGL(ccl_init_kernel, px_grid, dim3(256), 0, s, bits, h->labels, d);
+    hipLaunchKernelGGL(ccl_merge_kernel, px_grid, dim3(256), 0, s, bits, h->labels, d);
+    hipLaunchKernelGGL(ccl_flatten_kernel, dim3(d.nchunks, N), dim3(256), 0, s, bits, h->labels, h->chunk_cnt, d);
     hipLaunchKernelGGL(chunk_suffix_kernel, dim3(N), dim3(1024), 0, s, h->chunk_cnt, h->totals, d);
-    hipLaunchKernelGGL(gather_starts_kernel, dim3(d.nchunks, N), dim3(256), 0, s, h->bits, h->labels, h->chunk_cnt, h->cands, d);
-    hipLaunchKernelGGL(trace_count_kernel, dim3(cdiv(MAX_CAND, 64), N), dim3(64), 0, s, h->bits, h->cands, h->totals, h->info, d);
+    hipLaunchKernelGGL(gather_starts_kernel, dim3(d.nchunks, N), dim3(256), 0, s, bits, h->labels, h->chunk_cnt, h->cands, d);
+    hipLaunchKernelGGL(trace_count_kernel, dim3(cdiv(MAX_CAND, 64), N), dim3(64), 0, s, bits, h->cands, h->totals, h->info, d);
     hipLaunchKernelGGL(pool_offsets_kernel, dim3(N), dim3(1024), 0, s, h->info, h->totals, h->flags, d);
-    hipLaunchKernelGGL(trace_write_kernel, dim3(cdiv(MAX_CAND, 64), N), dim3(64), 0, s, h->bits, h->cands, h->totals, h->info,
+    hipLaunchKernelGGL(trace_write_kernel, dim3(cdiv(MAX_CAND, 64), N), dim3(64), 0, s, bits, h->cands, h->totals, h->info,
                        h->pool, h->flags, d);
     hipLaunchKernelGGL(contour_kernel, dim3(MAX_CAND, N), dim3(CT_THREADS), 0, s, d_maps, h->cands, h->totals, h->info, h->pool,
-                       h->gslots, h->slot_locks, h->results, h->flags, h->src_wh, box_thresh, unclip_ratio, h->slot_words, d);
+                       h->gslots, h->slot_locks, h->results, h->flags, h->src_wh, box_thresh, unclip_ratio, h->slot_words, use_padding_resize, d);
     hipLaunchKernelGGL(compact_kernel, dim3(N), dim3(1024), 0, s, h->results, h->totals, h->boxes, h->counts, max_boxes);
     if (int e = launch_ok("dbpost kernels")) return e;
     PT_HIP(hipMemcpyAsync(h_counts, h->counts, sizeof(int) * N, hipMemcpyDeviceToHost, s));

@@ -49,7 +49,7 @@ class _Workspace:
 _ws = _Workspace()
 
 
-def device_boxes(maps, src_wh, thresh, box_thresh, unclip_ratio, bitmap=None, use_padding_resize=False, ws=None):
+def device_boxes(maps, src_wh, thresh, box_thresh, unclip_ratio, bitmap=None, use_padding_resize=False, ws=None, use_dilation=False):
     """maps: f32 cuda tensor [N,H,W]; src_wh: int array [N,2] (src_w, src_h); bitmap: optional u8 cuda tensor [N,H,W].
     -> (list of int16[K,4,2] per image, flags int32[N])"""
     if not maps.is_cuda:
@@ -67,9 +67,9 @@ def device_boxes(maps, src_wh, thresh, box_thresh, unclip_ratio, bitmap=None, us
             raise RuntimeError("device_boxes: bitmap must be on the same cuda device")
         bitmap = bitmap.contiguous().to(torch.uint8)
         bptr = _lib.ptr(bitmap)
-    _lib.check(_lib.lib().ptocr_db_postprocess(
+    _lib.check(_lib.lib().ptocr_db_postprocess_ex(
         hd, _lib.ptr(maps), bptr, n, h, w, C.c_float(thresh), C.c_float(box_thresh), C.c_float(unclip_ratio),
-        src.ctypes.data_as(C.c_void_p), int(bool(use_padding_resize)), boxes.ctypes.data_as(C.c_void_p), MAX_CANDIDATES,
+        src.ctypes.data_as(C.c_void_p), int(bool(use_padding_resize)), int(bool(use_dilation)), boxes.ctypes.data_as(C.c_void_p), MAX_CANDIDATES,
         counts.ctypes.data_as(C.c_void_p), flags.ctypes.data_as(C.c_void_p), _lib.cur_stream()), "ptocr_db_postprocess")
     return [boxes[i, :counts[i]].copy() for i in range(n)], flags
 
@@ -100,8 +100,6 @@ class DBPostProcess(object):
                 "np.round, 8-connected fill) and is not built")
         if out_polygon:
             raise NotImplementedError("out_polygon=True needs cpp_speedup=False in the reference; not on the hot path")
-        if use_dilation:
-            raise NotImplementedError("use_dilation=True (cv2.dilate 2x2 before the C++ call) is not built yet")
 
     def submit(self, outs_dict, shape_list, use_padding_resize=False):
         """Asynchronous __call__: returns a future whose .result() is the reference's return value.  The post-process
@@ -143,7 +141,7 @@ class DBPostProcess(object):
         shape_list = np.asarray(shape_list)
         src_wh = np.stack([shape_list[:, 1].astype(np.int64), shape_list[:, 0].astype(np.int64)], axis=1)   # (src_w, src_h)
         boxes, flags = device_boxes(pred, src_wh, self.thresh, self.box_thresh, self.unclip_ratio,
-                                    use_padding_resize=use_padding_resize, ws=self._ws)
+                                    use_padding_resize=use_padding_resize, ws=self._ws, use_dilation=self.use_dilation)
         self.last_flags = flags
         return [{"points": b, "scores": [1.0] * len(b)} for b in boxes]
 

@@ -153,3 +153,27 @@ def test_dbpostprocess_class_contract():
             exp = dbpost.boxes_from_bitmap(maps[i], bm, 0.5, 1.7, int(shape_list[i][1]), int(shape_list[i][0]))
             assert r["points"].dtype == np.int16 and np.array_equal(r["points"], exp.astype(np.int16))
             assert r["scores"] == [1.0] * len(exp)
+
+
+def test_use_dilation_and_padding_resize_options():
+    """The two remaining DBPostProcess options: cv2.dilate 2x2 before extraction, and the padding-resize back-mapping."""
+    from pytorchocr_amd.postprocess.db_postprocess import device_boxes
+    maps = synth_prob_maps(2, 160, 160, seed=11, noise=0.3)
+    src = [[300, 200], [123, 160]]
+    got, _ = device_boxes(torch.from_numpy(maps).cuda(), src, 0.3, 0.5, 1.7, use_dilation=True)
+    for i in range(2):
+        bm = dbpost.dilate2x2(dbpost.binarize(maps[i], 0.3))
+        exp = dbpost.boxes_from_bitmap(maps[i], bm, 0.5, 1.7, src[i][0], src[i][1])
+        assert np.array_equal(got[i].astype(np.int32), exp)
+    got, _ = device_boxes(torch.from_numpy(maps).cuda(), src, 0.3, 0.5, 1.7, use_padding_resize=True)
+    n = 0
+    for i in range(2):
+        bm = dbpost.binarize(maps[i], 0.3)
+        exp = dbpost.boxes_from_bitmap(maps[i], bm, 0.5, 1.7, src[i][0], src[i][1], use_padding_resize=True)
+        assert np.array_equal(got[i].astype(np.int32), exp)
+        n += len(exp)
+    assert n > 5
+    # dilation on a hand-made bitmap: a single pixel grows to the 2x2 block towards +x/+y
+    z = np.zeros((1, 40, 70), np.float32); z[0, 10, 31] = 0.9; z[0, 0, 0] = 0.9; z[0, 39, 69] = 0.9
+    bm = dbpost.dilate2x2(dbpost.binarize(z[0], 0.3))
+    assert bm[10:12, 31:33].all() and bm.sum() == 4 + 4 + 1

@@ -88,8 +88,7 @@ def test_convtranspose_pack_layout():
 def test_unsupported_options_raise():
     with pytest.raises(NotImplementedError):
         build_post_process(dict(name="DBPostProcess", cpp_speedup=False), {})
-    with pytest.raises(NotImplementedError):
-        build_post_process(dict(name="DBPostProcess", cpp_speedup=True, use_dilation=True), {})
+    assert build_post_process(dict(name="DBPostProcess", cpp_speedup=True, use_dilation=True), {}).use_dilation
     with pytest.raises(NotImplementedError):
         build_model(dict(DET, Neck=dict(DET["Neck"], use_asf=True, attention_type="scale_spatial")))
     assert hasattr(build_model(dict(DET, Neck=dict(DET["Neck"], use_asf=True))).neck, "concat_attention")
