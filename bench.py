@@ -170,6 +170,11 @@ def run_det(args, rank, local, world, device):
     conv_flops = (DET_GFLOP_PER_IMG - DET_TAIL_GFLOP_PER_IMG) * 1e9 * B * args.steps
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     cpu = det_cpu_baseline(args.cpu_images, H, W) if world == 1 and args.cpu_images > 0 else None
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "conv_traffic.json")       # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+    if os.path.exists(tp):
+        with open(tp) as f:
+            traffic = json.load(f).get("hbm_bytes_per_launch")
     line = {
         "metric": "images/sec end-to-end (DBNet-r18 det+post, 736x1280)",
         "value": round(world * B * args.steps / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
@@ -180,7 +185,7 @@ def run_det(args, rank, local, world, device):
                    "global_batch": world * B, "post_input": args.post_input, "post_overlap": bool(args.overlap), "boxes_per_image": round(nbox / (B * args.steps), 1),
                    "parallelism": "image-sharded x%d, RCCL weight broadcast only" % world},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                      "kernel": "conv_mfma_kernel (all %d launches per step, %.3f ms avg launch, HIP events on the launch stream)"
                                % (n_launch // max(args.steps, 1), conv_ms / max(n_launch, 1))},
         "cpu_baseline": cpu,
@@ -261,12 +266,18 @@ def main():
             raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)          # one process per GPU; the modulo only matters for the 2-ranks-on-1-GPU rehearsal
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
+        backend = os.environ.get("PTOCR_DIST_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm; "gloo" only to rehearse the control flow
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
+        else:
+            dist.init_process_group(backend=backend, init_method="env://")
     line = (run_det if args.workload == "det" else run_crnn)(args, rank, local, world, device)
     if world > 1:
         import torch.distributed as dist
