@@ -11,6 +11,9 @@ from .._lib import ConvDesc, RES_NONE, RES_ADD_PRE_RELU, RES_ADD_UP2_POST_RELU  
 
 # bench.py sets this to a list to time every conv launch with HIP events on the launch stream
 PROFILE = None
+# 3x3 / stride 1 layers run as Winograd F(2x2,3x3) unless PTOCR_WINOGRAD=0 (then the direct implicit GEMM runs them)
+import os as _os
+USE_WINOGRAD = _os.environ.get("PTOCR_WINOGRAD", "1") != "0"
 
 
 def _require_cuda(t, what):
@@ -74,6 +77,15 @@ class PackedConv:
         self.pad_h, self.pad_w = conv.padding
         self.relu = _act_code(relu)
         self.convt = False
+        # Winograd F(2x2,3x3) form of the same weights for 3x3 / s1 / p1 layers: U = G g G^T, packed [Cout/64][Cin/4][16][64][4]
+        self.wino_u = None
+        if (kh, kw) == (3, 3) and self.stride == 1 and (self.pad_h, self.pad_w) == (1, 1) and cin % 16 == 0 and cout % 64 == 0 \
+                and cin_pad == cin and self.relu in (ACT_NONE, ACT_RELU):
+            G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64)
+            U = torch.einsum("ar,ocrs,bs->ocab", G, w, G)                          # [Cout, Cin, 4, 4]
+            U = U.reshape(cout // 64, 64, cin // 4, 4, 16).permute(0, 2, 4, 1, 3)  # [ct, chunk, xi, cout, c4]
+            self.wino_u = U.contiguous().float().to(device)
+            self.wino_b = b.float().contiguous().to(device)
 
 
 class PackedConvT2x2:
@@ -112,6 +124,20 @@ def conv2d(x, pc, res=None, res_mode=RES_NONE, out=None, out_up=1, out_coff=0, s
     scale = 2 if pc.convt else out_up
     if out is None:
         out = torch.empty((N, Ho * scale, Wo * scale, pc.c_tensor), dtype=torch.float32, device=x.device)
+    if USE_WINOGRAD and getattr(pc, "wino_u", None) is not None and out_up == 1 and res_mode in (RES_NONE, RES_ADD_PRE_RELU) \
+            and (store is None or store == pc.cout_real) and N * H * W * Cin * 4 < 2 ** 31:
+        if PROFILE is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _lib.check(_lib.lib().ptocr_conv3x3_wino_f32(_lib.ptr(x), _lib.ptr(pc.wino_u), _lib.ptr(pc.wino_b),
+                                                     _lib.ptr(res) if res is not None else C.c_void_p(0), _lib.ptr(out),
+                                                     N, H, W, Cin, pc.cout_real, int(pc.relu), res_mode,
+                                                     res.shape[3] if res is not None else 0, out.shape[3], out_coff,
+                                                     _lib.cur_stream()), "ptocr_conv3x3_wino_f32")
+        if PROFILE is not None:
+            e1.record()
+            PROFILE.append((e0, e1))
+        return out
     if pc.convt:
         cout_k, cstore = 4 * pc.co, 0
         assert 4 * pc.co == pc.cout, "transposed-conv column groups must fill the GEMM width"

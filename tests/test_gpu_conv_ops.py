@@ -209,3 +209,36 @@ def test_squeeze_excitation():
     y = ops.se_scale_(xp.to(dev), ops.PackedSE(se, dev)).cpu()
     assert float(y[..., 240:].abs().max()) == 0.0
     assert (y[..., :240].permute(0, 3, 1, 2) - ref).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("case", [(2, 64, 20, 36, 64), (1, 256, 23, 40, 64), (1, 128, 16, 32, 128), (1, 64, 33, 47, 192)])
+def test_winograd_3x3_matches_torch(case):
+    """Winograd F(2x2,3x3) path (default for 3x3/s1/p1 layers) against torch fp32, incl. odd sizes, residual, concat slice."""
+    from pytorchocr_amd.modeling import ops
+    assert ops.USE_WINOGRAD
+    N, Cin, H, W, Cout = case
+    dev = _dev()
+    conv = nn.Conv2d(Cin, Cout, 3, 1, 1, bias=False)
+    bn = nn.BatchNorm2d(Cout).eval()
+    with torch.no_grad():
+        conv.weight.copy_(_rand(Cout, Cin, 3, 3, seed=1) * (3.0 / (Cin * 9)) ** 0.5)
+        bn.weight.copy_(_rand(Cout, seed=3) * 0.4 + 1); bn.bias.copy_(_rand(Cout, seed=4) * 0.2)
+        bn.running_mean.copy_(_rand(Cout, seed=5) * 0.2); bn.running_var.copy_(_rand(Cout, seed=6) * 0.5 + 1)
+    x = _rand(N, Cin, H, W, seed=7)
+    res = _rand(N, Cout, H, W, seed=8)
+    with torch.no_grad():
+        ref = F.relu(bn(conv(x)))
+        ref_res = F.relu(bn(conv(x)) + res)
+    pc = ops.PackedConv(conv, bn, dev, relu=True)
+    assert pc.wino_u is not None
+    xd = _nhwc(x).to(dev)
+    tol = 3e-5 * max(1.0, ref.abs().max().item())
+    y = ops.conv2d(xd, pc).cpu().permute(0, 3, 1, 2)
+    assert (y - ref).abs().max().item() <= tol
+    y = ops.conv2d(xd, pc, res=_nhwc(res).to(dev), res_mode=ops.RES_ADD_PRE_RELU).cpu().permute(0, 3, 1, 2)
+    assert (y - ref_res).abs().max().item() <= tol
+    big = torch.full((N, H, W, Cout + 128), 3.0, device=dev)
+    ops.conv2d(xd, pc, out=big, out_coff=64, store=Cout)
+    big = big.cpu()
+    assert (big[..., 64:64 + Cout].permute(0, 3, 1, 2) - ref).abs().max().item() <= tol
+    assert float((big[..., :64] - 3).abs().max()) == 0 and float((big[..., 64 + Cout:] - 3).abs().max()) == 0
