@@ -66,10 +66,11 @@ int ptocr_conv2d_f32(const ptocr_conv_desc *d, const float *d_x, const float *d_
 /* 3x3 / stride 1 / pad 1 convolution by Winograd F(2x2,3x3) on fp32 MFMA (2.25x fewer multiplies, fp32 accuracy).
  * d_u: host-transformed weights U = G g G^T (BN folded), packed f32[Cout/64][Cin/4][16][64][4]; Cin % 16 == 0, Cout % 64 == 0.
  * Epilogue: bias, optional pre-ReLU residual (d_res f32[N,H,W,res_ldc]), optional ReLU, store into channels
- * [out_coff, out_coff+Cout) of a tensor with channel stride out_ldc. */
+ * [out_coff, out_coff+Cout) of a tensor with channel stride out_ldc; up > 1 (<= 8, no residual) stores every output pixel
+ * to an up x up block of y f32[N,H*up,W*up,out_ldc] (nearest upsample, fpn.py:125-133). */
 int ptocr_conv3x3_wino_f32(const float *d_x, const float *d_u, const float *d_bias, const float *d_res, float *d_y,
                            int N, int H, int W, int Cin, int Cout, int relu, int res_mode, int res_ldc, int out_ldc,
-                           int out_coff, void *stream);
+                           int out_coff, int up, void *stream);
 
 /* f32[N,C,H,W] -> f32[N,H,W,Cpad] (channels >= C zero-filled; Cpad % 4 == 0) */
 int ptocr_nchw_to_nhwc_f32(const float *d_x, float *d_y, int N, int C, int H, int W, int Cpad, void *stream);

@@ -11,6 +11,7 @@ from .._lib import ConvDesc, RES_NONE, RES_ADD_PRE_RELU, RES_ADD_UP2_POST_RELU  
 
 # bench.py sets this to a list to time every conv launch with HIP events on the launch stream
 PROFILE = None
+PROFILE_LABELS = None                          # optional list: one text label per PROFILE entry (tools/profile_det_layers.py)
 # 3x3 / stride 1 layers run as Winograd F(2x2,3x3) unless PTOCR_WINOGRAD=0 (then the direct implicit GEMM runs them)
 import os as _os
 USE_WINOGRAD = _os.environ.get("PTOCR_WINOGRAD", "1") != "0"
@@ -124,8 +125,8 @@ def conv2d(x, pc, res=None, res_mode=RES_NONE, out=None, out_up=1, out_coff=0, s
     scale = 2 if pc.convt else out_up
     if out is None:
         out = torch.empty((N, Ho * scale, Wo * scale, pc.c_tensor), dtype=torch.float32, device=x.device)
-    if USE_WINOGRAD and getattr(pc, "wino_u", None) is not None and out_up == 1 and res_mode in (RES_NONE, RES_ADD_PRE_RELU) \
-            and (store is None or store == pc.cout_real) and N * H * W * Cin * 4 < 2 ** 31:
+    if USE_WINOGRAD and getattr(pc, "wino_u", None) is not None and (res_mode == RES_NONE or (res_mode == RES_ADD_PRE_RELU and out_up == 1)) \
+            and out_up <= 8 and (store is None or store == pc.cout_real) and N * H * W * Cin * 4 < 2 ** 31:
         if PROFILE is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -133,10 +134,12 @@ def conv2d(x, pc, res=None, res_mode=RES_NONE, out=None, out_up=1, out_coff=0, s
                                                      _lib.ptr(res) if res is not None else C.c_void_p(0), _lib.ptr(out),
                                                      N, H, W, Cin, pc.cout_real, int(pc.relu), res_mode,
                                                      res.shape[3] if res is not None else 0, out.shape[3], out_coff,
-                                                     _lib.cur_stream()), "ptocr_conv3x3_wino_f32")
+                                                     out_up, _lib.cur_stream()), "ptocr_conv3x3_wino_f32")
         if PROFILE is not None:
             e1.record()
             PROFILE.append((e0, e1))
+            if PROFILE_LABELS is not None:
+                PROFILE_LABELS.append("wino3x3 %dx%dx%dx%d->%d%s" % (N, H, W, Cin, pc.cout_real, " up%d" % out_up if out_up > 1 else ""))
         return out
     if pc.convt:
         cout_k, cstore = 4 * pc.co, 0
@@ -158,6 +161,9 @@ def conv2d(x, pc, res=None, res_mode=RES_NONE, out=None, out_up=1, out_coff=0, s
     if PROFILE is not None:
         e1.record()
         PROFILE.append((e0, e1))
+        if PROFILE_LABELS is not None:
+            PROFILE_LABELS.append("conv%dx%d s%d %dx%dx%dx%d->%d%s" % (pc.kh, pc.kw, pc.stride, N, H, W, Cin, cout_k,
+                                                                      " up%d" % out_up if out_up > 1 else ""))
     return out
 
 

@@ -211,7 +211,8 @@ def test_squeeze_excitation():
     assert (y[..., :240].permute(0, 3, 1, 2) - ref).abs().max().item() <= 2e-5
 
 
-@pytest.mark.parametrize("case", [(2, 64, 20, 36, 64), (1, 256, 23, 40, 64), (1, 128, 16, 32, 128), (1, 64, 33, 47, 192)])
+@pytest.mark.parametrize("case", [(2, 64, 20, 36, 64), (1, 256, 23, 40, 64), (1, 128, 16, 32, 128), (1, 64, 33, 47, 192),
+                                  (5, 32, 150, 170, 64)])
 def test_winograd_3x3_matches_torch(case):
     """Winograd F(2x2,3x3) path (default for 3x3/s1/p1 layers) against torch fp32, incl. odd sizes, residual, concat slice."""
     from pytorchocr_amd.modeling import ops
@@ -242,3 +243,11 @@ def test_winograd_3x3_matches_torch(case):
     big = big.cpu()
     assert (big[..., 64:64 + Cout].permute(0, 3, 1, 2) - ref).abs().max().item() <= tol
     assert float((big[..., :64] - 3).abs().max()) == 0 and float((big[..., 64 + Cout:] - 3).abs().max()) == 0
+    # nearest upsample fused into the store (the FPN's p3/p4/p5 branches write straight into the concat buffer)
+    up = 2 if H * W > 2000 else 4
+    big = torch.full((N, H * up, W * up, Cout + 64), 3.0, device=dev)
+    ops.conv2d(xd, pc, out=big, out_up=up, out_coff=64, store=Cout)
+    big = big.cpu()
+    ref_up = F.interpolate(ref, scale_factor=up, mode="nearest")
+    assert (big[..., 64:].permute(0, 3, 1, 2) - ref_up).abs().max().item() <= tol
+    assert float((big[..., :64] - 3).abs().max()) == 0
