@@ -16,6 +16,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 # -ffp-contract=off: the post-process geometry must round op by op like the reference's x86 build.
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("PTOCR_EXTRA_HIPCC_FLAGS", "").split()        # kernel experiments, e.g. -DPTOCR_WINO_EXPERIMENT
 
 
 def sources():

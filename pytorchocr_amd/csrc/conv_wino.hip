@@ -18,6 +18,7 @@
 // replicated up x up: the FPN's nearest upsample into the concat buffer).  The next patch's first loads are issued before
 // the output transform so that their latency and the store drain hide behind it.
 #include "common.h"
+#include <cstdlib>
 
 namespace ptocr {
 
@@ -40,298 +41,303 @@ struct WinoArgs {
     int relu, res_mode, out_ldc, out_coff, res_ldc, up;
     int total;                             // patches x images x (Cout / 64)
     long x_bytes, u_bytes;
+    unsigned long long *dbg;               // timing probe (PTOCR_WINO_TIMING): 4 clock samples per workgroup, or null
 };
 
-template <int TXN>
-__global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs p) {
+template <int TXN, int DBG = 0>
+__global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs p) {
     constexpr int TYN = 64 / TXN;                   // tiles per patch column
     constexpr int PW = 2 * TXN + 2, PH = 2 * TYN + 2, NPX = PW * PH;
     constexpr int W_RAW = wino_raw_floats(TXN);
-    static_assert(NPX * 4 <= 6 * 256, "raw patch must fit six 16-byte pieces per thread");
+    static_assert(NPX * 4 <= 3 * 512, "raw patch must fit three 16-byte pieces per thread");
+    static_assert(8 * 64 * W_EL <= 4 * W_V + 2 * W_RAW, "exchange tiles must fit the LDS allocation");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Vb = smem;                       // [2][16][64][WLD]
     float *Ub = smem + 2 * W_V;             // [2][16][64][WLD]
     float *Rb = smem + 4 * W_V;             // [2][NPX + 1][WPX]
 
-    // Thread-derived indices are re-derived from an opaque copy of threadIdx.x at the start of every patch and again before
-    // the output transform: otherwise the compiler hoists the main loop's ~100 address registers out of the persistent loop
-    // and keeps them alive (spilled) through the output transform.
-    int tid, lane, wave, tt, tch, t_roff, t_voff, frow, fh, f_off;
-    auto rebase = [&]() {
-        tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));
-        lane = tid & 63;
-        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        // input transform: lane -> (tile 16 w + 8 (lane >> 5) + (lane & 7), channel (lane >> 3) & 3 of the chunk)
-        tt = wave * 16 + (lane >> 5) * 8 + (lane & 7);
-        tch = (lane >> 3) & 3;
-        t_roff = ((2 * (tt / TXN)) * PW + 2 * (tt % TXN)) * WPX + tch;
-        t_voff = tt * WLD + tch;
-        frow = lane & 31; fh = lane >> 5;
-        f_off = (wave * 4 * 64 + frow) * WLD + 2 * fh;            // MFMA fragments: xi = wave*4 + j, row frow, k = 2h + t
-    };
-    rebase();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // 0..7: two waves per SIMD
     const int patches = p.tiles_x * p.tiles_y;
     const int per_cb = p.N * patches;
     const int nS = p.Cin >> 4;              // super-steps of 16 channels
-    const int nchunks = p.Cin >> 2;
+    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 0] = __builtin_readcyclecounter();
 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.u), 0, (int)p.u_bytes, 0x00020000);
     const unsigned oob = 0x80000000u;             // tensors are < 2 GiB: stays out of range after adding a channel offset
 
-    // ---- patch decode (uniform) + raw patch loader: NPX pixels x 4 float4 (16 channels); thread handles pieces f = tid + 256 r
-    int n, oy0, ox0, n0;
-    unsigned u_base;
-    unsigned r_off[6];                      // byte offset of the piece for channel block 0
-    unsigned r_valid;                       // bit r: piece r lies inside the image (else it reads as zeros)
-    auto decode = [&](int id) {
-        const int cb = id / per_cb, rem = id - cb * per_cb;
-        n = rem / patches;
-        const int pr = rem - n * patches;
-        const int pty = pr / p.tiles_x, ptx = pr - pty * p.tiles_x;
-        oy0 = pty * (2 * TYN); ox0 = ptx * (2 * TXN); n0 = cb * 64;
-        u_base = (unsigned)cb * (unsigned)nchunks * 16384u;
-        r_valid = 0;
+    // ---- patch decode (uniform) + raw patch loader: NPX pixels x 4 float4 (16 channels); thread handles pieces f = tid + 512 r
+    const int id = blockIdx.x;
+    const int cb = id / per_cb, rem = id - cb * per_cb;
+    const int n = rem / patches;
+    const int pr = rem - n * patches;
+    const int pty = pr / p.tiles_x, ptx = pr - pty * p.tiles_x;
+    const int oy0 = pty * (2 * TYN), ox0 = ptx * (2 * TXN), n0 = cb * 64;
+    const unsigned u_base = (unsigned)cb * (unsigned)(p.Cin >> 2) * 16384u;
+    unsigned r_off[3];                      // byte offset of the piece for channel block 0
+    unsigned r_valid = 0;                   // bit r: piece r lies inside the image (else it reads as zeros)
 #pragma unroll
-        for (int r = 0; r < 6; r++) {
-            const int f = tid + 256 * r;
-            const int px = f >> 2, cq = f & 3;
-            const int py = px / PW, pxx = px - py * PW;
-            const int iy = oy0 - 1 + py, ix = ox0 - 1 + pxx;
-            const bool ok = px < NPX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            r_off[r] = ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * p.Cin + cq * 4) * 4) : 0u;
-            r_valid |= (unsigned)ok << r;
-        }
-    };
+    for (int r = 0; r < 3; r++) {
+        const int f = tid + 512 * r;
+        const int px = f >> 2, cq = f & 3;
+        const int py = px / PW, pxx = px - py * PW;
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + pxx;
+        const bool ok = px < NPX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        r_off[r] = ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * p.Cin + cq * 4) * 4) : 0u;
+        r_valid |= (unsigned)ok << r;
+    }
     // Loads past the last channel block / chunk are not predicated: they read the neighbouring pixel's channels or the next
     // weight block (or zeros beyond the buffer) into LDS buffers that are never consumed.
-    f32x4 rreg[6];
+    f32x4 rreg[3];
     auto raw_gload1 = [&](int S, int r) {
         const unsigned off = ((r_valid >> r) & 1u) ? r_off[r] + (unsigned)(S * 64) : oob;
         rreg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
     };
     auto raw_lstore1 = [&](int buf, int r) {
-        const int f = tid + 256 * r;
+        const int f = tid + 512 * r;
         const int px = f >> 2 < NPX ? f >> 2 : NPX;                                // pieces beyond the patch land in the dump pixel
         float *d = Rb + buf * W_RAW + px * WPX + (f & 3) * 4;
         *reinterpret_cast<f32x2 *>(d) = f32x2{rreg[r][0], rreg[r][1]};
         *reinterpret_cast<f32x2 *>(d + 2) = f32x2{rreg[r][2], rreg[r][3]};
     };
-    // ---- U loader: chunk = [16 xi][64 cout][4] floats contiguous (16 KB); thread handles float4 f = tid + 256 r
-    f32x4 ureg[4];
+    // ---- U loader: chunk = [16 xi][64 cout][4] floats contiguous (16 KB); thread handles float4 f = tid + 512 r
+    f32x4 ureg[2];
     auto u_gload1 = [&](int chunk, int r) {
-        const unsigned off = u_base + (unsigned)(chunk * 16384 + (tid + 256 * r) * 16);
+        const unsigned off = u_base + (unsigned)(chunk * 16384 + (tid + 512 * r) * 16);
         ureg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, off, 0, 0));
     };
     auto u_lstore1 = [&](int buf, int r) {
-        float *d = Ub + buf * W_V + (tid + 256 * r) * WLD;
+        float *d = Ub + buf * W_V + (tid + 512 * r) * WLD;
         *reinterpret_cast<f32x2 *>(d) = f32x2{ureg[r][0], ureg[r][1]};
         *reinterpret_cast<f32x2 *>(d + 2) = f32x2{ureg[r][2], ureg[r][3]};
     };
-    // ---- input transform: lane -> (tile 16 w + 8 (lane >> 5) + (lane & 7), channel (lane >> 3) & 3 of the chunk); scalar
-    // B^T d B in three phases (LDS reads, row pass, column pass + LDS writes) so that the main loop can spread them between MFMAs
-    float td[4][4], tq[4][4];
-    auto tr_read = [&](const float *rp, int a, int b) { td[a][b] = rp[(a * PW + b) * WPX]; };
-    auto tr_rows = [&](int b) {      // B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
-        tq[0][b] = td[0][b] - td[2][b];
-        tq[1][b] = td[1][b] + td[2][b];
-        tq[2][b] = td[2][b] - td[1][b];
-        tq[3][b] = td[1][b] - td[3][b];
+    // ---- input transform B^T d B of one (tile, channel) item per thread pair: tile 16 (w & 3) + 8 (lane >> 5) + (lane & 7),
+    // channel (lane >> 3) & 3 of the chunk; waves 0-3 produce output rows a = 0, 1 (from patch rows 0..2), waves 4-7 rows
+    // a = 3, 2 (from patch rows 1..3).  With B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1] and k0..k2 the three rows read:
+    //   first half:  row0 = k0 - k2 (a=0), row1 = k1 + k2 (a=1);   second half: row0 = k0 - k2 (a=3), row1 = k1 - k0 (a=2)
+    // i.e. row1 = k1 + sgn * (half ? k0 : k2): one select + one exact fma, no divergent code.
+    const int th = wave >> 2;
+    const int tt = (wave & 3) * 16 + (lane >> 5) * 8 + (lane & 7);
+    const int tch = (lane >> 3) & 3;
+    const int t_roff = ((2 * (tt / TXN) + th) * PW + 2 * (tt % TXN)) * WPX + tch;
+    const int t_voff0 = ((th ? 3 : 0) * 4 * 64 + tt) * WLD + tch;          // V row block of row0
+    const int t_voff1 = ((th ? 2 : 1) * 4 * 64 + tt) * WLD + tch;          // V row block of row1
+    const float t_sgn = th ? -1.f : 1.f;
+    float td[3][4], tq[2][4];
+    auto tr_read = [&](const float *rp, int k, int b) { td[k][b] = rp[(k * PW + b) * WPX]; };
+    auto tr_rows = [&]() {
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            tq[0][b] = td[0][b] - td[2][b];
+            tq[1][b] = __builtin_fmaf(t_sgn, th ? td[0][b] : td[2][b], td[1][b]);
+        }
     };
     auto tr_cols = [&](float *vp, int a) {
-        vp[(a * 4 + 0) * 64 * WLD] = tq[a][0] - tq[a][2];
-        vp[(a * 4 + 1) * 64 * WLD] = tq[a][1] + tq[a][2];
-        vp[(a * 4 + 2) * 64 * WLD] = tq[a][2] - tq[a][1];
-        vp[(a * 4 + 3) * 64 * WLD] = tq[a][1] - tq[a][3];
+        vp[0 * 64 * WLD] = tq[a][0] - tq[a][2];
+        vp[1 * 64 * WLD] = tq[a][1] + tq[a][2];
+        vp[2 * 64 * WLD] = tq[a][2] - tq[a][1];
+        vp[3 * 64 * WLD] = tq[a][1] - tq[a][3];
     };
     auto raw_ptr = [&](int chunk) { return Rb + ((chunk >> 2) & 1) * W_RAW + t_roff + (chunk & 3) * 4; };
 
-    // MFMA operand fragments, two register sets: set (chunk & 1) is read right after the barrier that publishes the
-    // chunk's V / U, while the last MFMAs of the previous chunk are still executing
-    f32x16 acc[4][2][2];
-    f32x2 fa0[2][4], fa1[2][4], fb0[2][4], fb1[2][4];
+    // ---- MFMA: wave w owns frequencies xi = 2w, 2w+1: 2 xi x (2x2 MFMA tiles of 32x32) = 128 accumulator registers.
+    // Operand fragments in two register sets: set (chunk & 1) is read right after the barrier that publishes the chunk's
+    // V / U, while the last MFMAs of the previous chunk are still executing.
+    const int frow = lane & 31, fh = lane >> 5;
+    const int f_off = (wave * 2 * 64 + frow) * WLD + 2 * fh;      // xi = 2w + e, row frow, k = 2h + t
+    f32x16 acc[2][2][2];
+    f32x2 fa0[2][2], fa1[2][2], fb0[2][2], fb1[2][2];
     auto frag_load = [&](int set, int buf) {
         const float *va = Vb + buf * W_V + f_off;
         const float *ub = Ub + buf * W_V + f_off;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            fa0[set][j] = *reinterpret_cast<const f32x2 *>(va + j * 64 * WLD);
-            fa1[set][j] = *reinterpret_cast<const f32x2 *>(va + j * 64 * WLD + 32 * WLD);
-            fb0[set][j] = *reinterpret_cast<const f32x2 *>(ub + j * 64 * WLD);
-            fb1[set][j] = *reinterpret_cast<const f32x2 *>(ub + j * 64 * WLD + 32 * WLD);
+        for (int e = 0; e < 2; e++) {
+            fa0[set][e] = *reinterpret_cast<const f32x2 *>(va + e * 64 * WLD);
+            fa1[set][e] = *reinterpret_cast<const f32x2 *>(va + e * 64 * WLD + 32 * WLD);
+            fb0[set][e] = *reinterpret_cast<const f32x2 *>(ub + e * 64 * WLD);
+            fb1[set][e] = *reinterpret_cast<const f32x2 *>(ub + e * 64 * WLD + 32 * WLD);
         }
     };
-    auto mfma_g = [&](int set, int g) {                        // MFMA g of 32 of a chunk: xi j, k step t, tile (ma, nb)
-        const int j = g >> 3, t = (g >> 2) & 1, ma = (g >> 1) & 1, nb = g & 1;
-        acc[j][ma][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ma ? fa1[set][j][t] : fa0[set][j][t],
-                                                               nb ? fb1[set][j][t] : fb0[set][j][t], acc[j][ma][nb], 0, 0, 0);
+    auto mfma_g = [&](int set, int g) {                        // MFMA g of 16 of a chunk: xi e, k step t, tile (ma, nb)
+        const int e = g >> 3, t = (g >> 2) & 1, ma = (g >> 1) & 1, nb = g & 1;
+        acc[e][ma][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ma ? fa1[set][e][t] : fa0[set][e][t],
+                                                               nb ? fb1[set][e][t] : fb0[set][e][t], acc[e][ma][nb], 0, 0, 0);
     };
 
-    decode(blockIdx.x);
+    // ---- head: raw patch of super-step 0, weights and transform of chunk 0, weights of chunk 1 in flight
 #pragma unroll
-    for (int r = 0; r < 6; r++) raw_gload1(0, r);
+    for (int r = 0; r < 3; r++) raw_gload1(0, r);
 #pragma unroll
-    for (int r = 0; r < 4; r++) u_gload1(0, r);
-
+    for (int r = 0; r < 2; r++) u_gload1(0, r);
+#pragma unroll
+    for (int r = 0; r < 3; r++) raw_lstore1(0, r);
+#pragma unroll
+    for (int r = 0; r < 2; r++) { u_lstore1(0, r); u_gload1(1, r); }
+    __syncthreads();
     {
-        const int c_n = n, c_oy0 = oy0, c_ox0 = ox0, c_n0 = n0;
-        // ---- head: raw patch of super-step 0 and weights of chunk 0 (already in flight) to LDS, transform of chunk 0
+        const float *rp = raw_ptr(0);
 #pragma unroll
-        for (int r = 0; r < 6; r++) raw_lstore1(0, r);
+        for (int k = 0; k < 3; k++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) { u_lstore1(0, r); u_gload1(1, r); }
-        __syncthreads();
-        {
-            const float *rp = raw_ptr(0);
+            for (int b = 0; b < 4; b++) tr_read(rp, k, b);
+        tr_rows();
+        tr_cols(Vb + t_voff0, 0);
+        tr_cols(Vb + t_voff1, 1);
+    }
 #pragma unroll
-            for (int a = 0; a < 4; a++)
+    for (int e = 0; e < 2; e++)
 #pragma unroll
-                for (int b = 0; b < 4; b++) tr_read(rp, a, b);
+        for (int a = 0; a < 2; a++)
 #pragma unroll
-            for (int b = 0; b < 4; b++) tr_rows(b);
+            for (int b = 0; b < 2; b++)
 #pragma unroll
-            for (int a = 0; a < 4; a++) tr_cols(Vb + t_voff, a);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int a = 0; a < 2; a++)
-#pragma unroll
-                for (int b = 0; b < 2; b++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) acc[j][a][b][r] = 0.f;
-        __syncthreads();
-        frag_load(0, 0);
+                for (int r = 0; r < 16; r++) acc[e][a][b][r] = 0.f;
+    __syncthreads();
+    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 1] = __builtin_readcyclecounter();
+    frag_load(0, 0);
 
-        for (int S = 0; S < nS; S++) {                                                        // nS >= 1: no zero-trip path for the accumulators
+    for (int S = 0; S < nS; S++) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int chunk = 4 * S + q;
-                const int cur = q & 1, nxt = cur ^ 1;                 // chunk parity == q parity
-                const float *rp = raw_ptr(chunk + 1);
-                float *vp = Vb + nxt * W_V + t_voff;
-                // 24 slots of one MFMA plus a share of the side work for chunk+1/+2, in program order (sched_barrier pins it):
-                //   0-3   weights of chunk+1 (loaded a chunk ago) to LDS, weights of chunk+2 into the same registers;
-                //   0-2   raw patch refill for the next 16 channels (load at q=0/1, LDS store at q=1/2)
-                //   4-11  input transform: LDS reads;  12-15 row pass;  16-19 column pass + LDS writes;  20-23 MFMA only
+        for (int q = 0; q < 4; q++) {
+            const int chunk = 4 * S + q;
+            const int cur = q & 1, nxt = cur ^ 1;                 // chunk parity == q parity
+            const float *rp = raw_ptr(chunk + 1);
+            // 12 slots of one MFMA plus a share of the side work for chunk+1/+2, in program order (sched_barrier pins it).
+            // A wave's own VALU / LDS-write / VMEM instructions do not overlap its MFMAs on this hardware; they run in the
+            // shadow of the SIMD's other wave, so the slotting only has to keep load -> use distances long:
+            //   0-1   weights of chunk+1 (loaded a chunk ago) to LDS, weights of chunk+2 into the same registers
+            //   0-2   raw patch refill for the next 16 channels (load at q=0, LDS store at q=1)
+            //   2-7   input transform: LDS reads;  8 row pass;  9-10 column pass + LDS writes
 #pragma unroll
-                for (int g = 0; g < 24; g++) {
-                    mfma_g(cur, g);
-                    if (g < 4) { u_lstore1(nxt, g); u_gload1(chunk + 2, g); }
-                    if (g < 3) {
-                        if (q == 0) raw_gload1(S + 1, g);
-                        if (q == 1) { raw_lstore1((S + 1) & 1, g); raw_gload1(S + 1, 3 + g); }
-                        if (q == 2) raw_lstore1((S + 1) & 1, 3 + g);
-                    }
-                    if (g >= 4 && g < 12) { tr_read(rp, (g - 4) >> 1, 2 * (g & 1)); tr_read(rp, (g - 4) >> 1, 2 * (g & 1) + 1); }
-                    if (g >= 12 && g < 16) tr_rows(g - 12);
-                    if (g >= 16 && g < 20) tr_cols(vp, g - 16);
-                    __builtin_amdgcn_sched_barrier(0);
+            for (int g = 0; g < 12; g++) {
+                mfma_g(cur, g);
+                if (g < 2 && !(DBG & 2)) { u_lstore1(nxt, g); u_gload1(chunk + 2, g); }
+                if (g < 3 && !(DBG & 2)) {
+                    if (q == 0) raw_gload1(S + 1, g);
+                    if (q == 1) raw_lstore1((S + 1) & 1, g);
                 }
-                __syncthreads();
-                // chunk+1 is published: fetch its fragments under the last eight MFMAs of this chunk
-                frag_load(nxt, nxt);
-#pragma unroll
-                for (int g = 24; g < 32; g++) mfma_g(cur, g);
-#pragma unroll
-                for (int g = 0; g < 8; g++) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // DS read
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+                if (!(DBG & 1)) {
+                    if (g >= 2 && g < 8) { tr_read(rp, (g - 2) >> 1, 2 * (g & 1)); tr_read(rp, (g - 2) >> 1, 2 * (g & 1) + 1); }
+                    if (g == 8) tr_rows();
+                    if (g == 9) tr_cols(Vb + nxt * W_V + t_voff0, 0);
+                    if (g == 10) tr_cols(Vb + nxt * W_V + t_voff1, 1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-        }
-        __syncthreads();                                            // every wave is done with V / U: the exchange tile reuses them
-
-        // ---- output transform.  A^T = [1 1 1 0; 0 1 -1 -1].  T_b = sum_j M_ij A_jb :  T_0 = M0 + M1 + M2,  T_1 = M1 - M2 - M3
-        float *ex = smem;                                           // [4 waves][64 tiles][W_EL]
-        const int HW = p.H * p.W;
-        const int up = p.up;
+            if (!(DBG & 4)) __syncthreads();
+            // chunk+1 is published: fetch its fragments under the last four MFMAs of this chunk
+            frag_load(nxt, nxt);
 #pragma unroll
-        for (int b = 0; b < 2; b++) {
-            // residual rows for this pass, requested before the exchange so that their latency hides behind it
-            f32x4 rres[4][2];
-            if (p.res_mode == PTOCR_RES_ADD_PRE_RELU) {
+            for (int g = 12; g < 16; g++) mfma_g(cur, g);
 #pragma unroll
-                for (int it = 0; it < 4; it++) {
-                    const int item = tid + 256 * it;
-                    const int tile = item >> 4, cq = item & 15;
-                    const int ox = c_ox0 + 2 * (tile % TXN) + b;
-#pragma unroll
-                    for (int a = 0; a < 2; a++) {
-                        const int oy = c_oy0 + 2 * (tile / TXN) + a;
-                        const bool ok = oy < p.H && ox < p.W;
-                        const long m = ok ? (long)c_n * HW + (long)oy * p.W + ox : 0;
-                        rres[it][a] = *reinterpret_cast<const f32x4 *>(p.res + m * p.res_ldc + c_n0 + cq * 4);
-                    }
-                }
+            for (int g = 0; g < 4; g++) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // DS read
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
             }
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-                for (int nt = 0; nt < 2; nt++) {
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const float tv = b == 0 ? acc[0][mt][nt][r] + acc[1][mt][nt][r] + acc[2][mt][nt][r]
-                                                : acc[1][mt][nt][r] - acc[2][mt][nt][r] - acc[3][mt][nt][r];
-                        const int tile = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                        ex[(wave * 64 + tile) * W_EL + nt * 32 + frow] = tv;
-                    }
-                    __builtin_amdgcn_sched_barrier(0);           // keeps the accumulator reads from piling up in VGPRs
-                }
-            __syncthreads();
-            // Y_ab = sum_i A^T[a][i] T_ib :  Y_0b = T_0 + T_1 + T_2,  Y_1b = T_1 - T_2 - T_3 ; items = 64 tiles x 16 channel quads
-#pragma unroll
-            for (int it = 0; it < 4; it++) {
-                const int item = tid + 256 * it;
-                const int tile = item >> 4, cq = item & 15;
-                const f32x4 t0 = *reinterpret_cast<const f32x4 *>(ex + (0 * 64 + tile) * W_EL + cq * 4);
-                const f32x4 t1 = *reinterpret_cast<const f32x4 *>(ex + (1 * 64 + tile) * W_EL + cq * 4);
-                const f32x4 t2 = *reinterpret_cast<const f32x4 *>(ex + (2 * 64 + tile) * W_EL + cq * 4);
-                const f32x4 t3 = *reinterpret_cast<const f32x4 *>(ex + (3 * 64 + tile) * W_EL + cq * 4);
-                const int col = c_n0 + cq * 4;
-                const f32x4 bias4 = *reinterpret_cast<const f32x4 *>(p.bias + col);
-                const int ox = c_ox0 + 2 * (tile % TXN) + b;
-#pragma unroll
-                for (int a = 0; a < 2; a++) {
-                    const int oy = c_oy0 + 2 * (tile / TXN) + a;
-                    if (oy >= p.H || ox >= p.W) continue;
-                    f32x4 v = (a == 0 ? t0 + t1 + t2 : t1 - t2 - t3) + bias4;
-                    if (p.res_mode == PTOCR_RES_ADD_PRE_RELU) v += rres[it][a];
-                    if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                    if (up == 1) {
-                        const long m = (long)c_n * HW + (long)oy * p.W + ox;
-                        *reinterpret_cast<f32x4 *>(p.y + m * p.out_ldc + p.out_coff + col) = v;
-                    } else {                                        // nearest upsample: up x up replicas
-                        const long Wu = (long)p.W * up;
-                        float *yb = p.y + (((long)c_n * p.H * up + (long)oy * up) * Wu + (long)ox * up) * p.out_ldc + p.out_coff + col;
-                        for (int dy = 0; dy < up; dy++)
-                            for (int dx = 0; dx < up; dx++) *reinterpret_cast<f32x4 *>(yb + (dy * Wu + dx) * p.out_ldc) = v;
-                    }
-                }
-            }
-            __syncthreads();
         }
     }
+    __syncthreads();                                            // every wave is done with V / U: the exchange tiles reuse them
+    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 2] = __builtin_readcyclecounter();
+
+    // ---- output transform Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1].  Wave w holds M_ij for i = w >> 1, j = 2 (w & 1) + {0, 1}.
+    // Column pass in registers: its part of T_ib = sum_j M_ij A_jb is  b=0: M_i0 + M_i1 | M_i2 ;  b=1: M_i1 | -M_i2 - M_i3.
+    // The eight partial tiles go through LDS; Y_0b = sum of the partials of waves 0..5, Y_1b = (w2 + w3) - (w4 + w5 + w6 + w7).
+    float *ex = smem;                                           // [8 waves][64 tiles][W_EL]
+    const int HW = p.H * p.W;
+    const int up = p.up;
+    const int jh = wave & 1;
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        // residual rows for this pass, requested before the exchange so that their latency hides behind it
+        f32x4 rres[2][2];
+        if (p.res_mode == PTOCR_RES_ADD_PRE_RELU) {
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                const int item = tid + 512 * it;
+                const int tile = item >> 4, cq = item & 15;
+                const int ox = ox0 + 2 * (tile % TXN) + b;
+#pragma unroll
+                for (int a = 0; a < 2; a++) {
+                    const int oy = oy0 + 2 * (tile / TXN) + a;
+                    const bool ok = oy < p.H && ox < p.W;
+                    const long m = ok ? (long)n * HW + (long)oy * p.W + ox : 0;
+                    rres[it][a] = *reinterpret_cast<const f32x4 *>(p.res + m * p.res_ldc + n0 + cq * 4);
+                }
+            }
+        }
+        const float c0 = b == 0 ? 1.f : (jh ? -1.f : 0.f);      // partial = c0 * acc[0] + c1 * acc[1] (exact: coefficients 0, +-1)
+        const float c1 = b == 0 ? (jh ? 0.f : 1.f) : (jh ? -1.f : 1.f);
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float tv = __builtin_fmaf(c1, acc[1][mt][nt][r], c0 * acc[0][mt][nt][r]);
+                    const int tile = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    ex[(wave * 64 + tile) * W_EL + nt * 32 + frow] = tv;
+                }
+                __builtin_amdgcn_sched_barrier(0);               // keeps the accumulator reads from piling up in VGPRs
+            }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int item = tid + 512 * it;                    // items = 64 tiles x 16 channel quads
+            const int tile = item >> 4, cq = item & 15;
+            f32x4 t[8];
+#pragma unroll
+            for (int w = 0; w < 8; w++) t[w] = *reinterpret_cast<const f32x4 *>(ex + (w * 64 + tile) * W_EL + cq * 4);
+            const int col = n0 + cq * 4;
+            const f32x4 bias4 = *reinterpret_cast<const f32x4 *>(p.bias + col);
+            const f32x4 mid = t[2] + t[3];
+            const f32x4 y0 = ((t[0] + t[1]) + mid) + (t[4] + t[5]);
+            const f32x4 y1 = (mid - (t[4] + t[5])) - (t[6] + t[7]);
+            const int ox = ox0 + 2 * (tile % TXN) + b;
+#pragma unroll
+            for (int a = 0; a < 2; a++) {
+                const int oy = oy0 + 2 * (tile / TXN) + a;
+                if (oy >= p.H || ox >= p.W) continue;
+                f32x4 v = (a == 0 ? y0 : y1) + bias4;
+                if (p.res_mode == PTOCR_RES_ADD_PRE_RELU) v += rres[it][a];
+                if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                if (up == 1) {
+                    const long m = (long)n * HW + (long)oy * p.W + ox;
+                    *reinterpret_cast<f32x4 *>(p.y + m * p.out_ldc + p.out_coff + col) = v;
+                } else {                                        // nearest upsample: up x up replicas
+                    const long Wu = (long)p.W * up;
+                    float *yb = p.y + (((long)n * p.H * up + (long)oy * up) * Wu + (long)ox * up) * p.out_ldc + p.out_coff + col;
+                    for (int dy = 0; dy < up; dy++)
+                        for (int dx = 0; dx < up; dx++) *reinterpret_cast<f32x4 *>(yb + (dy * Wu + dx) * p.out_ldc) = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 3] = __builtin_readcyclecounter();
 }
 
-template <int TXN>
+template <int TXN, int DBG = 0>
 static int launch_wino(const WinoArgs &a, hipStream_t stream) {
     const size_t lds = sizeof(float) * (4 * W_V + 2 * wino_raw_floats(TXN));
     static bool attr_set = false;
     if (!attr_set) {
-        PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino_kernel<TXN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const void *fn = reinterpret_cast<const void *>(&conv_wino_kernel<TXN, DBG>);
+        PT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv_wino_kernel<TXN>, dim3((unsigned)a.total), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((conv_wino_kernel<TXN, DBG>), dim3((unsigned)a.total), dim3(512), lds, stream, a);
     return launch_ok("conv_wino_kernel");
 }
 
 }  // namespace ptocr
 
 using namespace ptocr;
+
+static unsigned long long *g_wino_dbg = nullptr;
+// debug: device buffer of 4 clock samples per workgroup (start, main loop start, main loop end, end); null switches it off
+extern "C" void ptocr_wino_set_timing_buffer(void *d_buf) { g_wino_dbg = (unsigned long long *)d_buf; }
 
 // d_u: weights transformed on the host, packed f32[Cout/64][Cin/4][16][64][4] (U = G g G^T per (cout, cin), BN folded).
 // up > 1 writes every output pixel up x up times (nearest upsample) into y[N][H*up][W*up][out_ldc].
@@ -350,6 +356,7 @@ extern "C" int ptocr_conv3x3_wino_f32(const float *d_x, const float *d_u, const 
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.relu = relu; a.res_mode = res_mode; a.out_ldc = out_ldc; a.out_coff = out_coff; a.res_ldc = res_ldc > 0 ? res_ldc : Cout;
     a.up = up;
+    a.dbg = g_wino_dbg;
     a.x_bytes = (long)N * H * W * Cin * 4;
     a.u_bytes = (long)Cout * Cin * 16 * 4;
     PT_CHECK(a.x_bytes < (1L << 31) && a.u_bytes < (1L << 31), "ptocr_conv3x3_wino_f32: tensor larger than 2 GiB");
@@ -361,5 +368,16 @@ extern "C" int ptocr_conv3x3_wino_f32(const float *d_x, const float *d_u, const 
     const long total = (long)N * a.tiles_x * a.tiles_y * (Cout / 64);
     PT_CHECK(total < (1L << 31), "ptocr_conv3x3_wino_f32: too many patches");
     a.total = (int)total;
+#ifdef PTOCR_WINO_EXPERIMENT
+    static const int dbgm = getenv("PTOCR_WINO_DBG") ? atoi(getenv("PTOCR_WINO_DBG")) : 0;
+    if (!use_tall) switch (dbgm) {
+        case 1: return launch_wino<8, 1>(a, (hipStream_t)stream);
+        case 2: return launch_wino<8, 2>(a, (hipStream_t)stream);
+        case 3: return launch_wino<8, 3>(a, (hipStream_t)stream);
+        case 4: return launch_wino<8, 4>(a, (hipStream_t)stream);
+        case 7: return launch_wino<8, 7>(a, (hipStream_t)stream);
+        default: break;
+    }
+#endif
     return use_tall ? launch_wino<4>(a, (hipStream_t)stream) : launch_wino<8>(a, (hipStream_t)stream);
 }
