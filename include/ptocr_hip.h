@@ -71,6 +71,9 @@ int ptocr_conv2d_f32(const ptocr_conv_desc *d, const float *d_x, const float *d_
 int ptocr_conv3x3_wino_f32(const float *d_x, const float *d_u, const float *d_bias, const float *d_res, float *d_y,
                            int N, int H, int W, int Cin, int Cout, int relu, int res_mode, int res_ldc, int out_ldc,
                            int out_coff, int up, void *stream);
+/* Measurement hook (no reference counterpart): d_buf = device u64[4 * workgroups] receives s_memtime samples (start, main
+ * loop start, main loop end, end) from every Winograd workgroup launched afterwards; NULL switches the probe off. */
+void ptocr_wino_set_timing_buffer(void *d_buf);
 
 /* f32[N,C,H,W] -> f32[N,H,W,Cpad] (channels >= C zero-filled; Cpad % 4 == 0) */
 int ptocr_nchw_to_nhwc_f32(const float *d_x, float *d_y, int N, int C, int H, int W, int Cpad, void *stream);

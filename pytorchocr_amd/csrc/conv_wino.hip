@@ -4,19 +4,24 @@
 // fewer MFMAs than the direct implicit GEMM, at fp32 accuracy (transform constants are 0, +-1, +-1/2).
 // Replaces the same ATen conv2d calls as conv_mfma.hip (det_resnet.py:66-82, fpn.py:59-82, det_db_head.py:10).
 //
-// Work item ("patch"): 64 Winograd tiles (TXN x TYN tiles = 2TXN x 2TYN outputs) of one image x 64 output channels.  One
-// persistent workgroup per CU (4 waves, one per SIMD) walks patches id = blockIdx.x, + gridDim.x, ...; consecutive ids
-// share the output-channel block, so the weights stay in the XCD's L2.
-// The 16 "frequencies" xi = (i, j) are 16 independent GEMMs [64 tiles x Cin] x [Cin x 64]; wave i owns row i (four xi):
-// 4 xi x (2x2 MFMA tiles of 32x32) = 256 accumulator registers.
-// K loop in chunks of 4 channels (two v_mfma_f32_32x32x2_f32 per tile pair): per chunk each wave issues 32 MFMAs while,
-// in their shadow, it (a) transforms the next chunk's input (B^T d B from an LDS copy of the raw patch, 16 channels deep),
-// (b) copies the next chunk of pre-transformed weights U (packed contiguously on the host) to LDS, and (c) every fourth
-// chunk refills the raw patch for the next 16 channels.  V, U and the raw patch are all double-buffered in LDS (~147 KB).
-// Output transform: wave i reduces its four M_ij to T_ib = sum_j M_ij A_jb in registers; the sum over i (A^T) goes through
-// LDS, two passes (b = 0, 1), followed by bias / residual / ReLU and 16-byte channel-contiguous stores (optionally
-// replicated up x up: the FPN's nearest upsample into the concat buffer).  The next patch's first loads are issued before
-// the output transform so that their latency and the store drain hide behind it.
+// Work item ("patch"): 64 Winograd tiles (TXN x TYN tiles = 2TXN x 2TYN outputs; 16x16 or, for short images, 32 rows x 8
+// columns) of one image x 64 output channels, one 512-thread workgroup per patch (8 waves = two per SIMD, 1 workgroup/CU).
+// Consecutive blockIdx share the output-channel block, so the weights stay in the XCD's L2.
+// The 16 "frequencies" xi = (i, j) are 16 independent GEMMs [64 tiles x Cin] x [Cin x 64]; wave w owns xi = 2w, 2w+1:
+// 2 xi x (2x2 MFMA tiles of 32x32) = 128 accumulator registers.
+// K loop in chunks of 4 channels (two v_mfma_f32_32x32x2_f32 per tile pair): per chunk each wave issues 16 MFMAs and a
+// 1/8 share of the side work: (a) input transform of the next chunk (B^T d B from an LDS copy of the raw patch, 16 channels
+// deep; a thread pair per (tile, channel), each half producing two of the four output rows), (b) copy of the next chunk of
+// pre-transformed weights U (packed contiguously on the host) to LDS, (c) every fourth chunk the refill of the raw patch.
+// V, U and the raw patch are all double-buffered in LDS (~145 KB).
+// Measured on MI355X (tools/wino_timing.py, s_memtime probes): fp32 MFMAs do not overlap the same SIMD's VALU / LDS-store /
+// VMEM issue, whichever wave issues it -- a chunk costs 2048 MFMA cycles + ~500 cycles of side work (2560 measured; 2060
+// with the side work compiled out) -- so the side work is kept minimal rather than "hidden"; two waves per SIMD mainly
+// shorten the output transform and the barrier skew (4 waves/workgroup: 2740 cycles per chunk, 14.7k-cycle epilogue; 8
+// waves: 2560 and 8.9k).
+// Output transform: wave w reduces its two M_ij over j in registers (its part of T_ib = sum_j M_ij A_jb); the sum over the
+// eight partial tiles (A^T over i) goes through LDS, two passes (b = 0, 1), followed by bias / residual / ReLU and 16-byte
+// channel-contiguous stores (optionally replicated up x up: the FPN's nearest upsample into the concat buffer).
 #include "common.h"
 #include <cstdlib>
 
@@ -31,25 +36,28 @@ constexpr int W_V = 16 * 64 * WLD;         // floats per V (or U) buffer
 constexpr int WPX = 18;                    // LDS pixel stride (floats) of the raw patch: 16 channels + 2, so that the transform's
                                            // ds_read_b32 (banks mod 32, 32-lane groups) of 8 tiles x 4 channels is conflict-free
 constexpr int W_EL = 68;                   // exchange tile row stride
-constexpr int wino_raw_floats(int txn) { return ((2 * txn + 2) * (2 * (64 / txn) + 2) + 1) * WPX + 2; }   // + one dump pixel
+// patch geometry: TN images x TYN x TXN tiles = 64 tiles; raw patch = TN sub-patches of (2 TYN + 2) x (2 TXN + 2) pixels
+constexpr int wino_raw_floats(int txn, int tyn) { return ((64 / (txn * tyn)) * (2 * txn + 2) * (2 * tyn + 2) + 1) * WPX + 2; }   // + one dump pixel
 
 struct WinoArgs {
     const float *x, *u, *bias, *res;
     float *y;
     int N, H, W, Cin, Cout;                // stride 1, pad 1: output H x W
-    int tiles_x, tiles_y;                  // patches per image
+    int tiles_x, tiles_y;                  // patches per image group (TN images)
     int relu, res_mode, out_ldc, out_coff, res_ldc, up;
-    int total;                             // patches x images x (Cout / 64)
+    int total;                             // patches x image groups x (Cout / 64)
     long x_bytes, u_bytes;
-    unsigned long long *dbg;               // timing probe (PTOCR_WINO_TIMING): 4 clock samples per workgroup, or null
+    unsigned long long *dbg;               // timing probe (ptocr_wino_set_timing_buffer): 4 clock samples per workgroup, or null
 };
 
-template <int TXN, int DBG = 0>
+template <int TXN, int TYN, int DBG = 0>
 __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs p) {
-    constexpr int TYN = 64 / TXN;                   // tiles per patch column
-    constexpr int PW = 2 * TXN + 2, PH = 2 * TYN + 2, NPX = PW * PH;
-    constexpr int W_RAW = wino_raw_floats(TXN);
-    static_assert(NPX * 4 <= 3 * 512, "raw patch must fit three 16-byte pieces per thread");
+    constexpr int TN = 64 / (TXN * TYN);            // images per patch (short images: several images share a patch)
+    constexpr int PW = 2 * TXN + 2, PH = 2 * TYN + 2, NPX = TN * PW * PH;
+    constexpr int W_RAW = wino_raw_floats(TXN, TYN);
+    constexpr int NPIECE = (NPX * 4 + 511) / 512;   // 16-byte pieces of the raw patch per thread (3 or 4)
+    static_assert(TN * TXN * TYN == 64 && NPIECE <= 4, "unsupported patch geometry");
+    static_assert(4 * W_V + 2 * W_RAW <= 40960, "LDS budget (160 KB)");
     static_assert(8 * 64 * W_EL <= 4 * W_V + 2 * W_RAW, "exchange tiles must fit the LDS allocation");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Vb = smem;                       // [2][16][64][WLD]
@@ -59,7 +67,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // 0..7: two waves per SIMD
     const int patches = p.tiles_x * p.tiles_y;
-    const int per_cb = p.N * patches;
+    const int per_cb = ((p.N + TN - 1) / TN) * patches;
     const int nS = p.Cin >> 4;              // super-steps of 16 channels
     if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 0] = __builtin_readcyclecounter();
 
@@ -70,26 +78,27 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs p) {
     // ---- patch decode (uniform) + raw patch loader: NPX pixels x 4 float4 (16 channels); thread handles pieces f = tid + 512 r
     const int id = blockIdx.x;
     const int cb = id / per_cb, rem = id - cb * per_cb;
-    const int n = rem / patches;
-    const int pr = rem - n * patches;
+    const int n_base = (rem / patches) * TN;           // first image of the patch
+    const int pr = rem - (rem / patches) * patches;
     const int pty = pr / p.tiles_x, ptx = pr - pty * p.tiles_x;
     const int oy0 = pty * (2 * TYN), ox0 = ptx * (2 * TXN), n0 = cb * 64;
     const unsigned u_base = (unsigned)cb * (unsigned)(p.Cin >> 2) * 16384u;
-    unsigned r_off[3];                      // byte offset of the piece for channel block 0
-    unsigned r_valid = 0;                   // bit r: piece r lies inside the image (else it reads as zeros)
+    unsigned r_off[NPIECE];                 // byte offset of the piece for channel block 0
+    unsigned r_valid = 0;                   // bit r: piece r lies inside an image (else it reads as zeros)
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
+    for (int r = 0; r < NPIECE; r++) {
         const int f = tid + 512 * r;
         const int px = f >> 2, cq = f & 3;
-        const int py = px / PW, pxx = px - py * PW;
-        const int iy = oy0 - 1 + py, ix = ox0 - 1 + pxx;
-        const bool ok = px < NPX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        r_off[r] = ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * p.Cin + cq * 4) * 4) : 0u;
+        const int img = px / (PW * PH), pq = px - img * (PW * PH);
+        const int py = pq / PW, pxx = pq - py * PW;
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + pxx, nn = n_base + img;
+        const bool ok = px < NPX && nn < p.N && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        r_off[r] = ok ? (unsigned)((((nn * p.H + iy) * p.W + ix) * p.Cin + cq * 4) * 4) : 0u;
         r_valid |= (unsigned)ok << r;
     }
     // Loads past the last channel block / chunk are not predicated: they read the neighbouring pixel's channels or the next
     // weight block (or zeros beyond the buffer) into LDS buffers that are never consumed.
-    f32x4 rreg[3];
+    f32x4 rreg[NPIECE];
     auto raw_gload1 = [&](int S, int r) {
         const unsigned off = ((r_valid >> r) & 1u) ? r_off[r] + (unsigned)(S * 64) : oob;
         rreg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
@@ -120,7 +129,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs p) {
     const int th = wave >> 2;
     const int tt = (wave & 3) * 16 + (lane >> 5) * 8 + (lane & 7);
     const int tch = (lane >> 3) & 3;
-    const int t_roff = ((2 * (tt / TXN) + th) * PW + 2 * (tt % TXN)) * WPX + tch;
+    const int t_img = tt / (TXN * TYN), t_ty = (tt / TXN) % TYN, t_tx = tt % TXN;
+    const int t_roff = ((t_img * PH + 2 * t_ty + th) * PW + 2 * t_tx) * WPX + tch;
     const int t_voff0 = ((th ? 3 : 0) * 4 * 64 + tt) * WLD + tch;          // V row block of row0
     const int t_voff1 = ((th ? 2 : 1) * 4 * 64 + tt) * WLD + tch;          // V row block of row1
     const float t_sgn = th ? -1.f : 1.f;
@@ -167,11 +177,11 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs p) {
 
     // ---- head: raw patch of super-step 0, weights and transform of chunk 0, weights of chunk 1 in flight
 #pragma unroll
-    for (int r = 0; r < 3; r++) raw_gload1(0, r);
+    for (int r = 0; r < NPIECE; r++) raw_gload1(0, r);
 #pragma unroll
     for (int r = 0; r < 2; r++) u_gload1(0, r);
 #pragma unroll
-    for (int r = 0; r < 3; r++) raw_lstore1(0, r);
+    for (int r = 0; r < NPIECE; r++) raw_lstore1(0, r);
 #pragma unroll
     for (int r = 0; r < 2; r++) { u_lstore1(0, r); u_gload1(1, r); }
     __syncthreads();
@@ -207,13 +217,13 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs p) {
             // A wave's own VALU / LDS-write / VMEM instructions do not overlap its MFMAs on this hardware; they run in the
             // shadow of the SIMD's other wave, so the slotting only has to keep load -> use distances long:
             //   0-1   weights of chunk+1 (loaded a chunk ago) to LDS, weights of chunk+2 into the same registers
-            //   0-2   raw patch refill for the next 16 channels (load at q=0, LDS store at q=1)
+            //   0-3   raw patch refill for the next 16 channels (load at q=0, LDS store at q=1)
             //   2-7   input transform: LDS reads;  8 row pass;  9-10 column pass + LDS writes
 #pragma unroll
             for (int g = 0; g < 12; g++) {
                 mfma_g(cur, g);
                 if (g < 2 && !(DBG & 2)) { u_lstore1(nxt, g); u_gload1(chunk + 2, g); }
-                if (g < 3 && !(DBG & 2)) {
+                if (g < NPIECE && !(DBG & 2)) {
                     if (q == 0) raw_gload1(S + 1, g);
                     if (q == 1) raw_lstore1((S + 1) & 1, g);
                 }
@@ -258,10 +268,11 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs p) {
                 const int item = tid + 512 * it;
                 const int tile = item >> 4, cq = item & 15;
                 const int ox = ox0 + 2 * (tile % TXN) + b;
+                const int n = n_base + tile / (TXN * TYN);
 #pragma unroll
                 for (int a = 0; a < 2; a++) {
-                    const int oy = oy0 + 2 * (tile / TXN) + a;
-                    const bool ok = oy < p.H && ox < p.W;
+                    const int oy = oy0 + 2 * ((tile / TXN) % TYN) + a;
+                    const bool ok = oy < p.H && ox < p.W && n < p.N;
                     const long m = ok ? (long)n * HW + (long)oy * p.W + ox : 0;
                     rres[it][a] = *reinterpret_cast<const f32x4 *>(p.res + m * p.res_ldc + n0 + cq * 4);
                 }
@@ -295,10 +306,11 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs p) {
             const f32x4 y0 = ((t[0] + t[1]) + mid) + (t[4] + t[5]);
             const f32x4 y1 = (mid - (t[4] + t[5])) - (t[6] + t[7]);
             const int ox = ox0 + 2 * (tile % TXN) + b;
+            const int n = n_base + tile / (TXN * TYN);
 #pragma unroll
             for (int a = 0; a < 2; a++) {
-                const int oy = oy0 + 2 * (tile / TXN) + a;
-                if (oy >= p.H || ox >= p.W) continue;
+                const int oy = oy0 + 2 * ((tile / TXN) % TYN) + a;
+                if (oy >= p.H || ox >= p.W || n >= p.N) continue;
                 f32x4 v = (a == 0 ? y0 : y1) + bias4;
                 if (p.res_mode == PTOCR_RES_ADD_PRE_RELU) v += rres[it][a];
                 if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
@@ -318,16 +330,21 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs p) {
     if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 3] = __builtin_readcyclecounter();
 }
 
-template <int TXN, int DBG = 0>
-static int launch_wino(const WinoArgs &a, hipStream_t stream) {
-    const size_t lds = sizeof(float) * (4 * W_V + 2 * wino_raw_floats(TXN));
+template <int TXN, int TYN, int DBG = 0>
+static int launch_wino(WinoArgs a, hipStream_t stream) {
+    constexpr int TN = 64 / (TXN * TYN);
+    a.tiles_x = cdiv(a.W, 2 * TXN); a.tiles_y = cdiv(a.H, 2 * TYN);
+    const long total = (long)cdiv(a.N, TN) * a.tiles_x * a.tiles_y * (a.Cout / 64);
+    PT_CHECK(total < (1L << 31), "ptocr_conv3x3_wino_f32: too many patches");
+    a.total = (int)total;
+    const size_t lds = sizeof(float) * (4 * W_V + 2 * wino_raw_floats(TXN, TYN));
     static bool attr_set = false;
     if (!attr_set) {
-        const void *fn = reinterpret_cast<const void *>(&conv_wino_kernel<TXN, DBG>);
+        const void *fn = reinterpret_cast<const void *>(&conv_wino_kernel<TXN, TYN, DBG>);
         PT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_wino_kernel<TXN, DBG>), dim3((unsigned)a.total), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((conv_wino_kernel<TXN, TYN, DBG>), dim3((unsigned)a.total), dim3(512), lds, stream, a);
     return launch_ok("conv_wino_kernel");
 }
 
@@ -360,24 +377,27 @@ extern "C" int ptocr_conv3x3_wino_f32(const float *d_x, const float *d_u, const 
     a.x_bytes = (long)N * H * W * Cin * 4;
     a.u_bytes = (long)Cout * Cin * 16 * 4;
     PT_CHECK(a.x_bytes < (1L << 31) && a.u_bytes < (1L << 31), "ptocr_conv3x3_wino_f32: tensor larger than 2 GiB");
-    // patch geometry: 16 x 16 outputs, or 32 rows x 8 columns when that covers the image with fewer wasted outputs
-    const long sq = (long)cdiv(W, 16) * cdiv(H, 16), tall = (long)cdiv(W, 8) * cdiv(H, 32);
-    const bool use_tall = tall < sq;
-    a.tiles_x = use_tall ? cdiv(W, 8) : cdiv(W, 16);
-    a.tiles_y = use_tall ? cdiv(H, 32) : cdiv(H, 16);
-    const long total = (long)N * a.tiles_x * a.tiles_y * (Cout / 64);
-    PT_CHECK(total < (1L << 31), "ptocr_conv3x3_wino_f32: too many patches");
-    a.total = (int)total;
+    // patch geometry (64 tiles): 16x16 outputs, 32 rows x 8 columns, or -- for short images (text lines) -- 8x16 outputs of 2
+    // images / 4x16 outputs of 4 images; the one that covers the batch with the fewest patches wins
+    const long cnt[4] = {(long)N * cdiv(H, 16) * cdiv(W, 16), (long)N * cdiv(H, 32) * cdiv(W, 8),
+                         (long)cdiv(N, 2) * cdiv(H, 8) * cdiv(W, 16), (long)cdiv(N, 4) * cdiv(H, 4) * cdiv(W, 16)};
+    int geo = 0;
+    for (int g = 1; g < 4; g++)
+        if (cnt[g] < cnt[geo]) geo = g;
 #ifdef PTOCR_WINO_EXPERIMENT
     static const int dbgm = getenv("PTOCR_WINO_DBG") ? atoi(getenv("PTOCR_WINO_DBG")) : 0;
-    if (!use_tall) switch (dbgm) {
-        case 1: return launch_wino<8, 1>(a, (hipStream_t)stream);
-        case 2: return launch_wino<8, 2>(a, (hipStream_t)stream);
-        case 3: return launch_wino<8, 3>(a, (hipStream_t)stream);
-        case 4: return launch_wino<8, 4>(a, (hipStream_t)stream);
-        case 7: return launch_wino<8, 7>(a, (hipStream_t)stream);
+    if (geo == 0) switch (dbgm) {
+        case 1: return launch_wino<8, 8, 1>(a, (hipStream_t)stream);
+        case 2: return launch_wino<8, 8, 2>(a, (hipStream_t)stream);
+        case 3: return launch_wino<8, 8, 3>(a, (hipStream_t)stream);
+        case 4: return launch_wino<8, 8, 4>(a, (hipStream_t)stream);
         default: break;
     }
 #endif
-    return use_tall ? launch_wino<4>(a, (hipStream_t)stream) : launch_wino<8>(a, (hipStream_t)stream);
+    switch (geo) {
+        case 1: return launch_wino<4, 16>(a, (hipStream_t)stream);
+        case 2: return launch_wino<8, 4>(a, (hipStream_t)stream);
+        case 3: return launch_wino<8, 2>(a, (hipStream_t)stream);
+        default: return launch_wino<8, 8>(a, (hipStream_t)stream);
+    }
 }
