@@ -130,65 +130,120 @@ __device__ __forceinline__ void uf_union(int *lab, int a, int b) {
     }
 }
 
-// label[p] = first pixel of p's run: every run is a tree of depth 1 whose root is the run start
-__global__ __launch_bounds__(256) void ccl_init_kernel(const unsigned *__restrict__ bits, int *__restrict__ lab, DbpostDims d) {
-    const int img = blockIdx.z, y = blockIdx.y;
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= d.W) return;
-    const unsigned *row = bits + ((long)img * d.H + y) * d.WW;
-    lab[(long)img * d.HW + (long)y * d.W + x] = y * d.W + run_start(row, x);
+// The three CC kernels work on 32-pixel bitmap words (one thread per word) and touch `labels` only at RUN STARTS: a
+// run (maximal horizontal stretch of one class) is a union-find node named by the linear index of its first pixel; the
+// label entries of all other pixels are never written or read.  Every union below links two run starts, larger root under
+// smaller, so a component's root is its raster-first pixel -- exactly where Suzuki's scan starts that border.
+struct WordCtx {
+    unsigned w, valid, starts, ends;        // bits, in-image mask, run-start mask, run-end mask
+};
+
+__device__ __forceinline__ WordCtx word_ctx(const unsigned *row, int wi, const DbpostDims &d) {
+    WordCtx c;
+    c.w = row[wi];
+    const int rem = d.W - wi * 32;
+    c.valid = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1);
+    const unsigned carry = wi ? row[wi - 1] >> 31 : 0u;
+    c.starts = (c.w ^ ((c.w << 1) | carry)) & c.valid;
+    if (wi == 0) c.starts |= 1u;                                   // x = 0 always starts a run
+    const unsigned next = (wi + 1 < d.WW) ? (row[wi + 1] & 1u) : 0u;
+    c.ends = (c.w ^ ((c.w >> 1) | (next << 31))) & c.valid;
+    if (rem <= 32) c.ends |= 1u << (rem - 1);                      // x = W-1 always ends a run
+    return c;
 }
 
-// merges runs of adjacent rows; only run boundaries issue unions (see the rules in the comments)
-__global__ __launch_bounds__(256) void ccl_merge_kernel(const unsigned *__restrict__ bits, int *__restrict__ labels, DbpostDims d) {
-    const int img = blockIdx.z, y = blockIdx.y;
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= d.W) return;
+// label[s] = s for every run start s
+__global__ __launch_bounds__(256) void ccl_init_kernel(const unsigned *__restrict__ bits, int *__restrict__ labels, DbpostDims d) {
+    const int img = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= d.H * d.WW) return;
+    const int y = idx / d.WW, wi = idx - y * d.WW;
     const unsigned *row = bits + ((long)img * d.H + y) * d.WW;
     int *lab = labels + (long)img * d.HW;
-    const int p = y * d.W + x;
-    const int c = pix(row, x);
-    const bool left_same = x > 0 && pix(row, x - 1) == c;
-    const bool right_same = x + 1 < d.W && pix(row, x + 1) == c;
-    if (!c) {
-        // background touching the image border belongs to the frame component
-        if (x == 0 || x == d.W - 1 || ((y == 0 || y == d.H - 1) && !left_same)) uf_union(lab, p, FRAME);
+    unsigned m = word_ctx(row, wi, d).starts;
+    const int base = y * d.W + wi * 32;
+    while (m) {
+        const int i = __ffs(m) - 1;
+        m &= m - 1;
+        lab[base + i] = base + i;
+    }
+}
+
+// merges runs of adjacent rows; only run boundaries issue unions (the rules are those of a per-pixel scan, evaluated
+// on bit masks): vertical links where one of the two runs starts; for foreground (8-connected) the NW link at a run
+// start and the NE link at a run end, when the pixel straight above is background; background is 4-connected and every
+// background run touching the image border is united with the virtual FRAME root.
+__global__ __launch_bounds__(256) void ccl_merge_kernel(const unsigned *__restrict__ bits, int *__restrict__ labels, DbpostDims d) {
+    const int img = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= d.H * d.WW) return;
+    const int y = idx / d.WW, wi = idx - y * d.WW;
+    const unsigned *row = bits + ((long)img * d.H + y) * d.WW;
+    int *lab = labels + (long)img * d.HW;
+    const WordCtx c = word_ctx(row, wi, d);
+    const int x0 = wi * 32, base = y * d.W + x0;
+    auto rs_cur = [&](int i) { return (c.starts >> i) & 1u ? base + i : y * d.W + run_start(row, x0 + i); };
+    // background touching the image border belongs to the frame component
+    {
+        unsigned m = ~c.w & c.valid;
+        unsigned f = (y == 0 || y == d.H - 1) ? (m & c.starts) : 0u;
+        if (wi == 0) f |= m & 1u;
+        if (x0 + 32 >= d.W) f |= m & (1u << (d.W - 1 - x0));
+        while (f) {
+            const int i = __ffs(f) - 1;
+            f &= f - 1;
+            uf_union(lab, rs_cur(i), FRAME);
+        }
     }
     if (y == 0) return;
     const unsigned *up = row - d.WW;
-    const int q = p - d.W;
-    const int n = pix(up, x);
-    if (n == c) {
-        // vertical link: needed only where one of the two runs starts (otherwise the pair to the left covers it)
-        const bool up_left_same = x > 0 && pix(up, x - 1) == c;
-        if (!left_same || !up_left_same) uf_union(lab, p, q);
-    } else if (c) {
-        // foreground, 8-connectivity: diagonal links only matter when the pixel straight above is background
-        if (x > 0 && !left_same && pix(up, x - 1)) uf_union(lab, p, q - 1);          // NW, taken at a run start
-        if (x + 1 < d.W && !right_same && pix(up, x + 1)) uf_union(lab, p, q + 1);   // NE, taken at a run end
+    const WordCtx u = word_ctx(up, wi, d);
+    const int ubase = base - d.W;
+    auto rs_up = [&](int x) { return (y - 1) * d.W + run_start(up, x); };
+    // vertical links: same class above, and the current or the upper run starts here
+    unsigned v = ~(c.w ^ u.w) & c.valid & (c.starts | u.starts);
+    while (v) {
+        const int i = __ffs(v) - 1;
+        v &= v - 1;
+        uf_union(lab, rs_cur(i), (u.starts >> i) & 1u ? ubase + i : rs_up(x0 + i));
+    }
+    // foreground with background straight above: diagonal links
+    const unsigned fgbg = c.w & ~u.w & c.valid;
+    const unsigned ucarry = wi ? up[wi - 1] >> 31 : 0u;
+    unsigned nw = fgbg & c.starts & ((u.w << 1) | ucarry);         // pix(up, x-1) set; x = 0 has no NW neighbour (carry 0)
+    while (nw) {
+        const int i = __ffs(nw) - 1;
+        nw &= nw - 1;
+        uf_union(lab, base + i, rs_up(x0 + i - 1));
+    }
+    const unsigned unext = (wi + 1 < d.WW) ? (up[wi + 1] & 1u) : 0u;
+    unsigned ne = fgbg & c.ends & ((u.w >> 1) | (unext << 31));     // pix(up, x+1) set (bits beyond W are clear)
+    while (ne) {
+        const int i = __ffs(ne) - 1;
+        ne &= ne - 1;
+        uf_union(lab, rs_cur(i), ubase + i + 1);                    // up(x) = 0, up(x+1) = 1: a run start
     }
 }
 
-// label[p] = root; counts border starts (roots) per 1024-pixel chunk
+// label[s] = root for every run start s; counts border starts (roots) per 1024-pixel chunk (chunk_cnt zeroed by the host)
 __global__ __launch_bounds__(256) void ccl_flatten_kernel(const unsigned *__restrict__ bits, int *__restrict__ labels,
                                                           int *__restrict__ chunk_cnt, DbpostDims d) {
-    const int img = blockIdx.y, chunk = blockIdx.x;
+    const int img = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= d.H * d.WW) return;
+    const int y = idx / d.WW, wi = idx - y * d.WW;
+    const unsigned *row = bits + ((long)img * d.H + y) * d.WW;
     int *lab = labels + (long)img * d.HW;
-    __shared__ int cnt;
-    if (threadIdx.x == 0) cnt = 0;
-    __syncthreads();
-    int mine = 0;
-    for (int k = 0; k < CHUNK / 256; k++) {
-        const long p = (long)chunk * CHUNK + k * 256 + threadIdx.x;
-        if (p < d.HW) {
-            const int r = uf_find(lab, (int)p);
-            lab[p] = r;
-            mine += (r == (int)p);
-        }
+    unsigned m = word_ctx(row, wi, d).starts;
+    const int base = y * d.W + wi * 32;
+    while (m) {
+        const int i = __ffs(m) - 1;
+        m &= m - 1;
+        const int s = base + i;
+        const int r = uf_find(lab, s);
+        lab[s] = r;
+        if (r == s) atomicAdd(&chunk_cnt[(long)img * d.nchunks + s / CHUNK], 1);
     }
-    if (mine) atomicAdd(&cnt, mine);
-    __syncthreads();
-    if (threadIdx.x == 0) chunk_cnt[(long)img * d.nchunks + chunk] = cnt;
 }
 
 // suffix sums over chunks (one block per image): chunk_cnt[c] := number of starts in chunks > c; total per image
@@ -237,7 +292,12 @@ __global__ __launch_bounds__(256) void gather_starts_kernel(const unsigned *__re
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int k = CHUNK / 256 - 1; k >= 0; k--) {               // highest pixels first
         const long p = (long)chunk * CHUNK + k * 256 + (255 - threadIdx.x);   // thread 0 takes the highest pixel
-        const bool is = p < d.HW && lab[p] == (int)p;
+        bool is = false;
+        if (p < d.HW) {                                         // only run starts carry labels
+            const int y = (int)(p / d.W), x = (int)(p - (long)y * d.W);
+            const unsigned *row = bits + ((long)img * d.H + y) * d.WW;
+            is = (x == 0 || pix(row, x) != pix(row, x - 1)) && lab[p] == (int)p;
+        }
         const unsigned long long m = __ballot(is);
         if (lane == 0) wave_cnt[wave] = __popcll(m);
         __syncthreads();
@@ -260,68 +320,92 @@ __global__ __launch_bounds__(256) void gather_starts_kernel(const unsigned *__re
 }
 
 // ------------------------------------------------------------------------------------------ border following
-struct BitImg {
+// direction k (0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE) -> step, from 2-bit fields (value + 1) so that no table load sits in the walk
+__device__ __forceinline__ int dir_dx(int k) { return (int)((0x901Au >> (2 * k)) & 3u) - 1; }    // {1,1,0,-1,-1,-1,0,1}
+__device__ __forceinline__ int dir_dy(int k) { return (int)((0xA901u >> (2 * k)) & 3u) - 1; }    // {0,-1,-1,-1,0,1,1,1}
+
+struct TraceOut { int npts, xmin, xmax, ymin, ymax; };
+
+// One WAVE per border.  The walk itself is sequential, so all 64 lanes execute it redundantly on wave-uniform state while
+// the bitmap around the current pixel sits in registers: an 8-row x 8-word (256-pixel) window, lane l = word (l & 7) of
+// row (l >> 3), fetched with one coalesced load and re-centred when the walk leaves it.  A step then costs a few readlanes
+// instead of six dependent global loads per lane, and the kernel holds no LDS (it has to co-reside with the convolution
+// workgroups of the next batch, which take almost a whole CU's LDS).  What remains is the dependent instruction chain of
+// the walk itself (~1200 cycles per step for a lone wave), i.e. latency, not bandwidth.
+struct BitWindow {
     const unsigned *bits; int H, W, WW;
-    // 3 pixels (x-1, x, x+1) of row r as bits 0..2; outside the image = 0
-    __device__ __forceinline__ unsigned row3(int r, int x) const {
-        if ((unsigned)r >= (unsigned)H) return 0;
-        const unsigned *row = bits + (long)r * WW;
-        const int xs = x - 1;
-        if (xs < 0) return (row[0] & 3u) << 1;
-        const int wi = xs >> 5, sh = xs & 31;
-        unsigned long long c = row[wi];
-        if (wi + 1 < WW) c |= (unsigned long long)row[wi + 1] << 32;
-        return (unsigned)(c >> sh) & 7u;
+    int y0, wx0;                 // window origin: row, word column (may lie outside the image: those words read 0)
+    unsigned word;               // this lane's word
+    __device__ __forceinline__ void load(int x, int y, int lane) {
+        y0 = y - 3;
+        wx0 = (x >> 5) - 4 + ((x & 31) >= 16);
+        const int r = y0 + (lane >> 3), wi = wx0 + (lane & 7);
+        word = ((unsigned)r < (unsigned)H && (unsigned)wi < (unsigned)WW) ? bits[(long)r * WW + wi] : 0u;
     }
-    // 8-neighbour mask, bit k = neighbour in direction k (0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE)
-    __device__ __forceinline__ unsigned nbr8(int x, int y) const {
-        const unsigned a = row3(y - 1, x), b = row3(y, x), c = row3(y + 1, x);
+    __device__ __forceinline__ bool inside(int x, int y) const {
+        return y >= y0 + 1 && y <= y0 + 6 && x >= wx0 * 32 + 1 && x <= wx0 * 32 + 254;
+    }
+    // 3 pixels (x-1, x, x+1) of window row rr as bits 0..2
+    __device__ __forceinline__ unsigned row3(int rr, int x) const {
+        const int xs = x - 1 - wx0 * 32;                        // 0 .. 253
+        const int l = __builtin_amdgcn_readfirstlane(rr * 8 + (xs >> 5));
+        const unsigned lo = __builtin_amdgcn_readlane(word, l);
+        const unsigned hi = __builtin_amdgcn_readlane(word, (l + 1) & 63);   // next row's word only when xs & 31 <= 29: unused bits
+        const unsigned long long c = lo | ((unsigned long long)hi << 32);
+        return (unsigned)(c >> (xs & 31)) & 7u;
+    }
+    // 8-neighbour mask, bit k = neighbour in direction k (0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE); pixels outside the image = 0
+    __device__ __forceinline__ unsigned nbr8(int x, int y, int lane) {
+        if (!inside(x, y)) load(x, y, lane);
+        const int rr = y - y0;
+        const unsigned a = row3(rr - 1, x), b = row3(rr, x), c = row3(rr + 1, x);
         return ((b >> 2) & 1) | (((a >> 2) & 1) << 1) | (((a >> 1) & 1) << 2) | ((a & 1) << 3) |
                ((b & 1) << 4) | ((c & 1) << 5) | (((c >> 1) & 1) << 6) | (((c >> 2) & 1) << 7);
     }
 };
 
-__device__ __constant__ const int8_t k_dx[8] = {1, 1, 0, -1, -1, -1, 0, 1};
-__device__ __constant__ const int8_t k_dy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
-
-struct TraceOut { int npts, xmin, xmax, ymin, ymax; };
-
-// Suzuki-Abe border following from (sx, sy) with the direction-change points of CHAIN_APPROX_SIMPLE.
-// out == nullptr: count only.  Points are stored as (x | y << 16).
+// Suzuki-Abe border following from (sx, sy) with the direction-change points of CHAIN_APPROX_SIMPLE, executed by a whole
+// wave on uniform state.  WRITE: points are stored as (x | y << 16), 64 at a time (lane i keeps point i of the batch).
 template <bool WRITE>
-__device__ TraceOut trace_border(const BitImg &im, int sx, int sy, int is_hole, unsigned *out) {
+__device__ TraceOut trace_border(BitWindow &im, int sx, int sy, int is_hole, unsigned *out, int lane) {
     TraceOut t; t.npts = 0; t.xmin = t.xmax = sx; t.ymin = t.ymax = sy;
-    unsigned nb = im.nbr8(sx, sy);
+    im.load(sx, sy, lane);
+    unsigned nb = im.nbr8(sx, sy, lane);
     // first neighbour clockwise from W (outer) or from E (hole)
     int s = is_hole ? 0 : 4, s_end = s;
     do { s = (s - 1) & 7; } while (!((nb >> s) & 1) && s != s_end);
     if (s == s_end) {                            // single pixel domain
-        if (WRITE) out[0] = (unsigned)sx | ((unsigned)sy << 16);
+        if (WRITE && lane == 0) out[0] = (unsigned)sx | ((unsigned)sy << 16);
         t.npts = 1;
         return t;
     }
-    const int i1x = sx + k_dx[s], i1y = sy + k_dy[s];
+    const int i1x = sx + dir_dx(s), i1y = sy + dir_dy(s);
     int prev_s = s ^ 4;
     int x = sx, y = sy;
+    unsigned mine = 0;                           // the batch point held by this lane
     // every wave must terminate: a border has fewer steps than 4 per pixel; a longer walk means a broken start
     for (long guard = 4L * im.H * im.W + 16; guard > 0; guard--) {
         // counter-clockwise search for the next border pixel starting after direction s
         const unsigned rot = ((nb | (nb << 8)) >> (s + 1)) & 0xffu;     // bit j = direction s+1+j
         if (rot == 0) break;                                              // isolated pixel: cannot happen after a valid start
         const int j = __ffs(rot) - 1;
-        s = (s + 1 + j) & 7;
+        s = __builtin_amdgcn_readfirstlane((s + 1 + j) & 7);   // wave-uniform: keep the walk on the scalar unit
         if (s != prev_s) {
-            if (WRITE) out[t.npts] = (unsigned)x | ((unsigned)y << 16);
+            if (WRITE) {
+                if (lane == (t.npts & 63)) mine = (unsigned)x | ((unsigned)y << 16);
+                if ((t.npts & 63) == 63) out[(t.npts & ~63) + lane] = mine;
+            }
             t.npts++;
             prev_s = s;
             t.xmin = min(t.xmin, x); t.xmax = max(t.xmax, x); t.ymin = min(t.ymin, y); t.ymax = max(t.ymax, y);
         }
-        const int nx = x + k_dx[s], ny = y + k_dy[s];
+        const int nx = x + dir_dx(s), ny = y + dir_dy(s);
         if (nx == sx && ny == sy && x == i1x && y == i1y) break;
-        x = nx; y = ny;
+        x = __builtin_amdgcn_readfirstlane(nx); y = __builtin_amdgcn_readfirstlane(ny);
         s = (s + 4) & 7;
-        nb = im.nbr8(x, y);
+        nb = im.nbr8(x, y, lane);
     }
+    if (WRITE && lane < (t.npts & 63)) out[(t.npts & ~63) + lane] = mine;      // the last partial batch
     return t;
 }
 
@@ -332,17 +416,20 @@ struct CandInfo {          // per candidate, filled by the count pass
 
 __global__ __launch_bounds__(64) void trace_count_kernel(const unsigned *__restrict__ bits, const Cand *__restrict__ cands,
                                                          const int *__restrict__ totals, CandInfo *__restrict__ info, DbpostDims d) {
-    const int img = blockIdx.y;
-    const int k = blockIdx.x * 64 + threadIdx.x;
+    const int img = blockIdx.y, k = blockIdx.x;
+    const int lane = threadIdx.x;
     const int num = min(totals[img], MAX_CAND);
     if (k >= num) return;
     const Cand c = cands[(long)img * MAX_CAND + k];
-    BitImg im; im.bits = bits + (long)img * d.H * d.WW; im.H = d.H; im.W = d.W; im.WW = d.WW;
-    const int y = c.p / d.W, x = c.p - y * d.W;
-    const TraceOut t = trace_border<false>(im, x - c.is_hole, y, c.is_hole, nullptr);
-    CandInfo ci; ci.npts = t.npts; ci.off = 0;
-    ci.xmin = (short)t.xmin; ci.xmax = (short)t.xmax; ci.ymin = (short)t.ymin; ci.ymax = (short)t.ymax;
-    info[(long)img * MAX_CAND + k] = ci;
+    BitWindow im; im.bits = bits + (long)img * d.H * d.WW; im.H = d.H; im.W = d.W; im.WW = d.WW;
+    const int p = __builtin_amdgcn_readfirstlane(c.p), hole = __builtin_amdgcn_readfirstlane(c.is_hole);
+    const int y = p / d.W, x = p - y * d.W;
+    const TraceOut t = trace_border<false>(im, x - hole, y, hole, nullptr, lane);
+    if (lane == 0) {
+        CandInfo ci; ci.npts = t.npts; ci.off = 0;
+        ci.xmin = (short)t.xmin; ci.xmax = (short)t.xmax; ci.ymin = (short)t.ymin; ci.ymax = (short)t.ymax;
+        info[(long)img * MAX_CAND + k] = ci;
+    }
 }
 
 // exclusive scan of npts over the candidates of one image (borders with <= 2 points are dropped by the
@@ -369,16 +456,18 @@ __global__ __launch_bounds__(1024) void pool_offsets_kernel(CandInfo *__restrict
 __global__ __launch_bounds__(64) void trace_write_kernel(const unsigned *__restrict__ bits, const Cand *__restrict__ cands,
                                                          const int *__restrict__ totals, const CandInfo *__restrict__ info,
                                                          unsigned *__restrict__ pool, const int *__restrict__ flags, DbpostDims d) {
-    const int img = blockIdx.y;
-    const int k = blockIdx.x * 64 + threadIdx.x;
+    const int img = blockIdx.y, k = blockIdx.x;
+    const int lane = threadIdx.x;
     const int num = min(totals[img], MAX_CAND);
     if (k >= num || (flags[img] & 4)) return;
     const CandInfo ci = info[(long)img * MAX_CAND + k];
     if (ci.npts <= 2) return;
     const Cand c = cands[(long)img * MAX_CAND + k];
-    BitImg im; im.bits = bits + (long)img * d.H * d.WW; im.H = d.H; im.W = d.W; im.WW = d.WW;
-    const int y = c.p / d.W, x = c.p - y * d.W;
-    trace_border<true>(im, x - c.is_hole, y, c.is_hole, pool + (long)img * d.pool_cap + ci.off);
+    BitWindow im; im.bits = bits + (long)img * d.H * d.WW; im.H = d.H; im.W = d.W; im.WW = d.WW;
+    const int p = __builtin_amdgcn_readfirstlane(c.p), hole = __builtin_amdgcn_readfirstlane(c.is_hole);
+    const int off = __builtin_amdgcn_readfirstlane(ci.off);
+    const int y = p / d.W, x = p - y * d.W;
+    trace_border<true>(im, x - hole, y, hole, pool + (long)img * d.pool_cap + off, lane);
 }
 
 // ------------------------------------------------------------------------------------------ geometry (one lane)
@@ -851,41 +940,59 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const float *__rest
         atomicMax(&col_hi[x], y);
     }
     __syncthreads();
+    // ---- 1b. compact the non-empty columns in place (a CHAIN_APPROX_SIMPLE border touches few columns: 8 of 169 is
+    //          typical for a clean text blob), so that the quadratic filter below runs over m columns, not bw
+    int *col_x = col_hi + MAXW;                                 // [MAXW] x (relative to xmin) of compacted column a
+    static_assert(3 * MAXW <= 2 * LDS_PLANE_WORDS, "arena too small");
+    const int lane = tid & 63, wave = tid >> 6;
+    int m_cols = 0;
+    {
+        constexpr int ROUNDS = MAXW / CT_THREADS;               // bw <= MAXW
+        int v_lo[ROUNDS], v_hi[ROUNDS], v_pos[ROUNDS];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; r++) {
+            const int i = r * CT_THREADS + tid;
+            const bool has = i < bw && col_lo[i] != 0x7fffffff;
+            v_lo[r] = has ? col_lo[i] : 0; v_hi[r] = has ? col_hi[i] : 0;
+            const unsigned long long bal = __ballot(has);
+            if (lane == 0) wave_cnt[wave] = __popcll(bal);
+            __syncthreads();
+            int pos = m_cols + __popcll(bal & ((1ull << lane) - 1));
+            for (int w = 0; w < wave; w++) pos += wave_cnt[w];
+            v_pos[r] = has ? pos : -1;
+            for (int w = 0; w < CT_THREADS / 64; w++) m_cols += wave_cnt[w];
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < ROUNDS; r++)
+            if (v_pos[r] >= 0) { col_lo[v_pos[r]] = v_lo[r]; col_hi[v_pos[r]] = v_hi[r]; col_x[v_pos[r]] = r * CT_THREADS + tid; }
+        __syncthreads();
+    }
     // ---- 2. keep a column extreme only if it is a strict vertex of its chain: for the min-y chain, point i survives
     //         iff it lies strictly on the outer side of every chord (j, k), j < i < k.  It is enough to test the chord
-    //         through the steepest predecessor and the steepest successor.  Exact integer arithmetic, O(bw^2 / 256).
+    //         through the steepest predecessor and the steepest successor.  Exact integer arithmetic, O(m^2 / 256).
     //         End columns always survive.  Survivors are emitted in (x, y) order: the order cv::convexHull sorts to.
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int base = 0; base < bw; base += CT_THREADS) {
+    for (int base = 0; base < m_cols; base += CT_THREADS) {
         const int i = base + tid;
-        int keep_lo = 0, keep_hi = 0, ylo = 0, yhi = 0;
-        if (i < bw && col_lo[i] != 0x7fffffff) {
-            ylo = col_lo[i]; yhi = col_hi[i];
-            if (i == 0 || i == bw - 1) { keep_lo = 1; keep_hi = yhi != ylo; }
+        int keep_lo = 0, keep_hi = 0, ylo = 0, yhi = 0, xi = 0;
+        if (i < m_cols) {
+            ylo = col_lo[i]; yhi = col_hi[i]; xi = col_x[i];
+            if (i == 0 || i == m_cols - 1) { keep_lo = 1; keep_hi = yhi != ylo; }
             else {
-                // min-y chain: predecessor j* minimising the slope towards i ... found with cross products
-                int bj = -1, bk = -1;
-                for (int j = 0; j < i; j++) {
-                    if (col_lo[j] == 0x7fffffff) continue;
-                    // j better than bj if bj lies on/above... keep the j for which i is "most hidden": the chord j->i lowest (min y) on the left
-                    if (bj < 0 || cross3(j, col_lo[j], i, ylo, bj, col_lo[bj]) > 0) bj = j;
-                }
-                for (int kk = i + 1; kk < bw; kk++) {
-                    if (col_lo[kk] == 0x7fffffff) continue;
-                    if (bk < 0 || cross3(i, ylo, kk, col_lo[kk], bk, col_lo[bk]) > 0) bk = kk;
-                }
+                // min-y chain: the predecessor / successor for which i is "most hidden", found with cross products
+                int bj = 0, bk = i + 1;
+                for (int j = 1; j < i; j++)
+                    if (cross3(col_x[j], col_lo[j], xi, ylo, col_x[bj], col_lo[bj]) > 0) bj = j;
+                for (int kk = i + 2; kk < m_cols; kk++)
+                    if (cross3(xi, ylo, col_x[kk], col_lo[kk], col_x[bk], col_lo[bk]) > 0) bk = kk;
                 // strict vertex of the min-y chain <=> i strictly above (smaller y) the chord bj -> bk: cross(bj, bk, i) < 0
-                keep_lo = cross3(bj, col_lo[bj], bk, col_lo[bk], i, ylo) < 0;
-                bj = -1; bk = -1;
-                for (int j = 0; j < i; j++) {
-                    if (col_lo[j] == 0x7fffffff) continue;
-                    if (bj < 0 || cross3(j, col_hi[j], i, yhi, bj, col_hi[bj]) < 0) bj = j;
-                }
-                for (int kk = i + 1; kk < bw; kk++) {
-                    if (col_lo[kk] == 0x7fffffff) continue;
-                    if (bk < 0 || cross3(i, yhi, kk, col_hi[kk], bk, col_hi[bk]) < 0) bk = kk;
-                }
-                keep_hi = cross3(bj, col_hi[bj], bk, col_hi[bk], i, yhi) > 0;
+                keep_lo = cross3(col_x[bj], col_lo[bj], col_x[bk], col_lo[bk], xi, ylo) < 0;
+                bj = 0; bk = i + 1;
+                for (int j = 1; j < i; j++)
+                    if (cross3(col_x[j], col_hi[j], xi, yhi, col_x[bj], col_hi[bj]) < 0) bj = j;
+                for (int kk = i + 2; kk < m_cols; kk++)
+                    if (cross3(xi, yhi, col_x[kk], col_hi[kk], col_x[bk], col_hi[bk]) < 0) bk = kk;
+                keep_hi = cross3(col_x[bj], col_hi[bj], col_x[bk], col_hi[bk], xi, yhi) > 0;
                 if (yhi == ylo && keep_lo) keep_hi = 0;          // one point, emit once
             }
         }
@@ -896,8 +1003,8 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const float *__rest
         __syncthreads();
         int pos = sh_n + incl - mine;
         for (int w = 0; w < wave; w++) pos += wave_cnt[w];
-        if (keep_lo) { if (pos < MAXHULL) { cand_pts[pos].x = (float)(i + xmin); cand_pts[pos].y = (float)ylo; } pos++; }
-        if (keep_hi) { if (pos < MAXHULL) { cand_pts[pos].x = (float)(i + xmin); cand_pts[pos].y = (float)yhi; } pos++; }
+        if (keep_lo) { if (pos < MAXHULL) { cand_pts[pos].x = (float)(xi + xmin); cand_pts[pos].y = (float)ylo; } pos++; }
+        if (keep_hi) { if (pos < MAXHULL) { cand_pts[pos].x = (float)(xi + xmin); cand_pts[pos].y = (float)yhi; } pos++; }
         __syncthreads();
         if (tid == CT_THREADS - 1) sh_n = pos;
         __syncthreads();
@@ -1115,7 +1222,7 @@ extern "C" int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, co
     d.pool_cap = h->pool_cap;
     PT_HIP(hipMemcpyAsync(h->src_wh, h_src_wh, sizeof(int) * 2 * N, hipMemcpyHostToDevice, s));
     PT_HIP(hipMemsetAsync(h->flags, 0, sizeof(int) * N, s));
-    const dim3 row_grid(cdiv(W, 1024), H, N), px_grid(cdiv(W, 256), H, N);
+    const dim3 row_grid(cdiv(W, 1024), H, N);
     if (d_bitmap) hipLaunchKernelGGL(pack_u8_kernel, row_grid, dim3(256), 0, s, d_bitmap, h->bits, d);
     else hipLaunchKernelGGL(binarize_kernel, row_grid, dim3(256), 0, s, d_maps, h->bits, d, thresh);
     unsigned *bits = h->bits;
@@ -1123,14 +1230,16 @@ extern "C" int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, co
         hipLaunchKernelGGL(dilate2x2_kernel, dim3(cdiv(d.WW, 256), H, N), dim3(256), 0, s, h->bits, h->bits2, d);
         bits = h->bits2;
     }
-    hipLaunchKernelGGL(ccl_init_kernel, px_grid, dim3(256), 0, s, bits, h->labels, d);
-    hipLaunchKernelGGL(ccl_merge_kernel, px_grid, dim3(256), 0, s, bits, h->labels, d);
-    hipLaunchKernelGGL(ccl_flatten_kernel, dim3(d.nchunks, N), dim3(256), 0, s, bits, h->labels, h->chunk_cnt, d);
+    const dim3 word_grid(cdiv(H * d.WW, 256), N);
+    PT_HIP(hipMemsetAsync(h->chunk_cnt, 0, sizeof(int) * (size_t)N * d.nchunks, s));
+    hipLaunchKernelGGL(ccl_init_kernel, word_grid, dim3(256), 0, s, bits, h->labels, d);
+    hipLaunchKernelGGL(ccl_merge_kernel, word_grid, dim3(256), 0, s, bits, h->labels, d);
+    hipLaunchKernelGGL(ccl_flatten_kernel, word_grid, dim3(256), 0, s, bits, h->labels, h->chunk_cnt, d);
     hipLaunchKernelGGL(chunk_suffix_kernel, dim3(N), dim3(1024), 0, s, h->chunk_cnt, h->totals, d);
     hipLaunchKernelGGL(gather_starts_kernel, dim3(d.nchunks, N), dim3(256), 0, s, bits, h->labels, h->chunk_cnt, h->cands, d);
-    hipLaunchKernelGGL(trace_count_kernel, dim3(cdiv(MAX_CAND, 64), N), dim3(64), 0, s, bits, h->cands, h->totals, h->info, d);
+    hipLaunchKernelGGL(trace_count_kernel, dim3(MAX_CAND, N), dim3(64), 0, s, bits, h->cands, h->totals, h->info, d);
     hipLaunchKernelGGL(pool_offsets_kernel, dim3(N), dim3(1024), 0, s, h->info, h->totals, h->flags, d);
-    hipLaunchKernelGGL(trace_write_kernel, dim3(cdiv(MAX_CAND, 64), N), dim3(64), 0, s, bits, h->cands, h->totals, h->info,
+    hipLaunchKernelGGL(trace_write_kernel, dim3(MAX_CAND, N), dim3(64), 0, s, bits, h->cands, h->totals, h->info,
                        h->pool, h->flags, d);
     hipLaunchKernelGGL(contour_kernel, dim3(MAX_CAND, N), dim3(CT_THREADS), 0, s, d_maps, h->cands, h->totals, h->info, h->pool,
                        h->gslots, h->slot_locks, h->results, h->flags, h->src_wh, box_thresh, unclip_ratio, h->slot_words, use_padding_resize, d);
