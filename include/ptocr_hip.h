@@ -138,7 +138,8 @@ int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, const uint8_t
                             int32_t *h_flags, void *stream);
 
 /* Inspection hook for the parity tests: per-candidate records of the LAST ptocr_db_postprocess call for image `img`
- * (synchronises the device).  h_results: 1000 x {int status; int box[8]; float score; float rect[5]; int npix;
+ * (synchronises the device).  h_total: number of border starts found -- exact below 1000; for an image with more, the
+ * count of the bottom strip that already holds the 1000 used ones (>= 1000, the rest of the image is not labelled).  h_results: 1000 x {int status; int box[8]; float score; float rect[5]; int npix;
  * float distance;}  h_cands: 1000 x {int trigger_pixel; int is_hole;}  h_info: 1000 x {int npts; int off;
  * short xmin, xmax, ymin, ymax;}  status: 0 box, 1 <=2 points, 2 ssid<3, 3 score<box_thresh, 4 unclip<1.001, 5 ssid<5. */
 int ptocr_dbpost_debug_results(ptocr_dbpost_t h, int img, int32_t *h_total, void *h_results, void *h_cands, void *h_info);

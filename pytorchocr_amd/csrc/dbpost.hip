@@ -28,12 +28,15 @@ namespace ptocr {
 constexpr int MAX_CAND = 1000;          // reference db_postprocess.cpp:239 (hard-coded max_candidates)
 constexpr int CHUNK = 1024;             // pixels per root-count chunk
 constexpr int FRAME = -1;               // label of background connected to the image frame
+constexpr int QCAP = 512;               // points of a border's quick slot: borders up to QCAP points are traced once
+constexpr long QOFF = (long)MAX_CAND * QCAP;   // start of the exact-size region inside an image's pool
 
 struct DbpostDims {
     int N, H, W, WW;                    // WW = 32-bit words per bitmap row
     long HW;
     int nchunks;                        // chunks per image
-    long pool_cap;                      // points per image
+    long pool_cap;                      // points per image in the exact-size region of the point pool
+    long pool_stride;                   // points per image: quick slots (MAX_CAND x QCAP) + exact-size region
 };
 
 // ------------------------------------------------------------------------------------------ binarize
@@ -152,12 +155,25 @@ __device__ __forceinline__ WordCtx word_ctx(const unsigned *row, int wi, const D
     return c;
 }
 
-// label[s] = s for every run start s
-__global__ __launch_bounds__(256) void ccl_init_kernel(const unsigned *__restrict__ bits, int *__restrict__ labels, DbpostDims d) {
+// Two passes share these kernels.  Only the MAX_CAND borders with the largest start index are ever used (the reference keeps
+// the first 1000 of findContours' bottom-up list), so pass A labels just the bottom STRIP_ROWS rows -- a run of the strip's
+// first row that is linked to the row above joins the FRAME root (its component starts further up: not a start of the
+// strip) -- and when an image has >= MAX_CAND starts there (speckle / noise maps: tens of thousands of components) pass B,
+// the whole image, is skipped for it.  Clean maps have few components and go through both passes (pass A costs 9 %).
+constexpr int STRIP_ROWS = 64;
+struct CclPass { int y_first; const int *skip_if_full; };        // skip_if_full: per-image start counts of pass A, or null
+
+__device__ __forceinline__ bool ccl_skip(const CclPass &ps, int img) { return ps.skip_if_full && ps.skip_if_full[img] >= MAX_CAND; }
+
+// label[s] = s for every run start s (pass B also clears the image's chunk counters)
+__global__ __launch_bounds__(256) void ccl_init_kernel(const unsigned *__restrict__ bits, int *__restrict__ labels,
+                                                       int *__restrict__ chunk_cnt, DbpostDims d, CclPass ps) {
     const int img = blockIdx.y;
+    if (ccl_skip(ps, img)) return;
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= d.H * d.WW) return;
-    const int y = idx / d.WW, wi = idx - y * d.WW;
+    if (ps.skip_if_full && idx < d.nchunks) chunk_cnt[(long)img * d.nchunks + idx] = 0;
+    if (idx >= (d.H - ps.y_first) * d.WW) return;
+    const int y = ps.y_first + idx / d.WW, wi = idx % d.WW;
     const unsigned *row = bits + ((long)img * d.H + y) * d.WW;
     int *lab = labels + (long)img * d.HW;
     unsigned m = word_ctx(row, wi, d).starts;
@@ -173,11 +189,14 @@ __global__ __launch_bounds__(256) void ccl_init_kernel(const unsigned *__restric
 // on bit masks): vertical links where one of the two runs starts; for foreground (8-connected) the NW link at a run
 // start and the NE link at a run end, when the pixel straight above is background; background is 4-connected and every
 // background run touching the image border is united with the virtual FRAME root.
-__global__ __launch_bounds__(256) void ccl_merge_kernel(const unsigned *__restrict__ bits, int *__restrict__ labels, DbpostDims d) {
+__global__ __launch_bounds__(256) void ccl_merge_kernel(const unsigned *__restrict__ bits, int *__restrict__ labels, DbpostDims d,
+                                                        CclPass ps) {
     const int img = blockIdx.y;
+    if (ccl_skip(ps, img)) return;
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= d.H * d.WW) return;
-    const int y = idx / d.WW, wi = idx - y * d.WW;
+    if (idx >= (d.H - ps.y_first) * d.WW) return;
+    const int y = ps.y_first + idx / d.WW, wi = idx % d.WW;
+    const bool cut = y == ps.y_first && y > 0;                    // first row of the strip: links upwards end in FRAME
     const unsigned *row = bits + ((long)img * d.H + y) * d.WW;
     int *lab = labels + (long)img * d.HW;
     const WordCtx c = word_ctx(row, wi, d);
@@ -205,7 +224,7 @@ __global__ __launch_bounds__(256) void ccl_merge_kernel(const unsigned *__restri
     while (v) {
         const int i = __ffs(v) - 1;
         v &= v - 1;
-        uf_union(lab, rs_cur(i), (u.starts >> i) & 1u ? ubase + i : rs_up(x0 + i));
+        uf_union(lab, rs_cur(i), cut ? FRAME : ((u.starts >> i) & 1u ? ubase + i : rs_up(x0 + i)));
     }
     // foreground with background straight above: diagonal links
     const unsigned fgbg = c.w & ~u.w & c.valid;
@@ -214,24 +233,25 @@ __global__ __launch_bounds__(256) void ccl_merge_kernel(const unsigned *__restri
     while (nw) {
         const int i = __ffs(nw) - 1;
         nw &= nw - 1;
-        uf_union(lab, base + i, rs_up(x0 + i - 1));
+        uf_union(lab, base + i, cut ? FRAME : rs_up(x0 + i - 1));
     }
     const unsigned unext = (wi + 1 < d.WW) ? (up[wi + 1] & 1u) : 0u;
     unsigned ne = fgbg & c.ends & ((u.w >> 1) | (unext << 31));     // pix(up, x+1) set (bits beyond W are clear)
     while (ne) {
         const int i = __ffs(ne) - 1;
         ne &= ne - 1;
-        uf_union(lab, rs_cur(i), ubase + i + 1);                    // up(x) = 0, up(x+1) = 1: a run start
+        uf_union(lab, rs_cur(i), cut ? FRAME : ubase + i + 1);      // up(x) = 0, up(x+1) = 1: a run start
     }
 }
 
 // label[s] = root for every run start s; counts border starts (roots) per 1024-pixel chunk (chunk_cnt zeroed by the host)
 __global__ __launch_bounds__(256) void ccl_flatten_kernel(const unsigned *__restrict__ bits, int *__restrict__ labels,
-                                                          int *__restrict__ chunk_cnt, DbpostDims d) {
+                                                          int *__restrict__ chunk_cnt, DbpostDims d, CclPass ps) {
     const int img = blockIdx.y;
+    if (ccl_skip(ps, img)) return;
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= d.H * d.WW) return;
-    const int y = idx / d.WW, wi = idx - y * d.WW;
+    if (idx >= (d.H - ps.y_first) * d.WW) return;
+    const int y = ps.y_first + idx / d.WW, wi = idx % d.WW;
     const unsigned *row = bits + ((long)img * d.H + y) * d.WW;
     int *lab = labels + (long)img * d.HW;
     unsigned m = word_ctx(row, wi, d).starts;
@@ -247,8 +267,10 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(const unsigned *__rest
 }
 
 // suffix sums over chunks (one block per image): chunk_cnt[c] := number of starts in chunks > c; total per image
-__global__ __launch_bounds__(1024) void chunk_suffix_kernel(int *__restrict__ chunk_cnt, int *__restrict__ totals, DbpostDims d) {
+__global__ __launch_bounds__(1024) void chunk_suffix_kernel(int *__restrict__ chunk_cnt, int *__restrict__ totals, DbpostDims d,
+                                                            CclPass ps, int *__restrict__ strip_totals) {
     const int img = blockIdx.x;
+    if (ccl_skip(ps, img)) return;                               // pass A was enough: its suffix sums and total stand
     int *cc = chunk_cnt + (long)img * d.nchunks;
     __shared__ int part[1024];
     // each thread owns a contiguous slice of chunks, highest chunks first
@@ -272,7 +294,7 @@ __global__ __launch_bounds__(1024) void chunk_suffix_kernel(int *__restrict__ ch
         cc[c] = run;
         run += v;
     }
-    if (threadIdx.x == 1023) totals[img] = part[1023];
+    if (threadIdx.x == 1023) { totals[img] = part[1023]; if (!ps.skip_if_full) strip_totals[img] = part[1023]; }
 }
 
 // candidate k (0 = bottom-most start) of an image: trigger pixel and kind
@@ -367,7 +389,7 @@ struct BitWindow {
 // Suzuki-Abe border following from (sx, sy) with the direction-change points of CHAIN_APPROX_SIMPLE, executed by a whole
 // wave on uniform state.  WRITE: points are stored as (x | y << 16), 64 at a time (lane i keeps point i of the batch).
 template <bool WRITE>
-__device__ TraceOut trace_border(BitWindow &im, int sx, int sy, int is_hole, unsigned *out, int lane) {
+__device__ TraceOut trace_border(BitWindow &im, int sx, int sy, int is_hole, unsigned *out, int cap, int lane) {
     TraceOut t; t.npts = 0; t.xmin = t.xmax = sx; t.ymin = t.ymax = sy;
     im.load(sx, sy, lane);
     unsigned nb = im.nbr8(sx, sy, lane);
@@ -391,7 +413,7 @@ __device__ TraceOut trace_border(BitWindow &im, int sx, int sy, int is_hole, uns
         const int j = __ffs(rot) - 1;
         s = __builtin_amdgcn_readfirstlane((s + 1 + j) & 7);   // wave-uniform: keep the walk on the scalar unit
         if (s != prev_s) {
-            if (WRITE) {
+            if (WRITE && t.npts < cap) {                        // cap is a multiple of 64: whole batches only
                 if (lane == (t.npts & 63)) mine = (unsigned)x | ((unsigned)y << 16);
                 if ((t.npts & 63) == 63) out[(t.npts & ~63) + lane] = mine;
             }
@@ -405,7 +427,7 @@ __device__ TraceOut trace_border(BitWindow &im, int sx, int sy, int is_hole, uns
         s = (s + 4) & 7;
         nb = im.nbr8(x, y, lane);
     }
-    if (WRITE && lane < (t.npts & 63)) out[(t.npts & ~63) + lane] = mine;      // the last partial batch
+    if (WRITE && t.npts < cap && lane < (t.npts & 63)) out[(t.npts & ~63) + lane] = mine;      // the last partial batch
     return t;
 }
 
@@ -414,8 +436,11 @@ struct CandInfo {          // per candidate, filled by the count pass
     short xmin, xmax, ymin, ymax;
 };
 
+// first pass: counts the points of every border and stores them in the border's quick slot as long as they fit (<= QCAP:
+// every text-like border); only longer borders are traced a second time into an exact-size slot
 __global__ __launch_bounds__(64) void trace_count_kernel(const unsigned *__restrict__ bits, const Cand *__restrict__ cands,
-                                                         const int *__restrict__ totals, CandInfo *__restrict__ info, DbpostDims d) {
+                                                         const int *__restrict__ totals, CandInfo *__restrict__ info,
+                                                         unsigned *__restrict__ pool, DbpostDims d) {
     const int img = blockIdx.y, k = blockIdx.x;
     const int lane = threadIdx.x;
     const int num = min(totals[img], MAX_CAND);
@@ -424,9 +449,9 @@ __global__ __launch_bounds__(64) void trace_count_kernel(const unsigned *__restr
     BitWindow im; im.bits = bits + (long)img * d.H * d.WW; im.H = d.H; im.W = d.W; im.WW = d.WW;
     const int p = __builtin_amdgcn_readfirstlane(c.p), hole = __builtin_amdgcn_readfirstlane(c.is_hole);
     const int y = p / d.W, x = p - y * d.W;
-    const TraceOut t = trace_border<false>(im, x - hole, y, hole, nullptr, lane);
+    const TraceOut t = trace_border<true>(im, x - hole, y, hole, pool + (long)img * d.pool_stride + (long)k * QCAP, QCAP, lane);
     if (lane == 0) {
-        CandInfo ci; ci.npts = t.npts; ci.off = 0;
+        CandInfo ci; ci.npts = t.npts; ci.off = k * QCAP;
         ci.xmin = (short)t.xmin; ci.xmax = (short)t.xmax; ci.ymin = (short)t.ymin; ci.ymax = (short)t.ymax;
         info[(long)img * MAX_CAND + k] = ci;
     }
@@ -440,7 +465,7 @@ __global__ __launch_bounds__(1024) void pool_offsets_kernel(CandInfo *__restrict
     __shared__ int sh[1024];
     const int num = min(totals[img], MAX_CAND);
     int n = 0;
-    if (k < num) { n = info[(long)img * MAX_CAND + k].npts; if (n <= 2) n = 0; }
+    if (k < num) { n = info[(long)img * MAX_CAND + k].npts; if (n <= QCAP) n = 0; }   // short borders sit in their quick slots
     sh[k] = n;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
@@ -449,7 +474,7 @@ __global__ __launch_bounds__(1024) void pool_offsets_kernel(CandInfo *__restrict
         sh[k] += v;
         __syncthreads();
     }
-    if (k < num) info[(long)img * MAX_CAND + k].off = sh[k] - n;
+    if (k < num && n) info[(long)img * MAX_CAND + k].off = (int)QOFF + sh[k] - n;
     if (k == 1023 && (long)sh[1023] > d.pool_cap) atomicOr(&flags[img], 4);
 }
 
@@ -461,13 +486,13 @@ __global__ __launch_bounds__(64) void trace_write_kernel(const unsigned *__restr
     const int num = min(totals[img], MAX_CAND);
     if (k >= num || (flags[img] & 4)) return;
     const CandInfo ci = info[(long)img * MAX_CAND + k];
-    if (ci.npts <= 2) return;
+    if (ci.npts <= QCAP) return;
     const Cand c = cands[(long)img * MAX_CAND + k];
     BitWindow im; im.bits = bits + (long)img * d.H * d.WW; im.H = d.H; im.W = d.W; im.WW = d.WW;
     const int p = __builtin_amdgcn_readfirstlane(c.p), hole = __builtin_amdgcn_readfirstlane(c.is_hole);
     const int off = __builtin_amdgcn_readfirstlane(ci.off);
     const int y = p / d.W, x = p - y * d.W;
-    trace_border<true>(im, x - hole, y, hole, pool + (long)img * d.pool_cap + off, lane);
+    trace_border<true>(im, x - hole, y, hole, pool + (long)img * d.pool_stride + off, 0x7fffffc0, lane);
 }
 
 // ------------------------------------------------------------------------------------------ geometry (one lane)
@@ -909,7 +934,7 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const float *__rest
     const CandInfo ci = info[(long)img * MAX_CAND + k];
     if (flags[img] & 4) { if (tid == 0) res->status = ST_NONE; return; }
     if (ci.npts <= 2) { if (tid == 0) res->status = ST_SKIP_NPTS; return; }     // db_postprocess.cpp:255
-    const unsigned *pts = pool + (long)img * d.pool_cap + ci.off;
+    const unsigned *pts = pool + (long)img * d.pool_stride + ci.off;
     const int n = ci.npts;
     const int xmin = ci.xmin, xmax = ci.xmax, ymin = ci.ymin, ymax = ci.ymax;
     const int bw = xmax - xmin + 1, bh = ymax - ymin + 1;
@@ -1140,7 +1165,7 @@ using namespace ptocr;
 
 struct ptocr_dbpost {
     int max_n, max_h, max_w;
-    unsigned *bits; unsigned *bits2; int *labels; int *chunk_cnt; int *totals; Cand *cands; CandInfo *info; unsigned *pool;
+    unsigned *bits; unsigned *bits2; int *labels; int *chunk_cnt; int *totals; int *strip_totals; Cand *cands; CandInfo *info; unsigned *pool;
     unsigned *gslots; int *slot_locks; long slot_words; Result *results; int *flags; int *src_wh; short *boxes; int *counts;
     int boxes_cap;
     long pool_cap;
@@ -1161,9 +1186,10 @@ extern "C" int ptocr_dbpost_create(ptocr_dbpost_t *out, int max_n, int max_h, in
     PT_HIP(hipMalloc(&h->labels, sizeof(int) * max_n * hw));
     PT_HIP(hipMalloc(&h->chunk_cnt, sizeof(int) * max_n * nch));
     PT_HIP(hipMalloc(&h->totals, sizeof(int) * max_n));
+    PT_HIP(hipMalloc(&h->strip_totals, sizeof(int) * max_n));
     PT_HIP(hipMalloc(&h->cands, sizeof(Cand) * max_n * MAX_CAND));
     PT_HIP(hipMalloc(&h->info, sizeof(CandInfo) * max_n * MAX_CAND));
-    PT_HIP(hipMalloc(&h->pool, sizeof(unsigned) * max_n * h->pool_cap));
+    PT_HIP(hipMalloc(&h->pool, sizeof(unsigned) * max_n * (QOFF + h->pool_cap)));
     h->slot_words = (long)max_h * ww + 64;
     PT_HIP(hipMalloc(&h->gslots, sizeof(unsigned) * NSLOTS * 2 * h->slot_words));
     PT_HIP(hipMalloc(&h->slot_locks, sizeof(int) * NSLOTS));
@@ -1179,7 +1205,7 @@ extern "C" int ptocr_dbpost_create(ptocr_dbpost_t *out, int max_n, int max_h, in
 
 extern "C" int ptocr_dbpost_destroy(ptocr_dbpost_t h) {
     if (!h) return 0;
-    void *bufs[] = {h->bits, h->bits2, h->labels, h->chunk_cnt, h->totals, h->cands, h->info, h->pool, h->gslots, h->slot_locks,
+    void *bufs[] = {h->bits, h->bits2, h->labels, h->chunk_cnt, h->totals, h->strip_totals, h->cands, h->info, h->pool, h->gslots, h->slot_locks,
                     h->results, h->flags, h->src_wh, h->boxes, h->counts};
     for (void *b : bufs) (void)hipFree(b);
     delete h;
@@ -1220,6 +1246,7 @@ extern "C" int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, co
     d.N = N; d.H = H; d.W = W; d.WW = cdiv(W, 32); d.HW = (long)H * W;
     d.nchunks = (int)((d.HW + CHUNK - 1) / CHUNK);
     d.pool_cap = h->pool_cap;
+    d.pool_stride = QOFF + h->pool_cap;
     PT_HIP(hipMemcpyAsync(h->src_wh, h_src_wh, sizeof(int) * 2 * N, hipMemcpyHostToDevice, s));
     PT_HIP(hipMemsetAsync(h->flags, 0, sizeof(int) * N, s));
     const dim3 row_grid(cdiv(W, 1024), H, N);
@@ -1230,14 +1257,21 @@ extern "C" int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, co
         hipLaunchKernelGGL(dilate2x2_kernel, dim3(cdiv(d.WW, 256), H, N), dim3(256), 0, s, h->bits, h->bits2, d);
         bits = h->bits2;
     }
-    const dim3 word_grid(cdiv(H * d.WW, 256), N);
     PT_HIP(hipMemsetAsync(h->chunk_cnt, 0, sizeof(int) * (size_t)N * d.nchunks, s));
-    hipLaunchKernelGGL(ccl_init_kernel, word_grid, dim3(256), 0, s, bits, h->labels, d);
-    hipLaunchKernelGGL(ccl_merge_kernel, word_grid, dim3(256), 0, s, bits, h->labels, d);
-    hipLaunchKernelGGL(ccl_flatten_kernel, word_grid, dim3(256), 0, s, bits, h->labels, h->chunk_cnt, d);
-    hipLaunchKernelGGL(chunk_suffix_kernel, dim3(N), dim3(1024), 0, s, h->chunk_cnt, h->totals, d);
+    const int strip_y = H > 2 * STRIP_ROWS ? H - STRIP_ROWS : 0;      // small maps: one pass over everything
+    for (int pass = strip_y ? 0 : 1; pass < 2; pass++) {
+        CclPass ps;
+        ps.y_first = pass == 0 ? strip_y : 0;
+        ps.skip_if_full = (pass == 1 && strip_y) ? h->strip_totals : nullptr;
+        const int words = (H - ps.y_first) * d.WW;
+        const dim3 word_grid(cdiv(words > d.nchunks ? words : d.nchunks, 256), N);
+        hipLaunchKernelGGL(ccl_init_kernel, word_grid, dim3(256), 0, s, bits, h->labels, h->chunk_cnt, d, ps);
+        hipLaunchKernelGGL(ccl_merge_kernel, word_grid, dim3(256), 0, s, bits, h->labels, d, ps);
+        hipLaunchKernelGGL(ccl_flatten_kernel, word_grid, dim3(256), 0, s, bits, h->labels, h->chunk_cnt, d, ps);
+        hipLaunchKernelGGL(chunk_suffix_kernel, dim3(N), dim3(1024), 0, s, h->chunk_cnt, h->totals, d, ps, h->strip_totals);
+    }
     hipLaunchKernelGGL(gather_starts_kernel, dim3(d.nchunks, N), dim3(256), 0, s, bits, h->labels, h->chunk_cnt, h->cands, d);
-    hipLaunchKernelGGL(trace_count_kernel, dim3(MAX_CAND, N), dim3(64), 0, s, bits, h->cands, h->totals, h->info, d);
+    hipLaunchKernelGGL(trace_count_kernel, dim3(MAX_CAND, N), dim3(64), 0, s, bits, h->cands, h->totals, h->info, h->pool, d);
     hipLaunchKernelGGL(pool_offsets_kernel, dim3(N), dim3(1024), 0, s, h->info, h->totals, h->flags, d);
     hipLaunchKernelGGL(trace_write_kernel, dim3(MAX_CAND, N), dim3(64), 0, s, bits, h->cands, h->totals, h->info,
                        h->pool, h->flags, d);

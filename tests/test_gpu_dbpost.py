@@ -52,7 +52,8 @@ def _compare(maps, src_wh, thresh=0.3, box_thresh=0.5, ratio=1.7, strict=True):
         exp, dbg, ncont = dbpost.boxes_from_bitmap(maps[i], bm, box_thresh, ratio, src_wh[i][0], src_wh[i][1], True)
         tot, res, cands, info = _debug(i, W)
         msg = ""
-        if tot != ncont:
+        # the GPU stops counting once the bottom strip alone holds the 1000 borders the reference keeps
+        if (tot != ncont) if ncont < 1000 else (tot < 1000 or tot > ncont):
             msg = "image %d: %d borders on the GPU, %d in the oracle" % (i, tot, ncont)
         else:
             for k in range(min(tot, 1000)):
