@@ -71,6 +71,11 @@ int ptocr_conv2d_f32(const ptocr_conv_desc *d, const float *d_x, const float *d_
 int ptocr_conv3x3_wino_f32(const float *d_x, const float *d_u, const float *d_bias, const float *d_res, float *d_y,
                            int N, int H, int W, int Cin, int Cout, int relu, int res_mode, int res_ldc, int out_ldc,
                            int out_coff, int up, void *stream);
+/* ResNet stem: conv 7x7 / stride 2 / pad 3 of an RGB image stored as f32[N,H,W,4] (4th channel ignored) -> f32[N,Ho,Wo,64],
+ * Ho = (H-1)/2+1, Wo = (W-1)/2+1, + bias (folded BN) + optional ReLU (det_resnet.py:193-196).  d_w: f32[7][22][64],
+ * w[ky][kx*3 + c][cout], row [ky][21] all zero (K runs over 7 x 22 = 154 instead of the generic kernel's 7*7*4 = 196). */
+int ptocr_conv7x7s2_stem_f32(const float *d_x, const float *d_w, const float *d_bias, float *d_y, int N, int H, int W,
+                             int relu, void *stream);
 /* Measurement hook (no reference counterpart): d_buf = device u64[4 * workgroups] receives s_memtime samples (start, main
  * loop start, main loop end, end) from every Winograd workgroup launched afterwards; NULL switches the probe off. */
 void ptocr_wino_set_timing_buffer(void *d_buf);

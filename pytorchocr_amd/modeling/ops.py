@@ -15,6 +15,8 @@ PROFILE_LABELS = None                          # optional list: one text label p
 # 3x3 / stride 1 layers run as Winograd F(2x2,3x3) unless PTOCR_WINOGRAD=0 (then the direct implicit GEMM runs them)
 import os as _os
 USE_WINOGRAD = _os.environ.get("PTOCR_WINOGRAD", "1") != "0"
+# the 7x7 / stride 2 RGB stem runs in its own kernel unless PTOCR_STEM_KERNEL=0 (then the generic implicit GEMM runs it)
+USE_STEM_KERNEL = _os.environ.get("PTOCR_STEM_KERNEL", "1") != "0"
 
 
 def _require_cuda(t, what):
@@ -78,6 +80,14 @@ class PackedConv:
         self.pad_h, self.pad_w = conv.padding
         self.relu = _act_code(relu)
         self.convt = False
+        # ResNet stem (7x7 / s2 / p3, RGB -> 64): K axis without the padding channel, w[ky][kx*3 + c][cout], one zero row per ky
+        self.stem_w = None
+        if (kh, kw) == (7, 7) and self.stride == 2 and (self.pad_h, self.pad_w) == (3, 3) and cin == 3 and cout == 64 \
+                and cin_pad == 4 and self.relu in (ACT_NONE, ACT_RELU):
+            sw = torch.zeros(7, 22, 64, dtype=torch.float64)
+            sw[:, :21, :] = w.permute(2, 3, 1, 0).reshape(7, 21, 64)              # [ky][kx][c][cout] -> [ky][kx*3 + c][cout]
+            self.stem_w = sw.float().contiguous().to(device)
+            self.stem_b = b.float().contiguous().to(device)
         # Winograd F(2x2,3x3) form of the same weights for 3x3 / s1 / p1 layers: U = G g G^T, packed [Cout/64][Cin/4][16][64][4]
         self.wino_u = None
         if (kh, kw) == (3, 3) and self.stride == 1 and (self.pad_h, self.pad_w) == (1, 1) and cin % 16 == 0 and cout % 64 == 0 \
@@ -125,6 +135,19 @@ def conv2d(x, pc, res=None, res_mode=RES_NONE, out=None, out_up=1, out_coff=0, s
     scale = 2 if pc.convt else out_up
     if out is None:
         out = torch.empty((N, Ho * scale, Wo * scale, pc.c_tensor), dtype=torch.float32, device=x.device)
+    if USE_STEM_KERNEL and getattr(pc, "stem_w", None) is not None and res is None and out_up == 1 and out_coff == 0 \
+            and out.shape[3] == 64 and (store is None or store == 64) and N * H * W * 16 < 2 ** 31:
+        if PROFILE is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _lib.check(_lib.lib().ptocr_conv7x7s2_stem_f32(_lib.ptr(x), _lib.ptr(pc.stem_w), _lib.ptr(pc.stem_b), _lib.ptr(out),
+                                                       N, H, W, int(pc.relu), _lib.cur_stream()), "ptocr_conv7x7s2_stem_f32")
+        if PROFILE is not None:
+            e1.record()
+            PROFILE.append((e0, e1))
+            if PROFILE_LABELS is not None:
+                PROFILE_LABELS.append("stem7x7 %dx%dx%dx3->64" % (N, H, W))
+        return out
     if USE_WINOGRAD and getattr(pc, "wino_u", None) is not None and (res_mode == RES_NONE or (res_mode == RES_ADD_PRE_RELU and out_up == 1)) \
             and out_up <= 8 and (store is None or store == pc.cout_real) and N * H * W * Cin * 4 < 2 ** 31:
         if PROFILE is not None:

@@ -58,23 +58,38 @@ def test_conv_bn_relu_matches_torch(case):
     assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
 
 
-def test_stem_7x7_cin3():
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 70, 130), (3, 33, 47), (2, 160, 608)])
+def test_stem_7x7_cin3(shape):
+    """the stem kernel (K without the padding channel, persistent tiles) and, via PTOCR_STEM_KERNEL semantics, the generic
+    kernel: both against torch fp32; odd sizes exercise partial tiles and the zero border"""
     from pytorchocr_amd.modeling import ops
     dev = _dev()
+    N, H, W = shape
     conv = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
     bn = nn.BatchNorm2d(64).eval()
     with torch.no_grad():
         conv.weight.copy_(_rand(64, 3, 7, 7, seed=1) * 0.15)
         bn.running_mean.copy_(_rand(64, seed=5) * 0.2); bn.running_var.copy_(_rand(64, seed=6) * 0.5 + 1)
-    x = _rand(2, 3, 64, 96, seed=7)
+    x = _rand(N, 3, H, W, seed=7)
     with torch.no_grad():
         ref = F.relu(bn(conv(x)))
     pc = ops.PackedConv(conv, bn, dev, relu=True, cin_pad=4)
+    assert pc.stem_w is not None
     x4 = ops.nchw_to_nhwc(x.to(dev), 4)
     assert torch.equal(x4.cpu()[..., :3], _nhwc(x)) and float(x4[..., 3].abs().max()) == 0.0
-    y = ops.conv2d(x4, pc)
-    got = y.cpu().permute(0, 3, 1, 2)
-    assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    x4[..., 3] = 7.0                                     # the stem kernel must ignore the padding channel
+    tol = 2e-5 * max(1.0, ref.abs().max().item())
+    for use in (True, False):
+        ops.USE_STEM_KERNEL = use
+        try:
+            if not use:
+                x4[..., 3] = 0.0                             # the generic kernel multiplies it by zero weights
+            y = ops.conv2d(x4, pc)
+        finally:
+            ops.USE_STEM_KERNEL = True
+        got = y.cpu().permute(0, 3, 1, 2)
+        assert got.shape == ref.shape
+        assert (got - ref).abs().max().item() <= tol, use
 
 
 def test_residual_and_upsample_epilogues():
