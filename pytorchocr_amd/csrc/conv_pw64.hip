@@ -1,0 +1,178 @@
+// Pointwise (1x1) convolution with Cin = 64 and Cout a multiple of 32, up to 256 (+ folded BN, ReLU, optional FPN top-down
+// add) on fp32 MFMA.  The layer it exists for is the FPN lateral `in2` (fpn.py:46-51,112,117): 64 -> 256 channels on the
+// 1/4-resolution map -- 61.7 GFLOP per batch of 32 but 1.93 GB of output, i.e. bound by the HBM write, not by the MFMA.  The
+// generic implicit GEMM (conv_mfma.hip) spends 1.56 ms on it (one short K loop per workgroup: all prologue and epilogue);
+// here a persistent workgroup (256 threads, 1 per CU) keeps the whole weight matrix W[64][Cout] in LDS, streams 128-pixel
+// tiles through a double-buffered LDS tile (loads of tile i+1 in flight while tile i computes) and stores 16 bytes per lane
+// straight from the accumulators.
+// MFMA roles: A = weights (rows = 32 output channels), B = pixels (columns = 32 pixels): a lane ends up with 4 consecutive
+// output channels of ONE pixel per accumulator quad.  Wave w owns pixels [32w, 32w+32) of the tile and all Cout/32 channel
+// blocks (up to 8 MFMA tiles = 128 accumulator registers), 32 k-steps of v_mfma_f32_32x32x2_f32.
+#include "common.h"
+
+namespace ptocr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PW_K = 64;                        // input channels
+constexpr int PW_TM = 128;                      // pixels per tile
+constexpr int PW_RS = PW_K + 4;                 // LDS row stride of the pixel tile (16-byte aligned rows)
+constexpr int PW_MAXC = 256;
+
+struct Pw64Args {
+    const float *x, *w, *bias, *res;
+    float *y;
+    long M;                                     // pixels N*H*W
+    int H, W, Cout, relu, res_up2, out_ldc, out_coff, ntiles;
+    long x_bytes;
+};
+
+template <int NMT>                              // Cout / 32
+__global__ __launch_bounds__(256, 1) void conv_pw64_kernel(Pw64Args p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Wl = smem;                           // [64][Cout]
+    float *Xb = smem + PW_K * NMT * 32;         // [2][PW_TM][PW_RS]
+    float *Bl = Xb + 2 * PW_TM * PW_RS;         // [Cout] bias
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    constexpr int COUT = NMT * 32;
+
+    for (int i = tid; i < PW_K * COUT / 4; i += 256) reinterpret_cast<f32x4 *>(Wl)[i] = reinterpret_cast<const f32x4 *>(p.w)[i];
+    if (tid < COUT) Bl[tid] = p.bias[tid];
+
+    // tile loader: 128 pixels x 16 float4 = 2048 pieces, 8 per thread; piece f = tid + 256 r -> pixel f >> 4, quad f & 15
+    f32x4 xreg[8];
+    auto gload = [&](int tile) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int f = tid + 256 * r;
+            const long m = (long)tile * PW_TM + (f >> 4);                 // beyond M: out of range -> zeros
+            xreg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (unsigned)(m * (PW_K * 4) + (f & 15) * 16), 0, 0));
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int f = tid + 256 * r;
+            *reinterpret_cast<f32x4 *>(Xb + buf * PW_TM * PW_RS + (f >> 4) * PW_RS + (f & 15) * 4) = xreg[r];
+        }
+    };
+
+    const int c = lane & 31, kh = lane >> 5;
+    const float *wp = Wl + kh * COUT + c;                        // W[2s + kh][32 mt + c]
+    const int xoff = (32 * wave + c) * PW_RS + kh;               // X[32w + c][2s + kh]
+
+    int tile = blockIdx.x;                                       // host launches gridDim.x <= ntiles
+    gload(tile);
+    lstore(0);
+    __syncthreads();
+    for (int it = 0;; it++) {
+        const int buf = it & 1;
+        const int next = tile + (int)gridDim.x;
+        const bool has_next = next < p.ntiles;
+        if (has_next) gload(next);                               // in flight during this tile's MFMAs
+
+        // the FPN top-down rows of this tile are requested before the MFMA loop, so that their latency hides behind it
+        // (issued one by one in the epilogue they cost 17 us per tile, twice the MFMA time)
+        const long m = (long)tile * PW_TM + 32 * wave + c;
+        const bool live = m < p.M;
+        f32x4 rres[NMT][4];
+        if (p.res_up2) {                                         // + nearest-upsampled coarser map, after the ReLU
+            const long mm = live ? m : 0;
+            const int hw = p.H * p.W;
+            const int n = (int)(mm / hw), rem = (int)(mm - (long)n * hw);
+            const int oy = rem / p.W, ox = rem - oy * p.W;
+            const float *rp = p.res + (((long)n * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) * COUT + 4 * kh;
+#pragma unroll
+            for (int mt = 0; mt < NMT; mt++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) rres[mt][g] = *reinterpret_cast<const f32x4 *>(rp + 32 * mt + 8 * g);
+        }
+        f32x16 acc[NMT];
+#pragma unroll
+        for (int a = 0; a < NMT; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][r] = 0.f;
+        const float *xp = Xb + buf * PW_TM * PW_RS + xoff;
+#pragma unroll 4
+        for (int s = 0; s < PW_K / 2; s++) {
+            const float b = xp[2 * s];
+#pragma unroll
+            for (int mt = 0; mt < NMT; mt++)
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp[(2 * s) * COUT + 32 * mt], b, acc[mt], 0, 0, 0);
+        }
+
+        // epilogue: lane holds, for pixel m, output channels 32 mt + 8 g + 4 kh + {0..3}
+        if (live) {
+            float *yp = p.y + m * p.out_ldc + p.out_coff;
+#pragma unroll
+            for (int mt = 0; mt < NMT; mt++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int co = 32 * mt + 8 * g + 4 * kh;
+                    f32x4 v = f32x4{acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]} +
+                              *reinterpret_cast<const f32x4 *>(Bl + co);
+                    if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                    if (p.res_up2) v += rres[mt][g];
+                    *reinterpret_cast<f32x4 *>(yp + co) = v;
+                }
+        }
+        if (!has_next) break;
+        lstore(buf ^ 1);                                         // every wave finished reading buf^1 before the previous barrier
+        __syncthreads();
+        tile = next;
+    }
+}
+
+template <int NMT>
+static int launch_pw64(const Pw64Args &a, hipStream_t stream) {
+    const size_t lds = sizeof(float) * (PW_K * NMT * 32 + 2 * PW_TM * PW_RS + NMT * 32);
+    static bool attr_set = false;
+    if (!attr_set) {
+        PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pw64_kernel<NMT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        PT_HIP(hipGetDevice(&dev));
+        PT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const int grid = a.ntiles < n_cu ? a.ntiles : n_cu;          // one persistent workgroup per CU
+    hipLaunchKernelGGL((conv_pw64_kernel<NMT>), dim3((unsigned)grid), dim3(256), lds, stream, a);
+    return launch_ok("conv_pw64_kernel");
+}
+
+}  // namespace ptocr
+
+using namespace ptocr;
+
+// d_x: f32[N,H,W,64]; d_w: f32[64][Cout] (k-major, BN folded); d_res (res_up2 = 1): f32[N,H/2,W/2,Cout], added AFTER the
+// activation (fpn.py:133-134), H and W even; d_y: f32[N,H,W,out_ldc], channels [out_coff, out_coff + Cout).
+extern "C" int ptocr_conv1x1_k64_f32(const float *d_x, const float *d_w, const float *d_bias, const float *d_res, float *d_y,
+                                     int N, int H, int W, int Cout, int relu, int res_up2, int out_ldc, int out_coff, void *stream) {
+    PT_CHECK(d_x && d_w && d_bias && d_y, "ptocr_conv1x1_k64_f32: null argument");
+    PT_CHECK(N > 0 && H > 0 && W > 0, "ptocr_conv1x1_k64_f32: empty tensor");
+    PT_CHECK(Cout % 32 == 0 && Cout >= 32 && Cout <= PW_MAXC, "ptocr_conv1x1_k64_f32: Cout must be a multiple of 32 up to %d", PW_MAXC);
+    PT_CHECK(relu == 0 || relu == 1, "ptocr_conv1x1_k64_f32: activation must be none or ReLU");
+    PT_CHECK(!res_up2 || (d_res && H % 2 == 0 && W % 2 == 0), "ptocr_conv1x1_k64_f32: the upsample-add needs d_res and even H, W");
+    PT_CHECK(out_ldc % 4 == 0 && out_coff % 4 == 0 && out_ldc >= out_coff + Cout, "ptocr_conv1x1_k64_f32: channel strides must be multiples of 4");
+    Pw64Args a;
+    a.x = d_x; a.w = d_w; a.bias = d_bias; a.res = d_res; a.y = d_y;
+    a.M = (long)N * H * W; a.H = H; a.W = W; a.Cout = Cout; a.relu = relu; a.res_up2 = res_up2; a.out_ldc = out_ldc; a.out_coff = out_coff;
+    a.x_bytes = a.M * PW_K * 4;
+    PT_CHECK(a.x_bytes < (1L << 31), "ptocr_conv1x1_k64_f32: tensor larger than 2 GiB");
+    a.ntiles = (int)((a.M + PW_TM - 1) / PW_TM);
+    switch (Cout / 32) {
+        case 1: return launch_pw64<1>(a, (hipStream_t)stream);
+        case 2: return launch_pw64<2>(a, (hipStream_t)stream);
+        case 3: return launch_pw64<3>(a, (hipStream_t)stream);
+        case 4: return launch_pw64<4>(a, (hipStream_t)stream);
+        case 5: return launch_pw64<5>(a, (hipStream_t)stream);
+        case 6: return launch_pw64<6>(a, (hipStream_t)stream);
+        case 7: return launch_pw64<7>(a, (hipStream_t)stream);
+        default: return launch_pw64<8>(a, (hipStream_t)stream);
+    }
+}

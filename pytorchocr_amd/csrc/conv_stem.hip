@@ -83,6 +83,12 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(StemArgs p) {
     const int wb = kh * 64 + c;                                  // weights: W[2s + kh][32 mt + c]
     const int xb = (4 * wave) * ST_RS + 6 * c + kh;              // pixels: patch[2 (2w + nt) + ky][6c + 2s' + kh]
 
+    f32x4 bias4[2][4];                                           // this lane's 8 channel quads (loaded once: no load latency per tile)
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) bias4[mt][g] = *reinterpret_cast<const f32x4 *>(p.bias + 32 * mt + 8 * g + 4 * kh);
+
     int tile = blockIdx.x;                                       // host launches gridDim.x <= total
     decode(tile);
     gload();
@@ -130,8 +136,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(StemArgs p) {
 #pragma unroll
                     for (int g = 0; g < 4; g++) {
                         const int co = 32 * mt + 8 * g + 4 * kh;
-                        f32x4 v = f32x4{acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]} +
-                                  *reinterpret_cast<const f32x4 *>(p.bias + co);
+                        f32x4 v = f32x4{acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]} + bias4[mt][g];
                         if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
                         *reinterpret_cast<f32x4 *>(yp + co) = v;
                     }

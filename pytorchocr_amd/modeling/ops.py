@@ -17,6 +17,8 @@ import os as _os
 USE_WINOGRAD = _os.environ.get("PTOCR_WINOGRAD", "1") != "0"
 # the 7x7 / stride 2 RGB stem runs in its own kernel unless PTOCR_STEM_KERNEL=0 (then the generic implicit GEMM runs it)
 USE_STEM_KERNEL = _os.environ.get("PTOCR_STEM_KERNEL", "1") != "0"
+# 1x1 convolutions with 64 input channels run in the LDS-resident-weights kernel unless PTOCR_PW64_KERNEL=0
+USE_PW64_KERNEL = _os.environ.get("PTOCR_PW64_KERNEL", "1") != "0"
 
 
 def _require_cuda(t, what):
@@ -80,6 +82,12 @@ class PackedConv:
         self.pad_h, self.pad_w = conv.padding
         self.relu = _act_code(relu)
         self.convt = False
+        # pointwise layers with 64 input channels (the FPN lateral in2): W[k][cout], k-major, for the LDS-resident-weights kernel
+        self.pw_w = None
+        if (kh, kw) == (1, 1) and self.stride == 1 and (self.pad_h, self.pad_w) == (0, 0) and cin == 64 and cout % 32 == 0 \
+                and cout <= 256 and self.relu in (ACT_NONE, ACT_RELU):
+            self.pw_w = w.reshape(cout, cin).t().contiguous().float().to(device)
+            self.pw_b = b.float().contiguous().to(device)
         # ResNet stem (7x7 / s2 / p3, RGB -> 64): K axis without the padding channel, w[ky][kx*3 + c][cout], one zero row per ky
         self.stem_w = None
         if (kh, kw) == (7, 7) and self.stride == 2 and (self.pad_h, self.pad_w) == (3, 3) and cin == 3 and cout == 64 \
@@ -147,6 +155,22 @@ def conv2d(x, pc, res=None, res_mode=RES_NONE, out=None, out_up=1, out_coff=0, s
             PROFILE.append((e0, e1))
             if PROFILE_LABELS is not None:
                 PROFILE_LABELS.append("stem7x7 %dx%dx%dx3->64" % (N, H, W))
+        return out
+    if USE_PW64_KERNEL and getattr(pc, "pw_w", None) is not None and out_up == 1 and res_mode in (RES_NONE, RES_ADD_UP2_POST_RELU) \
+            and (store is None or store == pc.cout_real) and N * H * W * 256 < 2 ** 31 \
+            and (res_mode == RES_NONE or (H % 2 == 0 and W % 2 == 0 and res.shape[3] == pc.cout_real)):
+        if PROFILE is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _lib.check(_lib.lib().ptocr_conv1x1_k64_f32(_lib.ptr(x), _lib.ptr(pc.pw_w), _lib.ptr(pc.pw_b),
+                                                    _lib.ptr(res) if res is not None else C.c_void_p(0), _lib.ptr(out),
+                                                    N, H, W, pc.cout_real, int(pc.relu), int(res_mode == RES_ADD_UP2_POST_RELU),
+                                                    out.shape[3], out_coff, _lib.cur_stream()), "ptocr_conv1x1_k64_f32")
+        if PROFILE is not None:
+            e1.record()
+            PROFILE.append((e0, e1))
+            if PROFILE_LABELS is not None:
+                PROFILE_LABELS.append("pw1x1 %dx%dx%dx64->%d" % (N, H, W, pc.cout_real))
         return out
     if USE_WINOGRAD and getattr(pc, "wino_u", None) is not None and (res_mode == RES_NONE or (res_mode == RES_ADD_PRE_RELU and out_up == 1)) \
             and out_up <= 8 and (store is None or store == pc.cout_real) and N * H * W * Cin * 4 < 2 ** 31:

@@ -267,3 +267,42 @@ def test_winograd_3x3_matches_torch(case):
     ref_up = F.interpolate(ref, scale_factor=up, mode="nearest")
     assert (big[..., 64:].permute(0, 3, 1, 2) - ref_up).abs().max().item() <= tol
     assert float((big[..., :64] - 3).abs().max()) == 0
+
+
+@pytest.mark.parametrize("case", [(2, 20, 36, 256), (1, 7, 9, 96), (3, 46, 80, 32), (1, 184, 320, 256)])
+def test_pointwise_k64_kernel(case):
+    """1x1 / Cin=64 kernel (FPN lateral in2): plain, with the nearest-x2 top-down add after the ReLU, into a concat slice;
+    pixel counts that are not multiples of the 128-pixel tile; and the generic kernel on the same layer"""
+    from pytorchocr_amd.modeling import ops
+    N, H, W, Cout = case
+    dev = _dev()
+    conv = nn.Conv2d(64, Cout, 1, 1, 0, bias=False)
+    bn = nn.BatchNorm2d(Cout).eval()
+    with torch.no_grad():
+        conv.weight.copy_(_rand(Cout, 64, 1, 1, seed=1) * 0.2)
+        bn.weight.copy_(_rand(Cout, seed=3) * 0.4 + 1); bn.bias.copy_(_rand(Cout, seed=4) * 0.2)
+        bn.running_mean.copy_(_rand(Cout, seed=5) * 0.2); bn.running_var.copy_(_rand(Cout, seed=6) * 0.5 + 1)
+    x = _rand(N, 64, H, W, seed=7)
+    with torch.no_grad():
+        ref = F.relu(bn(conv(x)))
+    pc = ops.PackedConv(conv, bn, dev, relu=True)
+    assert pc.pw_w is not None
+    xd = _nhwc(x).to(dev)
+    tol = 2e-5 * max(1.0, ref.abs().max().item())
+    for use in (True, False):
+        ops.USE_PW64_KERNEL = use
+        try:
+            y = ops.conv2d(xd, pc).cpu().permute(0, 3, 1, 2)
+            assert (y - ref).abs().max().item() <= tol, use
+            if H % 2 == 0 and W % 2 == 0:
+                coarse = _rand(N, Cout, H // 2, W // 2, seed=9)
+                ref_up = ref + F.interpolate(coarse, scale_factor=2, mode="nearest")
+                y = ops.conv2d(xd, pc, res=_nhwc(coarse).to(dev), res_mode=ops.RES_ADD_UP2_POST_RELU).cpu().permute(0, 3, 1, 2)
+                assert (y - ref_up).abs().max().item() <= tol, use
+        finally:
+            ops.USE_PW64_KERNEL = True
+    big = torch.full((N, H, W, Cout + 96), 3.0, device=dev)
+    ops.conv2d(xd, pc, out=big, out_coff=32, store=Cout)
+    big = big.cpu()
+    assert (big[..., 32:32 + Cout].permute(0, 3, 1, 2) - ref).abs().max().item() <= tol
+    assert float((big[..., :32] - 3).abs().max()) == 0 and float((big[..., 32 + Cout:] - 3).abs().max()) == 0
