@@ -112,10 +112,17 @@ __device__ __forceinline__ int run_start(const unsigned *rowbits, int x) {
     return wi * 32 + (31 - __clz(m)) + 1;
 }
 
+// root of v (FRAME = -1 when the tree hangs off the frame root), with path halving: a node is re-pointed at its grandparent,
+// which is still an ancestor, so concurrent finds and unions stay correct; it keeps the chains short on speckle maps where
+// one giant component collects tens of thousands of runs
 __device__ __forceinline__ int uf_find(int *lab, int v) {
     while (v >= 0) {
         const int p = lab[v];
         if (p == v) break;
+        if (p >= 0) {
+            const int gp = lab[p];
+            if (gp != p) lab[v] = gp;
+        }
         v = p;
     }
     return v;
@@ -938,6 +945,10 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const float *__rest
     const int n = ci.npts;
     const int xmin = ci.xmin, xmax = ci.xmax, ymin = ci.ymin, ymax = ci.ymax;
     const int bw = xmax - xmin + 1, bh = ymax - ymin + 1;
+    // Speckle: both sides of a min-area rectangle are projections of the point set, so neither exceeds its diameter, which is
+    // at most the diagonal of the bounding box; a diagonal <= sqrt(8) means ssid < 3 (db_postprocess.cpp:265) without
+    // computing the rectangle.  Noise maps are made of thousands of such borders.
+    if ((bw - 1) * (bw - 1) + (bh - 1) * (bh - 1) <= 8) { if (tid == 0) res->status = ST_SKIP_SSID; return; }
 
     // LDS arena: column tables (hull phase) and mask planes (score phase) are never live together
     __shared__ __attribute__((aligned(16))) unsigned arena[2 * LDS_PLANE_WORDS];
