@@ -16,16 +16,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int HT_C = 64;                 // channels in and mid
 constexpr int HT_LD = HT_C + 4;          // LDS row stride (floats)
 constexpr int HT_PIX = 128;              // pixels per tile (4 waves x 32)
-constexpr int HT_TILES = 8;              // tiles per block (weights staged once per block)
 
 // w1: f32[256][64] (row (a*2+b)*64 + co, BN folded), b1: f32[256]; w2: f32[4][64] (a'*2+b'), b2 scalar
-__global__ __launch_bounds__(256) void db_head_tail_kernel(const float *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1,
-                                                           const float *__restrict__ w2, float b2, float *__restrict__ maps, int H, int W, long npix) {
-    __shared__ __attribute__((aligned(16))) float xs[HT_PIX * HT_LD];        // [pixel][ci]
-    __shared__ __attribute__((aligned(16))) float ws[256 * HT_LD];           // [col][ci]
-    __shared__ float w2s[4 * HT_C], b1s[256];
+// Persistent workgroups (one per CU): the 256 x 64 weights are staged in LDS once, the 128-pixel input tiles are double-
+// buffered in LDS and tile i+1 is fetched into registers while tile i computes (a synchronous load per tile cost 25 %).
+__global__ __launch_bounds__(256, 1) void db_head_tail_kernel(const float *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1,
+                                                              const float *__restrict__ w2, float b2, float *__restrict__ maps, int H, int W, long npix,
+                                                              int ntiles, long x_bytes) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *ws = smem;                                        // [256 col][HT_LD]
+    float *xsb = ws + 256 * HT_LD;                           // [2][HT_PIX pixel][HT_LD]
+    float *w2s = xsb + 2 * HT_PIX * HT_LD;                   // [4][64]
+    float *b1s = w2s + 4 * HT_C;                             // [256]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // the 256 x 64 weights are staged once per block; the block then walks HT_TILES consecutive 128-pixel tiles
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, (int)x_bytes, 0x00020000);
     for (int i = tid; i < 256 * 16; i += 256) {
         const int r = i >> 4, c4 = i & 15;
         *reinterpret_cast<f32x4 *>(&ws[r * HT_LD + c4 * 4]) = *reinterpret_cast<const f32x4 *>(w1 + (long)r * HT_C + c4 * 4);
@@ -33,17 +37,33 @@ __global__ __launch_bounds__(256) void db_head_tail_kernel(const float *__restri
     w2s[tid] = w2[tid];
     b1s[tid] = b1[tid];
     const int j = lane & 31, h = lane >> 5;                  // pixel within the wave's 32, k half
-  for (int tile = 0; tile < HT_TILES; tile++) {
-    const long p0 = ((long)blockIdx.x * HT_TILES + tile) * HT_PIX;
-    if (p0 >= npix) break;
-    __syncthreads();                                         // previous tile's reads of xs are done
-    for (int i = tid; i < HT_PIX * 16; i += 256) {
-        const int r = i >> 4, c4 = i & 15;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (p0 + r < npix) v = *reinterpret_cast<const f32x4 *>(x + (p0 + r) * HT_C + c4 * 4);
-        *reinterpret_cast<f32x4 *>(&xs[r * HT_LD + c4 * 4]) = v;
-    }
+    f32x4 xreg[8];
+    auto gload = [&](int tile) {                             // beyond npix: out of range -> zeros
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int f = tid + 256 * r;
+            const long m = (long)tile * HT_PIX + (f >> 4);
+            xreg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (unsigned)(m * (HT_C * 4) + (f & 15) * 16), 0, 0));
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int f = tid + 256 * r;
+            *reinterpret_cast<f32x4 *>(xsb + buf * HT_PIX * HT_LD + (f >> 4) * HT_LD + (f & 15) * 4) = xreg[r];
+        }
+    };
+    int tile = blockIdx.x;                                   // host launches gridDim.x <= ntiles
+    gload(tile);
+    lstore(0);
     __syncthreads();
+  for (int it = 0;; it++) {
+    const int buf = it & 1;
+    const int next = tile + (int)gridDim.x;
+    const bool has_next = next < ntiles;
+    if (has_next) gload(next);                               // in flight during this tile's MFMAs
+    const long p0 = (long)tile * HT_PIX;
+    const float *xs = xsb + buf * HT_PIX * HT_LD;
 
     const float *bx = xs + (wave * 32 + j) * HT_LD + 4 * h;  // B operand: pixel j, k = 8kk + 4h + t
     float outv[4][4];                                        // [ab][a'b'] partial sums of this lane
@@ -104,6 +124,10 @@ __global__ __launch_bounds__(256) void db_head_tail_kernel(const float *__restri
                 *reinterpret_cast<f32x4 *>(o + (long)(2 * a + ap) * (4 * W)) = row;
             }
     }
+    if (!has_next) break;
+    lstore(buf ^ 1);                                         // every wave finished reading buf^1 before the previous barrier
+    __syncthreads();
+    tile = next;
   }
 }
 
@@ -116,7 +140,23 @@ extern "C" int ptocr_db_head_tail_f32(const float *d_x, const float *d_w1, const
     PT_CHECK(d_x && d_w1 && d_b1 && d_w2 && d_maps && N >= 1, "ptocr_db_head_tail_f32: bad arguments");
     PT_CHECK(C == HT_C, "ptocr_db_head_tail_f32: the fused tail is specialised for 64 channels (got %d)", C);
     const long npix = (long)N * H * W;
-    hipLaunchKernelGGL(db_head_tail_kernel, dim3((unsigned)((npix + (long)HT_PIX * HT_TILES - 1) / ((long)HT_PIX * HT_TILES))), dim3(256), 0, (hipStream_t)stream, d_x, d_w1, d_b1,
-                       d_w2, b2, d_maps, H, W, npix);
+    const long x_bytes = npix * HT_C * 4;
+    PT_CHECK(x_bytes < (1L << 31), "ptocr_db_head_tail_f32: tensor larger than 2 GiB");
+    const int ntiles = (int)((npix + HT_PIX - 1) / HT_PIX);
+    const size_t lds = sizeof(float) * (256 * HT_LD + 2 * HT_PIX * HT_LD + 4 * HT_C + 256);
+    static bool attr_set = false;
+    if (!attr_set) {
+        PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(db_head_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        PT_HIP(hipGetDevice(&dev));
+        PT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const int grid = ntiles < n_cu ? ntiles : n_cu;
+    hipLaunchKernelGGL(db_head_tail_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, d_x, d_w1, d_b1, d_w2, b2, d_maps, H, W,
+                       npix, ntiles, x_bytes);
     return launch_ok("db_head_tail_kernel");
 }
