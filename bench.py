@@ -205,7 +205,7 @@ def run_det(args, rank, local, world, device):
                      "executed_tflops": round(achieved / 2.25, 2), "executed_frac": round(achieved / 2.25 / PEAK_F32_MFMA_TFLOPS, 4),
                      "all_conv": {"launches_per_step": n_launch // max(args.steps, 1), "ms_per_step": round(conv_ms / max(args.steps, 1), 3),
                                   "algorithmic_tflops": round(conv_all, 2),
-                                  "kernels": "conv_wino_kernel (3x3 s1) + conv_mfma_v2_kernel (7x7 stem, 3x3 s2, 1x1)"}},
+                                  "kernels": "conv_wino_kernel (3x3 s1) + stem_conv_kernel (7x7 s2) + conv_pw64_kernel (FPN in2) + conv_mfma_v2_kernel (3x3 s2, other 1x1)"}},
         "cpu_baseline": cpu,
     }
     return line
