@@ -26,7 +26,7 @@ constexpr int HLD = LH + 4;         // LDS row stride of h (floats): conflict-fr
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
 __global__ __launch_bounds__(256) void lstm_bidir_kernel(const float *__restrict__ xproj, const float *__restrict__ whh,
-                                                         float *__restrict__ out, int T, int B) {
+                                                         float *__restrict__ out, int T, int B, long x_bytes) {
     __shared__ __attribute__((aligned(16))) float hbuf[2][LROWS][HLD];
     const int dir = blockIdx.y;
     const int b0 = blockIdx.x * LROWS;
@@ -42,13 +42,37 @@ __global__ __launch_bounds__(256) void lstm_bidir_kernel(const float *__restrict
         for (int r = 0; r < 4; r++) c[q][r] = 0.f;
     __syncthreads();
 
-    // weight row pointers: gate g, sub-tile q -> gate column g*256 + 64*wave + 16*q + jc, this lane reads 4 consecutive k
-    const float *wrow[4][4];
+    // Buffer addressing keeps the address registers few: one lane offset per operand, the (gate, sub-tile) part in the
+    // scalar offset, the k-block in the instruction's immediate.
+    // weights: gate g, sub-tile q -> gate column g*256 + 64*wave + 16*q + jc, this lane reads 4 consecutive k
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(W), 0, 4 * LH * LH * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xproj), 0, (int)x_bytes, 0x00020000);
+    const unsigned w_voff = (unsigned)(((64 * wave + jc) * LH + 4 * kq) * 4);
+    auto load_w = [&](f32x4 (&w)[4][4], int kb) {
 #pragma unroll
-    for (int g = 0; g < 4; g++)
+        for (int g = 0; g < 4; g++)
 #pragma unroll
-        for (int q = 0; q < 4; q++) wrow[g][q] = W + (long)(g * LH + 64 * wave + 16 * q + jc) * LH + 4 * kq;
-
+            for (int q = 0; q < 4; q++)
+                w[g][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, w_voff + (unsigned)(kb * 64), (g * LH + 16 * q) * LH * 4, 0));
+    };
+    // input projection: row (b, t, dir) of xproj[B][T][2][4H], element g*256 + 64*wave + 16*q + jc
+    auto load_x = [&](f32x4 (&xp)[4][4], int step) {
+        const int t = dir ? (T - 1 - step) : step;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int b = b0 + 4 * kq + r;
+            b = b < B ? b : B - 1;
+            const unsigned voff = (unsigned)((((long)b * T + t) * 2 + dir) * (4 * LH) + 64 * wave + jc) * 4u;
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    xp[g][q][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, voff + (unsigned)((g * LH + 16 * q) * 4), 0, 0));
+        }
+    };
+    f32x4 w0[4][4], w1[4][4], xnext[4][4];
+    load_x(xnext, 0);
+    load_w(w0, 0);
     for (int step = 0; step < T; step++) {
         const int t = dir ? (T - 1 - step) : step;
         const int cur = step & 1;
@@ -57,26 +81,33 @@ __global__ __launch_bounds__(256) void lstm_bidir_kernel(const float *__restrict
 #pragma unroll
         for (int g = 0; g < 4; g++)
 #pragma unroll
-            for (int q = 0; q < 4; q++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    int b = b0 + 4 * kq + r;
-                    b = b < B ? b : B - 1;
-                    acc[g][q][r] = xproj[(((long)b * T + t) * 2 + dir) * (4 * LH) + g * LH + 64 * wave + 16 * q + jc];
-                }
+            for (int q = 0; q < 4; q++) acc[g][q] = xnext[g][q];
+        if (step + 1 < T) load_x(xnext, step + 1);
         const float *hrow = &hbuf[cur][jc][4 * kq];       // A operand: row jc, k = 16*kb + 4*kq + t
-#pragma unroll 2
-        for (int kb = 0; kb < LH / 16; kb++) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(hrow + 16 * kb);
 #pragma unroll
-            for (int g = 0; g < 4; g++)
+        for (int kb = 0; kb < LH / 16; kb += 2) {
+            load_w(w1, kb + 1);
+            {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(hrow + 16 * kb);
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const f32x4 bw = *reinterpret_cast<const f32x4 *>(wrow[g][q] + 16 * kb);
+                for (int tt = 0; tt < 4; tt++)             // k innermost-last: 16 independent accumulators between dependent MFMAs
 #pragma unroll
-                    for (int tt = 0; tt < 4; tt++)
-                        acc[g][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tt], bw[tt], acc[g][q], 0, 0, 0);
-                }
+                    for (int g = 0; g < 4; g++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            acc[g][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tt], w0[g][q][tt], acc[g][q], 0, 0, 0);
+            }
+            load_w(w0, (kb + 2) & (LH / 16 - 1));             // the last one fetches k-block 0 for the next time step
+            {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(hrow + 16 * (kb + 1));
+#pragma unroll
+                for (int tt = 0; tt < 4; tt++)             // k innermost-last: 16 independent accumulators between dependent MFMAs
+#pragma unroll
+                    for (int g = 0; g < 4; g++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            acc[g][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tt], w1[g][q][tt], acc[g][q], 0, 0, 0);
+            }
         }
         // cell update: torch gate order i, f, g, o
 #pragma unroll
@@ -164,7 +195,9 @@ using namespace ptocr;
 extern "C" int ptocr_lstm_bidir_f32(const float *d_xproj, const float *d_whh, float *d_out, int T, int B, int H, void *stream) {
     PT_CHECK(d_xproj && d_whh && d_out && T >= 1 && B >= 1, "ptocr_lstm_bidir_f32: bad arguments");
     PT_CHECK(H == LH, "ptocr_lstm_bidir_f32: hidden size must be %d (got %d)", LH, H);
-    hipLaunchKernelGGL(lstm_bidir_kernel, dim3(cdiv(B, LROWS), 2), dim3(256), 0, (hipStream_t)stream, d_xproj, d_whh, d_out, T, B);
+    const long x_bytes = (long)B * T * 2 * 4 * LH * 4;
+    PT_CHECK(x_bytes < (1L << 31), "ptocr_lstm_bidir_f32: B*T too large (projection tensor must stay below 2 GiB)");
+    hipLaunchKernelGGL(lstm_bidir_kernel, dim3(cdiv(B, LROWS), 2), dim3(256), 0, (hipStream_t)stream, d_xproj, d_whh, d_out, T, B, x_bytes);
     return launch_ok("lstm_bidir_kernel");
 }
 
