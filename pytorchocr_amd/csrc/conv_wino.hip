@@ -377,13 +377,14 @@ extern "C" int ptocr_conv3x3_wino_f32(const float *d_x, const float *d_u, const 
     a.x_bytes = (long)N * H * W * Cin * 4;
     a.u_bytes = (long)Cout * Cin * 16 * 4;
     PT_CHECK(a.x_bytes < (1L << 31) && a.u_bytes < (1L << 31), "ptocr_conv3x3_wino_f32: tensor larger than 2 GiB");
-    // patch geometry (64 tiles): 16x16 outputs, 32 rows x 8 columns, or -- for short images (text lines) -- 8x16 outputs of 2
-    // images / 4x16 outputs of 4 images; the one that covers the batch at the lowest cost wins (multi-image patches carry a
+    // patch geometry (64 tiles): 16x16 outputs, 32 rows x 8 columns, or -- for short images (text lines) and small maps -- 8x16
+    // outputs of 2 images / 4x16 or 8x8 outputs of 4 images; the one that covers the batch at the lowest cost wins (multi-image patches carry a
     // larger halo and one more raw piece per thread: measured 6 % / 12 % more time per patch)
-    const long cnt[4] = {100 * (long)N * cdiv(H, 16) * cdiv(W, 16), 100 * (long)N * cdiv(H, 32) * cdiv(W, 8),
-                         106 * (long)cdiv(N, 2) * cdiv(H, 8) * cdiv(W, 16), 112 * (long)cdiv(N, 4) * cdiv(H, 4) * cdiv(W, 16)};
+    const long cnt[5] = {100 * (long)N * cdiv(H, 16) * cdiv(W, 16), 100 * (long)N * cdiv(H, 32) * cdiv(W, 8),
+                         106 * (long)cdiv(N, 2) * cdiv(H, 8) * cdiv(W, 16), 112 * (long)cdiv(N, 4) * cdiv(H, 4) * cdiv(W, 16),
+                         112 * (long)cdiv(N, 4) * cdiv(H, 8) * cdiv(W, 8)};
     int geo = 0;
-    for (int g = 1; g < 4; g++)
+    for (int g = 1; g < 5; g++)
         if (cnt[g] < cnt[geo]) geo = g;
 #ifdef PTOCR_WINO_EXPERIMENT
     static const int dbgm = getenv("PTOCR_WINO_DBG") ? atoi(getenv("PTOCR_WINO_DBG")) : 0;
@@ -399,6 +400,7 @@ extern "C" int ptocr_conv3x3_wino_f32(const float *d_x, const float *d_u, const 
         case 1: return launch_wino<4, 16>(a, (hipStream_t)stream);
         case 2: return launch_wino<8, 4>(a, (hipStream_t)stream);
         case 3: return launch_wino<8, 2>(a, (hipStream_t)stream);
+        case 4: return launch_wino<4, 4>(a, (hipStream_t)stream);
         default: return launch_wino<8, 8>(a, (hipStream_t)stream);
     }
 }

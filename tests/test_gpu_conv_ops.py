@@ -227,7 +227,7 @@ def test_squeeze_excitation():
 
 
 @pytest.mark.parametrize("case", [(2, 64, 20, 36, 64), (1, 256, 23, 40, 64), (1, 128, 16, 32, 128), (1, 64, 33, 47, 192),
-                                  (5, 32, 150, 170, 64), (6, 64, 8, 48, 64), (7, 32, 4, 40, 64), (3, 32, 6, 21, 128)])
+                                  (5, 32, 150, 170, 64), (6, 64, 8, 48, 64), (7, 32, 4, 40, 64), (3, 32, 6, 21, 128), (8, 32, 23, 40, 64), (5, 32, 9, 24, 64)])
 def test_winograd_3x3_matches_torch(case):
     """Winograd F(2x2,3x3) path (default for 3x3/s1/p1 layers) against torch fp32, incl. odd sizes, residual, concat slice,
     all four patch geometries (16x16, 32x8, and the 2- / 4-image patches used for short text-line feature maps)."""
