@@ -266,10 +266,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="det", choices=["det", "crnn"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 32 det / 512 crnn)")
-    ap.add_argument("--post-input", default="both", choices=["both", "stress", "model"],
+    ap.add_argument("--post-input", default="both", choices=["both", "stress", "model", "none"],
                     help="maps post-processed inside the timed step: the model's own maps (true data flow; random weights "
                          "give noise-like maps), text-like stress maps with ~130 boxes per image, or both (default: "
-                         "strictly more work than the real pipeline)")
+                         "strictly more work than the real pipeline); none = forward only, a diagnostic that is NOT the metric")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false",
                     help="run the post-process synchronously after each forward instead of overlapping it with the next batch")
     ap.add_argument("--cpu-images", type=int, default=8, help="images in the CPU-baseline sample (0 = skip)")

@@ -114,3 +114,63 @@ def test_ctc_decode_host_part_matches_oracle():
     for (t1, c1), (t2, c2) in zip(got, exp):
         assert t1 == t2 and ((math.isnan(c1) and math.isnan(c2)) or abs(c1 - c2) < 1e-7)
     assert got[3][0] == "" and math.isnan(got[3][1])
+
+
+def test_winograd_pack_reproduces_conv():
+    """Host-side Winograd weights (U = G g G^T, packed [Cout/64][Cin/4][16][64][4], include/ptocr_hip.h) drive a numpy
+    restatement of what conv_wino_kernel computes (V = B^T d B, M = sum_c U V, Y = A^T M A) and reproduce torch's conv + BN."""
+    torch.manual_seed(3)
+    conv = nn.Conv2d(16, 64, 3, 1, 1, bias=False)
+    bn = nn.BatchNorm2d(64).eval()
+    with torch.no_grad():
+        bn.running_mean.uniform_(-0.3, 0.3); bn.running_var.uniform_(0.5, 1.5); bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.2, 0.2)
+    x = torch.randn(1, 16, 6, 8)
+    with torch.no_grad():
+        ref = bn(conv(x))[0].numpy()
+    pc = ops.PackedConv(conv, bn, torch.device("cpu"), relu=False, cin_pad=16)
+    assert pc.wino_u is not None and tuple(pc.wino_u.shape) == (1, 4, 16, 64, 4)
+    U = pc.wino_u.numpy().astype(np.float64)                       # [ct][chunk][xi][cout][c4]
+    Bt = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float64)
+    At = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], np.float64)
+    xp = np.pad(x[0].numpy().astype(np.float64), ((0, 0), (1, 1), (1, 1)))
+    out = np.zeros((64, 6, 8))
+    for ty in range(3):
+        for tx in range(4):
+            d = xp[:, 2 * ty:2 * ty + 4, 2 * tx:2 * tx + 4]                     # [c][4][4]
+            V = np.einsum("ai,cij,bj->cab", Bt, d, Bt).reshape(16, 16)        # [c][xi]
+            M = np.zeros((64, 16))
+            for c in range(16):
+                M += U[0, c // 4, :, :, c % 4].T * V[c][None, :]
+            Y = np.einsum("ai,oij,bj->oab", At, M.reshape(64, 4, 4), At)
+            out[:, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2] = Y
+    out += pc.wino_b.numpy()[:, None, None]
+    assert np.abs(out - ref).max() < 1e-5
+
+
+def test_stem_and_pointwise_pack_layouts():
+    """w[ky][kx*3 + c][cout] with a zero 22nd row per ky (stem kernel) and W[k][cout] (pointwise kernel) reproduce conv + BN."""
+    torch.manual_seed(4)
+    conv = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+    bn = nn.BatchNorm2d(64).eval()
+    with torch.no_grad():
+        bn.running_mean.uniform_(-0.3, 0.3); bn.running_var.uniform_(0.5, 1.5)
+    x = torch.randn(1, 3, 10, 12)
+    with torch.no_grad():
+        ref = bn(conv(x))[0].numpy()
+    pc = ops.PackedConv(conv, bn, torch.device("cpu"), relu=True, cin_pad=4)
+    assert pc.stem_w is not None and tuple(pc.stem_w.shape) == (7, 22, 64)
+    w = pc.stem_w.numpy().astype(np.float64)
+    assert float(np.abs(w[:, 21]).max()) == 0.0
+    xp = np.pad(x[0].numpy().astype(np.float64), ((0, 0), (3, 3), (3, 3)))
+    out = np.zeros((64, 5, 6))
+    for oy in range(5):
+        for ox in range(6):
+            patch = xp[:, 2 * oy:2 * oy + 7, 2 * ox:2 * ox + 7]             # [c][ky][kx]
+            k = patch.transpose(1, 2, 0).reshape(7, 21)                   # [ky][kx*3 + c]
+            out[:, oy, ox] = np.einsum("yj,yjo->o", k, w[:, :21])
+    out += pc.stem_b.numpy()[:, None, None]
+    assert np.abs(out - ref).max() < 1e-5
+    conv1 = nn.Conv2d(64, 96, 1, bias=False)
+    pc1 = ops.PackedConv(conv1, None, torch.device("cpu"), relu=True)
+    assert pc1.pw_w is not None and tuple(pc1.pw_w.shape) == (64, 96)
+    assert torch.allclose(pc1.pw_w, conv1.weight.detach().reshape(96, 64).t())
