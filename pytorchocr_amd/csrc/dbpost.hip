@@ -799,7 +799,8 @@ __device__ int clipper_offset_round(const CPt *path4, double delta, F2 *out, int
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return x > hi ? hi : (x < lo ? lo : x); }
 
 // ------------------------------------------------------------------------------------------ per-border workgroup
-enum { ST_OK = 0, ST_SKIP_NPTS = 1, ST_SKIP_SSID = 2, ST_SKIP_SCORE = 3, ST_SKIP_UNCLIP = 4, ST_SKIP_SSID2 = 5, ST_NONE = 6 };
+enum { ST_OK = 0, ST_SKIP_NPTS = 1, ST_SKIP_SSID = 2, ST_SKIP_SCORE = 3, ST_SKIP_UNCLIP = 4, ST_SKIP_SSID2 = 5, ST_NONE = 6,
+       ST_DEFER = 7 };   // ST_DEFER: left by the small-footprint pass for the full-size one (never visible after a call)
 
 struct Result { int status; int box[8]; float score; float rect[5]; int npix; float distance; };
 
@@ -927,7 +928,12 @@ __device__ double score_mask_raster_order(const unsigned *border, int xmin, int 
     return s;
 }
 
-__global__ __launch_bounds__(CT_THREADS) void contour_kernel(const float *__restrict__ maps, const Cand *__restrict__ cands,
+// Two instantiations share this body.  SMALL: column tables for borders up to 512 px wide, mask planes up to 30720 px and 80
+// hull candidates -- 17.5 KB of LDS and <= 80 VGPRs, so a dozen workgroups fit a CU and one fits NEXT TO a Winograd workgroup of
+// the following batch's forward pass (which leaves 18 KB of LDS and 92 VGPRs per SIMD); a border that exceeds any of the
+// limits is marked ST_DEFER.  The full-size instantiation (2048 px, 131072 px, 512 candidates; 53 KB) then handles only those.
+template <int MW, int PLANE, int MH, bool SMALL>
+__global__ __launch_bounds__(CT_THREADS, SMALL ? 6 : 1) void contour_kernel(const float *__restrict__ maps, const Cand *__restrict__ cands,
                                                              const int *__restrict__ totals, const CandInfo *__restrict__ info,
                                                              const unsigned *__restrict__ pool, unsigned *__restrict__ gslots,
                                                              int *__restrict__ slot_locks, Result *__restrict__ results,
@@ -939,6 +945,7 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const float *__rest
     if (k >= num) return;
     Result *res = &results[(long)img * MAX_CAND + k];
     const CandInfo ci = info[(long)img * MAX_CAND + k];
+    if (!SMALL && res->status != ST_DEFER) return;            // handled by the small-footprint pass
     if (flags[img] & 4) { if (tid == 0) res->status = ST_NONE; return; }
     if (ci.npts <= 2) { if (tid == 0) res->status = ST_SKIP_NPTS; return; }     // db_postprocess.cpp:255
     const unsigned *pts = pool + (long)img * d.pool_stride + ci.off;
@@ -949,16 +956,17 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const float *__rest
     // at most the diagonal of the bounding box; a diagonal <= sqrt(8) means ssid < 3 (db_postprocess.cpp:265) without
     // computing the rectangle.  Noise maps are made of thousands of such borders.
     if ((bw - 1) * (bw - 1) + (bh - 1) * (bh - 1) <= 8) { if (tid == 0) res->status = ST_SKIP_SSID; return; }
+    if (SMALL && (bw > MW || (long)((bw + 31) >> 5) * bh > PLANE)) { if (tid == 0) res->status = ST_DEFER; return; }
 
     // LDS arena: column tables (hull phase) and mask planes (score phase) are never live together
-    __shared__ __attribute__((aligned(16))) unsigned arena[2 * LDS_PLANE_WORDS];
-    int *col_lo = reinterpret_cast<int *>(arena);               // [MAXW] min y of the border points per column
-    int *col_hi = col_lo + MAXW;                                // [MAXW] max y
-    static_assert(2 * MAXW <= 2 * LDS_PLANE_WORDS, "arena too small");
-    __shared__ F2 cand_pts[MAXHULL];
-    __shared__ F2 hull_pts[MAXHULL];
-    __shared__ int stack[2 * (MAXHULL + 2)];
-    __shared__ float cal_scratch[3 * MAXHULL];
+    constexpr int ARENA = 2 * PLANE > 3 * MW ? 2 * PLANE : 3 * MW;
+    __shared__ __attribute__((aligned(16))) unsigned arena[ARENA];
+    int *col_lo = reinterpret_cast<int *>(arena);               // [MW] min y of the border points per column
+    int *col_hi = col_lo + MW;                                  // [MW] max y
+    __shared__ F2 cand_pts[MH];
+    __shared__ F2 hull_pts[MH];
+    __shared__ int stack[2 * (MH + 2)];
+    __shared__ float cal_scratch[3 * MH];
     __shared__ double red_d[CT_THREADS];
     __shared__ int red_i[CT_THREADS];
     __shared__ int wave_cnt[CT_THREADS / 64];
@@ -978,12 +986,11 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const float *__rest
     __syncthreads();
     // ---- 1b. compact the non-empty columns in place (a CHAIN_APPROX_SIMPLE border touches few columns: 8 of 169 is
     //          typical for a clean text blob), so that the quadratic filter below runs over m columns, not bw
-    int *col_x = col_hi + MAXW;                                 // [MAXW] x (relative to xmin) of compacted column a
-    static_assert(3 * MAXW <= 2 * LDS_PLANE_WORDS, "arena too small");
+    int *col_x = col_hi + MW;                                   // [MW] x (relative to xmin) of compacted column a
     const int lane = tid & 63, wave = tid >> 6;
     int m_cols = 0;
     {
-        constexpr int ROUNDS = MAXW / CT_THREADS;               // bw <= MAXW
+        constexpr int ROUNDS = MW / CT_THREADS;                 // bw <= MW
         int v_lo[ROUNDS], v_hi[ROUNDS], v_pos[ROUNDS];
 #pragma unroll
         for (int r = 0; r < ROUNDS; r++) {
@@ -1039,8 +1046,8 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const float *__rest
         __syncthreads();
         int pos = sh_n + incl - mine;
         for (int w = 0; w < wave; w++) pos += wave_cnt[w];
-        if (keep_lo) { if (pos < MAXHULL) { cand_pts[pos].x = (float)(xi + xmin); cand_pts[pos].y = (float)ylo; } pos++; }
-        if (keep_hi) { if (pos < MAXHULL) { cand_pts[pos].x = (float)(xi + xmin); cand_pts[pos].y = (float)yhi; } pos++; }
+        if (keep_lo) { if (pos < MH) { cand_pts[pos].x = (float)(xi + xmin); cand_pts[pos].y = (float)ylo; } pos++; }
+        if (keep_hi) { if (pos < MH) { cand_pts[pos].x = (float)(xi + xmin); cand_pts[pos].y = (float)yhi; } pos++; }
         __syncthreads();
         if (tid == CT_THREADS - 1) sh_n = pos;
         __syncthreads();
@@ -1048,7 +1055,7 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const float *__rest
     // ---- 3. min-area rect of the border, mini-box, first size filter (lane 0; a few dozen vertices)
     if (tid == 0) {
         int status = ST_OK;
-        if (sh_n > MAXHULL) { atomicOr(&flags[img], 4); status = ST_NONE; }
+        if (sh_n > MH) { if (SMALL) status = ST_DEFER; else { atomicOr(&flags[img], 4); status = ST_NONE; } }
         else {
             const RRect box = min_area_rect_sorted(cand_pts, sh_n, hull_pts, stack, cal_scratch);
             float ssid;
@@ -1066,8 +1073,8 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const float *__rest
     const long plane_words = (long)((bw + 31) >> 5) * bh;
     double total; int npix;
     float score;
-    if (plane_words <= LDS_PLANE_WORDS) {
-        unsigned *border = arena, *toggle = arena + LDS_PLANE_WORDS;
+    if (plane_words <= PLANE) {
+        unsigned *border = arena, *toggle = arena + PLANE;
         score_mask<false>(pts, n, xmin, ymin, bw, bh, border, toggle, pimg, d.W, red_d, red_i, &total, &npix);
         score = (float)(npix ? total / npix : 0.0);
         if (fabs((double)score - (double)box_thresh) <= 1e-6) {
@@ -1108,9 +1115,9 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const float *__rest
     if (distance < 0.75f) atomicOr(&flags[img], 1);            // sub-pixel sliver: Clipper's union clean-up not reproduced
     CPt path[4];
     for (int i = 0; i < 4; i++) { path[i].X = (long long)(int)sh_mini[i][0]; path[i].Y = (long long)(int)sh_mini[i][1]; }
-    const int np = clipper_offset_round(path, (double)distance, cand_pts, MAXHULL);
+    const int np = clipper_offset_round(path, (double)distance, cand_pts, MH);
     RRect ub;
-    if (np > MAXHULL) { atomicOr(&flags[img], 4); res->status = ST_NONE; return; }
+    if (np > MH) { if (SMALL) res->status = ST_DEFER; else { atomicOr(&flags[img], 4); res->status = ST_NONE; } return; }
     if (np <= 0) { ub.cx = 0; ub.cy = 0; ub.w = 1; ub.h = 1; ub.angle = 0; }
     else {
         for (int i = 1; i < np; i++) {                          // sort by (x, y) like cv::convexHull
@@ -1286,8 +1293,12 @@ extern "C" int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, co
     hipLaunchKernelGGL(pool_offsets_kernel, dim3(N), dim3(1024), 0, s, h->info, h->totals, h->flags, d);
     hipLaunchKernelGGL(trace_write_kernel, dim3(MAX_CAND, N), dim3(64), 0, s, bits, h->cands, h->totals, h->info,
                        h->pool, h->flags, d);
-    hipLaunchKernelGGL(contour_kernel, dim3(MAX_CAND, N), dim3(CT_THREADS), 0, s, d_maps, h->cands, h->totals, h->info, h->pool,
-                       h->gslots, h->slot_locks, h->results, h->flags, h->src_wh, box_thresh, unclip_ratio, h->slot_words, use_padding_resize, d);
+    hipLaunchKernelGGL((contour_kernel<512, 960, 80, true>), dim3(MAX_CAND, N), dim3(CT_THREADS), 0, s, d_maps, h->cands, h->totals, h->info,
+                       h->pool, h->gslots, h->slot_locks, h->results, h->flags, h->src_wh, box_thresh, unclip_ratio, h->slot_words,
+                       use_padding_resize, d);
+    hipLaunchKernelGGL((contour_kernel<MAXW, LDS_PLANE_WORDS, MAXHULL, false>), dim3(MAX_CAND, N), dim3(CT_THREADS), 0, s, d_maps, h->cands,
+                       h->totals, h->info, h->pool, h->gslots, h->slot_locks, h->results, h->flags, h->src_wh, box_thresh, unclip_ratio,
+                       h->slot_words, use_padding_resize, d);
     hipLaunchKernelGGL(compact_kernel, dim3(N), dim3(1024), 0, s, h->results, h->totals, h->boxes, h->counts, max_boxes);
     if (int e = launch_ok("dbpost kernels")) return e;
     PT_HIP(hipMemcpyAsync(h_counts, h->counts, sizeof(int) * N, hipMemcpyDeviceToHost, s));
