@@ -928,24 +928,19 @@ __device__ double score_mask_raster_order(const unsigned *border, int xmin, int 
     return s;
 }
 
-// Two instantiations share this body.  SMALL: column tables for borders up to 512 px wide, mask planes up to 30720 px and 80
-// hull candidates -- 17.5 KB of LDS and <= 80 VGPRs, so a dozen workgroups fit a CU and one fits NEXT TO a Winograd workgroup of
+// Two instantiations share this body (contour_kernel / contour_big_kernel below).  SMALL: column tables for borders up to
+// 512 px wide, mask planes up to 30720 px and 80 hull candidates -- 17.5 KB of LDS and <= 80 VGPRs, so a dozen workgroups fit a CU and one fits NEXT TO a Winograd workgroup of
 // the following batch's forward pass (which leaves 18 KB of LDS and 92 VGPRs per SIMD); a border that exceeds any of the
 // limits is marked ST_DEFER.  The full-size instantiation (2048 px, 131072 px, 512 candidates; 53 KB) then handles only those.
 template <int MW, int PLANE, int MH, bool SMALL>
-__global__ __launch_bounds__(CT_THREADS, SMALL ? 6 : 1) void contour_kernel(const float *__restrict__ maps, const Cand *__restrict__ cands,
-                                                             const int *__restrict__ totals, const CandInfo *__restrict__ info,
-                                                             const unsigned *__restrict__ pool, unsigned *__restrict__ gslots,
-                                                             int *__restrict__ slot_locks, Result *__restrict__ results,
-                                                             int *__restrict__ flags, const int *__restrict__ src_wh,
-                                                             float box_thresh, float unclip_ratio, long slot_words, int use_padding_resize,
-                                                             DbpostDims d) {
-    const int img = blockIdx.y, k = blockIdx.x, tid = threadIdx.x;
-    const int num = min(totals[img], MAX_CAND);
-    if (k >= num) return;
+__device__ void contour_body(int img, int k, const float *__restrict__ maps, const Cand *__restrict__ cands,
+                             const CandInfo *__restrict__ info, const unsigned *__restrict__ pool, unsigned *__restrict__ gslots,
+                             int *__restrict__ slot_locks, Result *__restrict__ results, int *__restrict__ flags,
+                             const int *__restrict__ src_wh, float box_thresh, float unclip_ratio, long slot_words,
+                             int use_padding_resize, const DbpostDims &d) {
+    const int tid = threadIdx.x;
     Result *res = &results[(long)img * MAX_CAND + k];
     const CandInfo ci = info[(long)img * MAX_CAND + k];
-    if (!SMALL && res->status != ST_DEFER) return;            // handled by the small-footprint pass
     if (flags[img] & 4) { if (tid == 0) res->status = ST_NONE; return; }
     if (ci.npts <= 2) { if (tid == 0) res->status = ST_SKIP_NPTS; return; }     // db_postprocess.cpp:255
     const unsigned *pts = pool + (long)img * d.pool_stride + ci.off;
@@ -1083,7 +1078,7 @@ __global__ __launch_bounds__(CT_THREADS, SMALL ? 6 : 1) void contour_kernel(cons
             score = (float)(npix ? red_d[0] / npix : 0.0);
         }
     } else {
-        const int slot = (int)(((long)img * gridDim.x + k) % NSLOTS);
+        const int slot = (int)(((long)img * MAX_CAND + k) % NSLOTS);
         unsigned *border = gslots + (long)slot * 2 * slot_words, *toggle = border + slot_words;
         if (tid == 0) { while (atomicCAS(&slot_locks[slot], 0, 1) != 0) __builtin_amdgcn_s_sleep(32); __threadfence(); }
         __syncthreads();
@@ -1152,6 +1147,38 @@ __global__ __launch_bounds__(CT_THREADS, SMALL ? 6 : 1) void contour_kernel(cons
         }
     }
     res->status = ST_OK;
+}
+
+// small-footprint pass: one workgroup per border
+__global__ __launch_bounds__(CT_THREADS, 6) void contour_kernel(const float *__restrict__ maps, const Cand *__restrict__ cands,
+                                                                const int *__restrict__ totals, const CandInfo *__restrict__ info,
+                                                                const unsigned *__restrict__ pool, unsigned *__restrict__ gslots,
+                                                                int *__restrict__ slot_locks, Result *__restrict__ results,
+                                                                int *__restrict__ flags, const int *__restrict__ src_wh,
+                                                                float box_thresh, float unclip_ratio, long slot_words, int use_padding_resize,
+                                                                DbpostDims d) {
+    const int img = blockIdx.y, k = blockIdx.x;
+    if (k >= min(totals[img], MAX_CAND)) return;
+    contour_body<512, 960, 80, true>(img, k, maps, cands, info, pool, gslots, slot_locks, results, flags, src_wh, box_thresh, unclip_ratio,
+                                     slot_words, use_padding_resize, d);
+}
+
+// full-size pass: a few workgroups per image walk the borders the small pass deferred (usually none)
+__global__ __launch_bounds__(CT_THREADS, 1) void contour_big_kernel(const float *__restrict__ maps, const Cand *__restrict__ cands,
+                                                                    const int *__restrict__ totals, const CandInfo *__restrict__ info,
+                                                                    const unsigned *__restrict__ pool, unsigned *__restrict__ gslots,
+                                                                    int *__restrict__ slot_locks, Result *__restrict__ results,
+                                                                    int *__restrict__ flags, const int *__restrict__ src_wh,
+                                                                    float box_thresh, float unclip_ratio, long slot_words,
+                                                                    int use_padding_resize, DbpostDims d) {
+    const int img = blockIdx.y;
+    const int num = min(totals[img], MAX_CAND);
+    for (int k = blockIdx.x; k < num; k += gridDim.x) {
+        if (results[(long)img * MAX_CAND + k].status != ST_DEFER) continue;       // uniform over the workgroup
+        contour_body<MAXW, LDS_PLANE_WORDS, MAXHULL, false>(img, k, maps, cands, info, pool, gslots, slot_locks, results, flags, src_wh,
+                                                            box_thresh, unclip_ratio, slot_words, use_padding_resize, d);
+        __syncthreads();                                                          // the body's LDS is reused by the next border
+    }
 }
 
 // boxes of one image in candidate order -> dense int16 list + count
@@ -1293,12 +1320,10 @@ extern "C" int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, co
     hipLaunchKernelGGL(pool_offsets_kernel, dim3(N), dim3(1024), 0, s, h->info, h->totals, h->flags, d);
     hipLaunchKernelGGL(trace_write_kernel, dim3(MAX_CAND, N), dim3(64), 0, s, bits, h->cands, h->totals, h->info,
                        h->pool, h->flags, d);
-    hipLaunchKernelGGL((contour_kernel<512, 960, 80, true>), dim3(MAX_CAND, N), dim3(CT_THREADS), 0, s, d_maps, h->cands, h->totals, h->info,
-                       h->pool, h->gslots, h->slot_locks, h->results, h->flags, h->src_wh, box_thresh, unclip_ratio, h->slot_words,
-                       use_padding_resize, d);
-    hipLaunchKernelGGL((contour_kernel<MAXW, LDS_PLANE_WORDS, MAXHULL, false>), dim3(MAX_CAND, N), dim3(CT_THREADS), 0, s, d_maps, h->cands,
-                       h->totals, h->info, h->pool, h->gslots, h->slot_locks, h->results, h->flags, h->src_wh, box_thresh, unclip_ratio,
-                       h->slot_words, use_padding_resize, d);
+    hipLaunchKernelGGL(contour_kernel, dim3(MAX_CAND, N), dim3(CT_THREADS), 0, s, d_maps, h->cands, h->totals, h->info, h->pool, h->gslots,
+                       h->slot_locks, h->results, h->flags, h->src_wh, box_thresh, unclip_ratio, h->slot_words, use_padding_resize, d);
+    hipLaunchKernelGGL(contour_big_kernel, dim3(64, N), dim3(CT_THREADS), 0, s, d_maps, h->cands, h->totals, h->info, h->pool, h->gslots,
+                       h->slot_locks, h->results, h->flags, h->src_wh, box_thresh, unclip_ratio, h->slot_words, use_padding_resize, d);
     hipLaunchKernelGGL(compact_kernel, dim3(N), dim3(1024), 0, s, h->results, h->totals, h->boxes, h->counts, max_boxes);
     if (int e = launch_ok("dbpost kernels")) return e;
     PT_HIP(hipMemcpyAsync(h_counts, h->counts, sizeof(int) * N, hipMemcpyDeviceToHost, s));
