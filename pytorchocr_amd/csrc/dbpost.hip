@@ -200,7 +200,8 @@ __global__ __launch_bounds__(256) void ccl_merge_kernel(const unsigned *__restri
                                                         CclPass ps) {
     const int img = blockIdx.y;
     if (ccl_skip(ps, img)) return;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int idx = (blockIdx.x * 256 + threadIdx.x) >> 2;       // four threads per word, one byte of its boundary masks each:
+    const unsigned part = 0xffu << (8 * (threadIdx.x & 3));     // speckle maps put ~10 unions into a word, each a chain of atomics
     if (idx >= (d.H - ps.y_first) * d.WW) return;
     const int y = ps.y_first + idx / d.WW, wi = idx % d.WW;
     const bool cut = y == ps.y_first && y > 0;                    // first row of the strip: links upwards end in FRAME
@@ -215,6 +216,7 @@ __global__ __launch_bounds__(256) void ccl_merge_kernel(const unsigned *__restri
         unsigned f = (y == 0 || y == d.H - 1) ? (m & c.starts) : 0u;
         if (wi == 0) f |= m & 1u;
         if (x0 + 32 >= d.W) f |= m & (1u << (d.W - 1 - x0));
+        f &= part;
         while (f) {
             const int i = __ffs(f) - 1;
             f &= f - 1;
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(256) void ccl_merge_kernel(const unsigned *__restri
     const int ubase = base - d.W;
     auto rs_up = [&](int x) { return (y - 1) * d.W + run_start(up, x); };
     // vertical links: same class above, and the current or the upper run starts here
-    unsigned v = ~(c.w ^ u.w) & c.valid & (c.starts | u.starts);
+    unsigned v = ~(c.w ^ u.w) & c.valid & (c.starts | u.starts) & part;
     while (v) {
         const int i = __ffs(v) - 1;
         v &= v - 1;
@@ -236,14 +238,14 @@ __global__ __launch_bounds__(256) void ccl_merge_kernel(const unsigned *__restri
     // foreground with background straight above: diagonal links
     const unsigned fgbg = c.w & ~u.w & c.valid;
     const unsigned ucarry = wi ? up[wi - 1] >> 31 : 0u;
-    unsigned nw = fgbg & c.starts & ((u.w << 1) | ucarry);         // pix(up, x-1) set; x = 0 has no NW neighbour (carry 0)
+    unsigned nw = fgbg & c.starts & ((u.w << 1) | ucarry) & part;         // pix(up, x-1) set; x = 0 has no NW neighbour (carry 0)
     while (nw) {
         const int i = __ffs(nw) - 1;
         nw &= nw - 1;
         uf_union(lab, base + i, cut ? FRAME : rs_up(x0 + i - 1));
     }
     const unsigned unext = (wi + 1 < d.WW) ? (up[wi + 1] & 1u) : 0u;
-    unsigned ne = fgbg & c.ends & ((u.w >> 1) | (unext << 31));     // pix(up, x+1) set (bits beyond W are clear)
+    unsigned ne = fgbg & c.ends & ((u.w >> 1) | (unext << 31)) & part;     // pix(up, x+1) set (bits beyond W are clear)
     while (ne) {
         const int i = __ffs(ne) - 1;
         ne &= ne - 1;
@@ -1311,7 +1313,7 @@ extern "C" int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, co
         const int words = (H - ps.y_first) * d.WW;
         const dim3 word_grid(cdiv(words > d.nchunks ? words : d.nchunks, 256), N);
         hipLaunchKernelGGL(ccl_init_kernel, word_grid, dim3(256), 0, s, bits, h->labels, h->chunk_cnt, d, ps);
-        hipLaunchKernelGGL(ccl_merge_kernel, word_grid, dim3(256), 0, s, bits, h->labels, d, ps);
+        hipLaunchKernelGGL(ccl_merge_kernel, dim3(cdiv(4 * words, 256), N), dim3(256), 0, s, bits, h->labels, d, ps);
         hipLaunchKernelGGL(ccl_flatten_kernel, word_grid, dim3(256), 0, s, bits, h->labels, h->chunk_cnt, d, ps);
         hipLaunchKernelGGL(chunk_suffix_kernel, dim3(N), dim3(1024), 0, s, h->chunk_cnt, h->totals, d, ps, h->strip_totals);
     }
