@@ -63,6 +63,35 @@ def test_full_size_against_oracle(contract):
     assert np.abs(y - ref).max() <= 1e-4
 
 
+def test_bench_batch_properties(contract):
+    """BASELINE configs[1] size, 32 x 736 x 1280 (too big for the CPU oracle in seconds): size-independent properties --
+    an image's maps do not depend on its position in the batch or on the batch size (every kernel, incl. the Winograd
+    patch geometries and the persistent tile walkers, computes each output in a fixed order), repeated runs are
+    bit-identical, values are probabilities, and the DB post-process of the batch equals the post-process per image."""
+    from pytorchocr_amd.postprocess import build_post_process
+    m = _model(contract)
+    base = torch.from_numpy(synth_images(4, 3, 736, 1280, seed=11)).to("cuda:0")
+    x = base.repeat(8, 1, 1, 1).contiguous()
+    with torch.no_grad():
+        y = m(x)["maps"]
+        y2 = m(x)["maps"]
+        y1 = m(base[:1].contiguous())["maps"]
+    assert y.shape == (32, 1, 736, 1280)
+    assert torch.equal(y, y2)
+    for i in range(4, 32):
+        assert torch.equal(y[i], y[i % 4]), i
+    assert torch.equal(y[0], y1[0])
+    assert float(y.min()) >= 0.0 and float(y.max()) <= 1.0 and bool(torch.isfinite(y).all())
+    post = build_post_process(dict(name="DBPostProcess", thresh=0.3, box_thresh=0.5, max_candidates=1000, unclip_ratio=1.7,
+                                   score_mode="poly", cpp_speedup=True), dict())
+    shape_list = np.array([[736, 1280, 1.0, 1.0]] * 32)
+    allb = post({"maps": y}, shape_list)
+    one = post({"maps": y[:1].contiguous()}, shape_list[:1])
+    assert np.array_equal(allb[0]["points"], one[0]["points"])
+    for i in range(4, 32):
+        assert np.array_equal(allb[i]["points"], allb[i % 4]["points"]), i
+
+
 def test_cpu_input_fails_loudly(contract):
     m = _model(contract)
     with pytest.raises(RuntimeError):
