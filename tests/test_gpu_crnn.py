@@ -107,3 +107,22 @@ def test_ctc_greedy_ties_take_first_index():
     assert idx.cpu().tolist() == [100, 6623, 0, 0, 1]
     ref = torch.softmax(x[:, :6624], 1).max(1).values
     assert (prob.cpu() - ref).abs().max().item() <= 1e-6
+
+
+def test_bench_batch_properties(contract):
+    """BASELINE configs[2] size (512 lines of 32 x 320): a line's label ids and confidences do not depend on its position in
+    the batch or on the batch size (bit-exact), repeated runs are bit-identical, and they equal the small-batch results that
+    the oracle test above pins."""
+    m, _ = _model(contract)
+    base = torch.from_numpy(synth_text_lines(16, 32, 320, seed=5)).cuda()
+    x = base.repeat(32, 1, 1, 1).contiguous()
+    with torch.no_grad():
+        idx, prob = m.forward_greedy(x)
+        idx2, prob2 = m.forward_greedy(x)
+        idx16, prob16 = m.forward_greedy(base)
+    assert tuple(idx.shape) == (512, 81) and idx.dtype == torch.int32
+    assert torch.equal(idx, idx2) and torch.equal(prob, prob2)
+    assert torch.equal(idx[:16], idx16) and torch.equal(prob[:16], prob16)
+    for i in range(16, 512, 16):
+        assert torch.equal(idx[i:i + 16], idx16) and torch.equal(prob[i:i + 16], prob16), i
+    assert int((idx16 != 0).sum()) > 0 and float(prob.min()) > 0.0 and float(prob.max()) <= 1.0
