@@ -177,6 +177,10 @@ int ptocr_linear_f32(const float *d_x, const float *d_w, const float *d_bias, fl
  * d_xproj f32[B][T][2][4H]: x@W_ih^T + b_ih + b_hh for (forward, backward), one ptocr_linear_f32 with Nout = 8H;
  * d_whh f32[2][4H][H] (weight_hh_l0, weight_hh_l0_reverse); d_out f32[B][T][2H] (forward half | backward half). */
 int ptocr_lstm_bidir_f32(const float *d_xproj, const float *d_whh, float *d_out, int T, int B, int H, void *stream);
+/* When every (16-line group, direction) can own four CUs the recurrence runs split over four workgroups that exchange h each
+ * time step (bounded spins).  A timed-out exchange is reported by the next ptocr_lstm_bidir_f32 call and by this function,
+ * which is meaningful after the stream has been synchronised (e.g. after the label ids were copied to the host). */
+int ptocr_lstm_check(void);
 /* Per row of d_x f32[rows][ld] (first C columns valid, ld % 4 == 0): first arg-max and the max softmax probability.
  * is_prob = 0: d_x holds logits, prob = 1 / sum(exp(x - max));  is_prob = 1: d_x already holds probabilities, prob = max.
  * With rows = b*T + t this is preds.argmax(2), preds.max(2) of rec_postprocess.py:83-84 as int32[B][T], f32[B][T]. */

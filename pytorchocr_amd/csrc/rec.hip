@@ -14,6 +14,7 @@
 // v_mfma_f32_16x16x4_f32: wave w owns hidden units [64w, 64w+64) of all four gates, so i,f,g,o of a unit meet in one
 // lane and the cell update is register-local; h lives in LDS (double-buffered), c in registers, W_hh streams from L2.
 #include "common.h"
+#include <cstdlib>
 
 namespace ptocr {
 
@@ -129,6 +130,117 @@ __global__ __launch_bounds__(256) void lstm_bidir_kernel(const float *__restrict
     }
 }
 
+// ---- split form: the step above is bound by streaming 1 MB of W_hh per time step from L2 into each CU (measured 66 k cycles
+// for 33 k cycles of MFMA).  Here FOUR workgroups share a (16-row group, direction): part p owns hidden units [64p, 64p+64) of
+// all four gates and keeps its 256 KB slice of W_hh in REGISTERS for the whole sequence (256 VGPRs per lane), so a step is 256
+// MFMAs per wave and no weight traffic at all.  The price is one exchange of h (16 x 256 floats) among the four workgroups per
+// time step, done with tagged 8-byte granules {tag = step + 1, value} written and polled with agent-scope relaxed atomics
+// (they bypass the per-CU L1; the data is its own flag, so no fence and no counter: cdna guide, Guideline 16, form R2).  The
+// exchange buffer is double-buffered by step parity: a workgroup can only produce h(s+2) after consuming h(s+1), which every
+// partner produced after consuming h(s).  Spins are bounded; a timeout sets *err and the host reports it.
+constexpr int LPARTS = 4;
+typedef unsigned long long u64;
+
+__global__ __launch_bounds__(256, 1) void lstm_bidir_split_kernel(const float *__restrict__ xproj, const float *__restrict__ whh,
+                                                                  float *__restrict__ out, u64 *__restrict__ hx, int *__restrict__ err,
+                                                                  int T, int B, long x_bytes) {
+    __shared__ __attribute__((aligned(16))) float hbuf[LROWS][HLD];
+    const int part = blockIdx.x, group = blockIdx.y, dir = blockIdx.z;
+    const int b0 = group * LROWS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int jc = lane & 15, kq = lane >> 4;             // MFMA 16x16x4: column / k-quarter (A,B), rows 4*kq + r (C/D)
+    const int unit = 64 * part + 16 * wave + jc;          // this lane's hidden unit (column of every gate tile)
+    const float *W = whh + (long)dir * 4 * LH * LH;
+
+    // resident weights: gate g, k-block kb -> W[g*256 + unit][16 kb + 4 kq .. +3]
+    f32x4 w[4][LH / 16];
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int kb = 0; kb < LH / 16; kb++)
+            w[g][kb] = *reinterpret_cast<const f32x4 *>(W + (long)(g * LH + unit) * LH + 16 * kb + 4 * kq);
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xproj), 0, (int)x_bytes, 0x00020000);
+    auto load_x = [&](f32x4 (&xp)[4], int step) {
+        const int t = dir ? (T - 1 - step) : step;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int b = b0 + 4 * kq + r;
+            b = b < B ? b : B - 1;
+            const unsigned voff = (unsigned)((((long)b * T + t) * 2 + dir) * (4 * LH) + unit) * 4u;
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                xp[g][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, voff + (unsigned)(g * LH * 4), 0, 0));
+        }
+    };
+    u64 *hx_base = hx + ((long)(group * 2 + dir) * 2) * LROWS * LH;         // [parity][row][unit] granules of this (group, dir)
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 xnext[4];
+    load_x(xnext, 0);
+    bool ok = true;
+    for (int step = 0; step < T; step++) {
+        const int t = dir ? (T - 1 - step) : step;
+        f32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) acc[g] = xnext[g];
+        if (step + 1 < T) load_x(xnext, step + 1);
+        // h(step-1) of all four parts -> LDS: thread i fetches row i >> 4, units 16 (i & 15) .. +15
+        {
+            const int row = tid >> 4, u0 = (tid & 15) * 16;
+            float hv[16];
+            if (step == 0) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) hv[i] = 0.f;
+            } else {
+                const u64 *src = hx_base + ((long)((step - 1) & 1) * LROWS + row) * LH + u0;
+                const unsigned want = (unsigned)step;                       // tag of step-1 is (step-1) + 1
+                for (unsigned spins = 0;; spins++) {
+                    bool all = true;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const u64 v = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        hv[i] = __builtin_bit_cast(float, (unsigned)v);
+                        all &= (unsigned)(v >> 32) == want;
+                    }
+                    if (all) break;
+                    if (spins > (1u << 22)) { ok = false; atomicExch(err, 1); break; }      // ~seconds: give up, never hang
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i += 4) *reinterpret_cast<f32x4 *>(&hbuf[row][u0 + i]) = f32x4{hv[i], hv[i + 1], hv[i + 2], hv[i + 3]};
+        }
+        __syncthreads();
+        const float *hrow = &hbuf[jc][4 * kq];            // A operand: row jc, k = 16*kb + 4*kq + t
+#pragma unroll
+        for (int kb = 0; kb < LH / 16; kb++) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(hrow + 16 * kb);
+#pragma unroll
+            for (int tt = 0; tt < 4; tt++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tt], w[g][kb][tt], acc[g], 0, 0, 0);
+        }
+        // cell update (torch gate order i, f, g, o) and publication of this part's slice of h(step)
+        u64 *dst = hx_base + (long)(step & 1) * LROWS * LH;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float ig = sigmoidf_(acc[0][r]);
+            const float fg = sigmoidf_(acc[1][r]);
+            const float gg = tanhf(acc[2][r]);
+            const float og = sigmoidf_(acc[3][r]);
+            c[r] = fg * c[r] + ig * gg;
+            const float h = og * tanhf(c[r]);
+            const int row = 4 * kq + r;
+            __hip_atomic_store(dst + (long)row * LH + unit, ((u64)(unsigned)(step + 1) << 32) | __builtin_bit_cast(unsigned, h),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int b = b0 + row;
+            if (b < B) out[((long)b * T + t) * (2 * LH) + dir * LH + unit] = h;
+        }
+        __syncthreads();                                  // hbuf is rewritten at the top of the next step
+        if (!ok) break;                                   // (the partners time out too)
+    }
+}
+
 // one wave per row: online max / sum-exp / first arg-max
 __global__ __launch_bounds__(256) void ctc_greedy_kernel(const float *__restrict__ x, int rows, int C, int ld, int is_prob,
                                                          int *__restrict__ idx_out, float *__restrict__ prob_out) {
@@ -192,13 +304,59 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float *__restri
 
 using namespace ptocr;
 
+static int *g_lstm_err_host = nullptr;     // pinned copy of the split kernel's timeout word (last call)
+
 extern "C" int ptocr_lstm_bidir_f32(const float *d_xproj, const float *d_whh, float *d_out, int T, int B, int H, void *stream) {
     PT_CHECK(d_xproj && d_whh && d_out && T >= 1 && B >= 1, "ptocr_lstm_bidir_f32: bad arguments");
     PT_CHECK(H == LH, "ptocr_lstm_bidir_f32: hidden size must be %d (got %d)", LH, H);
     const long x_bytes = (long)B * T * 2 * 4 * LH * 4;
     PT_CHECK(x_bytes < (1L << 31), "ptocr_lstm_bidir_f32: B*T too large (projection tensor must stay below 2 GiB)");
-    hipLaunchKernelGGL(lstm_bidir_kernel, dim3(cdiv(B, LROWS), 2), dim3(256), 0, (hipStream_t)stream, d_xproj, d_whh, d_out, T, B, x_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const int groups = cdiv(B, LROWS);
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        PT_HIP(hipGetDevice(&dev));
+        PT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    static const bool allow_split = !(getenv("PTOCR_LSTM_SPLIT") && atoi(getenv("PTOCR_LSTM_SPLIT")) == 0);
+    // split form: every (group, direction) runs on four CUs with register-resident weights; taken when all workgroups can be
+    // resident at once (one per CU), otherwise the one-workgroup-per-group form, which needs no exchange
+    if (allow_split && groups * 2 * LPARTS <= n_cu && T < (1 << 30)) {
+        static u64 *hx = nullptr;
+        static int *err = nullptr;
+        static int hx_groups = 0;
+        if (groups > hx_groups) {
+            if (hx) (void)hipFree(hx);
+            PT_HIP(hipMalloc(&hx, sizeof(u64) * (size_t)groups * 2 * 2 * LROWS * LH));
+            hx_groups = groups;
+        }
+        if (!err) {
+            PT_HIP(hipMalloc(&err, 64));
+            PT_HIP(hipHostMalloc(reinterpret_cast<void **>(&g_lstm_err_host), 64, hipHostMallocDefault));
+            *g_lstm_err_host = 0;
+        }
+        PT_CHECK(*(volatile int *)g_lstm_err_host == 0, "ptocr_lstm_bidir_f32: an earlier call's hidden-state exchange between workgroups timed out "
+                                        "(results of that call are invalid; set PTOCR_LSTM_SPLIT=0)");
+        PT_HIP(hipMemsetAsync(hx, 0, sizeof(u64) * (size_t)groups * 2 * 2 * LROWS * LH, s));       // tags must not survive a call
+        PT_HIP(hipMemsetAsync(err, 0, 64, s));
+        hipLaunchKernelGGL(lstm_bidir_split_kernel, dim3(LPARTS, groups, 2), dim3(256), 0, s, d_xproj, d_whh, d_out, hx, err, T, B, x_bytes);
+        if (int e = launch_ok("lstm_bidir_split_kernel")) return e;
+        // The timeout word is fetched into pinned memory behind the kernel and examined by the NEXT call on this path (and by
+        // ptocr_lstm_check) -- a synchronous check here would drain the launch queue twice per forward pass.
+        PT_HIP(hipMemcpyAsync(g_lstm_err_host, err, sizeof(int), hipMemcpyDeviceToHost, s));
+        return 0;
+    }
+    hipLaunchKernelGGL(lstm_bidir_kernel, dim3(groups, 2), dim3(256), 0, s, d_xproj, d_whh, d_out, T, B, x_bytes);
     return launch_ok("lstm_bidir_kernel");
+}
+
+// 0 when no split-LSTM call has timed out; meaningful once the stream the calls went to has been synchronised
+extern "C" int ptocr_lstm_check(void) {
+    PT_CHECK(!g_lstm_err_host || *(volatile int *)g_lstm_err_host == 0,
+             "ptocr_lstm_check: the hidden-state exchange between the workgroups of a split LSTM call timed out (its results are "
+             "invalid; set PTOCR_LSTM_SPLIT=0)");
+    return 0;
 }
 
 extern "C" int ptocr_ctc_greedy_f32(const float *d_x, int rows, int C, int ld, int is_prob, int32_t *d_idx, float *d_prob,

@@ -328,6 +328,11 @@ def lstm_bidir(xproj, w_hh, B, T):
     return out
 
 
+def lstm_check():
+    """raises if a split-LSTM call's inter-workgroup exchange timed out (call after the stream was synchronised)"""
+    _lib.check(_lib.lib().ptocr_lstm_check(), "ptocr_lstm_check")
+
+
 def ctc_greedy(x, C, is_prob):
     """x f32[rows, ld] -> (idx int32[rows], prob f32[rows])"""
     _require_cuda(x, "ctc_greedy")

@@ -94,6 +94,7 @@ class CTCLabelDecode(BaseRecLabelDecode):
             idx, prob = ops.ctc_greedy(x, Cn, is_prob=True)
             preds_idx = idx.reshape(T, B).cpu().numpy().T
             preds_prob = prob.reshape(T, B).cpu().numpy().T
+        ops.lstm_check()                    # the copies above synchronised the stream: a timed-out LSTM exchange surfaces here
         text = self.decode(preds_idx, preds_prob, is_remove_duplicate=True)
         if label is None:
             return text

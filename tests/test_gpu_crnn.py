@@ -35,7 +35,9 @@ def test_lstm_kernel_matches_torch():
     from pytorchocr_amd.modeling import ops
     from pytorchocr_amd.modeling.necks.rnn import BidirectionalLSTM
     torch.manual_seed(0)
-    for B, T, nin in ((3, 7, 64), (37, 21, 512)):
+    # (512, 81): every CU holds one workgroup of the split recurrence (4 workgroups per 16 lines and direction exchanging h
+    # each step); (520, 9): more groups than that, so the one-workgroup-per-group form runs
+    for B, T, nin in ((3, 7, 64), (37, 21, 512), (512, 81, 256), (520, 9, 64)):
         blk = BidirectionalLSTM(nin, 256, 256).eval()
         x = torch.randn(T, B, nin)
         with torch.no_grad():
