@@ -178,7 +178,9 @@ int ptocr_linear_f32(const float *d_x, const float *d_w, const float *d_bias, fl
  * d_whh f32[2][4H][H] (weight_hh_l0, weight_hh_l0_reverse); d_out f32[B][T][2H] (forward half | backward half). */
 int ptocr_lstm_bidir_f32(const float *d_xproj, const float *d_whh, float *d_out, int T, int B, int H, void *stream);
 /* When every (16-line group, direction) can own four CUs the recurrence runs split over four workgroups that exchange h each
- * time step (bounded spins).  A timed-out exchange is reported by the next ptocr_lstm_bidir_f32 call and by this function,
+ * time step (bounded spins) through a library-owned buffer: calls on that path must not run concurrently on two streams of
+ * one process (PTOCR_LSTM_SPLIT=0 selects the exchange-free form).  A timed-out exchange is reported by the next
+ * ptocr_lstm_bidir_f32 call and by this function,
  * which is meaningful after the stream has been synchronised (e.g. after the label ids were copied to the host). */
 int ptocr_lstm_check(void);
 /* Per row of d_x f32[rows][ld] (first C columns valid, ld % 4 == 0): first arg-max and the max softmax probability.
