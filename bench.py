@@ -33,6 +33,16 @@ DET_R18 = dict(model_type="det", algorithm="DB", Transform=None,
                Backbone=dict(name="ResNet", layers=18, pretrained=False),
                Neck=dict(name="FPN", out_channels=256, mode="DB", use_asf=False, attention_type="scale_channel_spatial"),
                Head=dict(name="DBHead", k=50))
+# the other detectors of SURVEY 8a, for tools / DESIGN numbers only (--det-model); the metric is DBNet-r18
+DET_VARIANTS = {
+    "r18": (DET_R18, "det_r18_db", 114.195),
+    "r18pp": (dict(DET_R18, Neck=dict(name="FPN", out_channels=256, mode="DB", use_asf=True, attention_type="scale_channel_spatial")),
+              "detpp_r18_db", 131.59),
+    "mbv3s": (dict(model_type="det", algorithm="DB", Transform=None,
+                   Backbone=dict(name="MobileNetV3", model_name="small", scale=1.0, pretrained=False),
+                   Neck=dict(name="FPN", out_channels=96, mode="DB", use_asf=False), Head=dict(name="DBHead", k=50)),
+              "det_mbv3s_db", 8.43),
+}
 DET_POST = dict(name="DBPostProcess", thresh=0.3, box_thresh=0.5, max_candidates=1000, unclip_ratio=1.7,
                 score_mode="poly", cpp_speedup=True, out_polygon=False)
 
@@ -106,7 +116,8 @@ def run_det(args, rank, local, world, device):
     from pytorchocr_amd.postprocess import build_post_process
     from pytorchocr_amd.utils.synth import synth_images, synth_prob_maps
     B, H, W = args.batch, 736, 1280
-    model = build_and_sync_weights(DET_R18, "det_r18_db", device, rank, world)
+    det_cfg, det_contract, _ = DET_VARIANTS[args.det_model]
+    model = build_and_sync_weights(det_cfg, det_contract, device, rank, world)
     post = build_post_process(DET_POST, dict(use_gpu=True, seed=2022))
     # synthetic images: a few distinct seeded images tiled to the batch (the generator is slow on the host)
     base = synth_images(4, 3, H, W, seed=2022 + rank)
@@ -179,7 +190,7 @@ def run_det(args, rank, local, world, device):
             co = int(lab.split("->")[1].split()[0])
             wino_ms += t; n_wino += 1
             wino_flops += 2.0 * n_ * h_ * w_ * ci * co * 9
-    conv_flops = (DET_GFLOP_PER_IMG - DET_TAIL_GFLOP_PER_IMG) * 1e9 * B * args.steps
+    conv_flops = (DET_VARIANTS[args.det_model][2] - DET_TAIL_GFLOP_PER_IMG) * 1e9 * B * args.steps
     conv_all = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     achieved = wino_flops / (wino_ms * 1e-3) / 1e12 if wino_ms > 0 else 0.0
     cpu = det_cpu_baseline(args.cpu_images, H, W) if world == 1 and args.cpu_images > 0 else None
@@ -189,7 +200,8 @@ def run_det(args, rank, local, world, device):
         with open(tp) as f:
             traffic = json.load(f).get("hbm_bytes_per_launch")
     line = {
-        "metric": "images/sec end-to-end (DBNet-r18 det+post, 736x1280)",
+        "metric": "images/sec end-to-end (DBNet-r18 det+post, 736x1280)" if args.det_model == "r18"
+                  else "images/sec end-to-end (%s det+post, 736x1280; NOT the BASELINE metric)" % args.det_model,
         "value": round(world * B * args.steps / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -270,6 +282,9 @@ def main():
                     help="maps post-processed inside the timed step: the model's own maps (true data flow; random weights "
                          "give noise-like maps), text-like stress maps with ~130 boxes per image, or both (default: "
                          "strictly more work than the real pipeline); none = forward only, a diagnostic that is NOT the metric")
+    ap.add_argument("--det-model", default="r18", choices=sorted(DET_VARIANTS),
+                    help="r18 = BASELINE configs[1] (the metric); r18pp (DB++ / ASF) and mbv3s (MobileNetV3-small, fp32) are the "
+                         "other detectors of the hot path, timed for DESIGN.md only")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false",
                     help="run the post-process synchronously after each forward instead of overlapping it with the next batch")
     ap.add_argument("--cpu-images", type=int, default=8, help="images in the CPU-baseline sample (0 = skip)")

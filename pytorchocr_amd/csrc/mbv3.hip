@@ -41,12 +41,28 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float *__restrict__ x
 
 constexpr int SE_PIX = 2048;
 
-// partial sums over pixel chunks: block = (C/4 channel quads) x (256 / (C/4)) pixel lanes, deterministic tree per block
+// partial sums over pixel chunks: block = (C/4 channel quads) x (L = 256 / (C/4) pixel lanes); lane pl sums pixels p0 + pl,
+// p0 + pl + L, ... (coalesced along channels), the L partial sums meet in LDS in a fixed order (deterministic)
 __global__ __launch_bounds__(256) void se_pool_kernel(const float *__restrict__ x, float *__restrict__ partial, int HW, int C, int nblk) {
+    __shared__ f32x4 red[256];
     const int n = blockIdx.y, blk = blockIdx.x;
     const int C4 = C >> 2;
     const int p0 = blk * SE_PIX, p1 = min(p0 + SE_PIX, HW);
-    // thread t handles channel quads q = t, t+256, ... (C4 may exceed 256) over all pixels of the chunk: coalesced along channels
+    if (C4 <= 256) {
+        const int L = 256 / C4;
+        const int q = threadIdx.x % C4, pl = threadIdx.x / C4;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (pl < L)
+            for (int p = p0 + pl; p < p1; p += L) s += *reinterpret_cast<const f32x4 *>(x + ((long)n * HW + p) * C + q * 4);
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (pl == 0) {
+            for (int l = 1; l < L; l++) s += red[l * C4 + q];
+            *reinterpret_cast<f32x4 *>(partial + ((long)n * nblk + blk) * C + q * 4) = s;
+        }
+        return;
+    }
+    // more than 1024 channels: thread t handles channel quads q = t, t+256, ... over all pixels of the chunk
     for (int q = threadIdx.x; q < C4; q += 256) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
         for (int p = p0; p < p1; p++) s += *reinterpret_cast<const f32x4 *>(x + ((long)n * HW + p) * C + q * 4);
