@@ -81,6 +81,10 @@ int ptocr_conv7x7s2_stem_f32(const float *d_x, const float *d_w, const float *d_
  * x2 AFTER the activation (fpn.py:133-134).  Output channels [out_coff, out_coff+Cout) of a tensor with channel stride out_ldc. */
 int ptocr_conv1x1_k64_f32(const float *d_x, const float *d_w, const float *d_bias, const float *d_res, float *d_y,
                           int N, int H, int W, int Cout, int relu, int res_up2, int out_ldc, int out_coff, void *stream);
+/* CRNN conv0 + relu0 + pooling0 fused (rec_vgg.py:78-88): y f32[N,H/2,W/2,64] = maxpool2x2(relu(conv3x3/s1/p1(x) + bias)) for an
+ * input with 1..4 channels stored as f32[N,H,W,4]; d_w f32[Cin*9][64], row (ci*3 + ky)*3 + kx (BN folded). */
+int ptocr_conv3x3_small_relu_pool_f32(const float *d_x, const float *d_w, const float *d_bias, float *d_y, int N, int H, int W,
+                                      int Cin, void *stream);
 /* Measurement hook (no reference counterpart): d_buf = device u64[4 * workgroups] receives s_memtime samples (start, main
  * loop start, main loop end, end) from every Winograd workgroup launched afterwards; NULL switches the probe off. */
 void ptocr_wino_set_timing_buffer(void *d_buf);

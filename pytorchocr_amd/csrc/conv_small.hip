@@ -1,0 +1,87 @@
+// CRNN's first layer, fused: conv 3x3 / s1 / p1 with 1..4 input channels -> 64 channels + bias + ReLU + 2x2/s2 max pool.
+// Replaces conv0 + relu0 + pooling0 of rec_vgg.py:78-88 (ATen conv2d, relu_, max_pool2d).
+//
+// With K = 9 the layer has no matrix work to speak of (6.7 GFLOP for 512 lines) -- it is bound by writing its output, and
+// the unfused form (implicit GEMM with the gray channel padded to 4, then the pool kernel) writes the 1.34 GB full-resolution
+// tensor and reads it back: 0.94 ms.  Here a thread owns one POOLED pixel and 4 output channels: it reads the 4x4 input patch
+// (16-byte pixels of the NHWC4 image, shared by the 16 lanes of the pixel), evaluates the four convolution outputs of the
+// pool window on the VALU (weights in LDS) and stores 16 bytes; 16 lanes write one pixel's 256 contiguous bytes.
+#include "common.h"
+
+namespace ptocr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// w: f32[Cin*9][64] ((ci*3 + ky)*3 + kx major, cout minor; BN folded), bias f32[64]
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_small_pool_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                                 const float *__restrict__ bias, float *__restrict__ y,
+                                                                 int N, int H, int W, int Hp, int Wp, long total) {
+    __shared__ __attribute__((aligned(16))) float ws[CIN * 9 * 64];
+    for (int i = threadIdx.x; i < CIN * 9 * 64; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int cq = (int)(idx & 15);
+    long pix = idx >> 4;
+    const int px = (int)(pix % Wp); pix /= Wp;
+    const int py = (int)(pix % Hp);
+    const int n = (int)(pix / Hp);
+    // 4x4 input patch: rows 2py-1 .. 2py+2, columns 2px-1 .. 2px+2 (zero outside the image)
+    float in[CIN][4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int iy = 2 * py - 1 + r, ix = 2 * px - 1 + c;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = *reinterpret_cast<const f32x4 *>(x + (((long)n * H + iy) * W + ix) * 4);
+#pragma unroll
+            for (int ci = 0; ci < CIN; ci++) in[ci][r][c] = v[ci];
+        }
+    f32x4 acc[2][2];
+    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias + cq * 4);
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = b4;
+#pragma unroll
+    for (int ci = 0; ci < CIN; ci++)
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) {
+                const f32x4 wv = *reinterpret_cast<const f32x4 *>(&ws[((ci * 3 + ky) * 3 + kx) * 64 + cq * 4]);
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int b = 0; b < 2; b++) acc[a][b] += wv * in[ci][a + ky][b + kx];
+            }
+    f32x4 m;
+#pragma unroll
+    for (int k = 0; k < 4; k++) m[k] = fmaxf(fmaxf(fmaxf(acc[0][0][k], acc[0][1][k]), fmaxf(acc[1][0][k], acc[1][1][k])), 0.f);
+    *reinterpret_cast<f32x4 *>(y + (((long)n * Hp + py) * Wp + px) * 64 + cq * 4) = m;
+}
+
+}  // namespace ptocr
+
+using namespace ptocr;
+
+// d_x: f32[N,H,W,4] (channels >= Cin ignored); d_w: f32[Cin*9][64], row (ci*3 + ky)*3 + kx; d_y: f32[N,H/2,W/2,64] =
+// maxpool2x2(relu(conv3x3(x) + bias)).  Cin in 1..4.
+extern "C" int ptocr_conv3x3_small_relu_pool_f32(const float *d_x, const float *d_w, const float *d_bias, float *d_y, int N, int H, int W,
+                                                 int Cin, void *stream) {
+    PT_CHECK(d_x && d_w && d_bias && d_y, "ptocr_conv3x3_small_relu_pool_f32: null argument");
+    PT_CHECK(N > 0 && H >= 2 && W >= 2 && Cin >= 1 && Cin <= 4, "ptocr_conv3x3_small_relu_pool_f32: need H, W >= 2 and 1 <= Cin <= 4");
+    const int Hp = H / 2, Wp = W / 2;
+    const long total = (long)N * Hp * Wp * 16;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    hipStream_t s = (hipStream_t)stream;
+    switch (Cin) {
+        case 1: hipLaunchKernelGGL(conv3x3_small_pool_kernel<1>, grid, dim3(256), 0, s, d_x, d_w, d_bias, d_y, N, H, W, Hp, Wp, total); break;
+        case 2: hipLaunchKernelGGL(conv3x3_small_pool_kernel<2>, grid, dim3(256), 0, s, d_x, d_w, d_bias, d_y, N, H, W, Hp, Wp, total); break;
+        case 3: hipLaunchKernelGGL(conv3x3_small_pool_kernel<3>, grid, dim3(256), 0, s, d_x, d_w, d_bias, d_y, N, H, W, Hp, Wp, total); break;
+        default: hipLaunchKernelGGL(conv3x3_small_pool_kernel<4>, grid, dim3(256), 0, s, d_x, d_w, d_bias, d_y, N, H, W, Hp, Wp, total); break;
+    }
+    return launch_ok("conv3x3_small_pool_kernel");
+}

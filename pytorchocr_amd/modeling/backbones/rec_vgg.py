@@ -43,7 +43,7 @@ class VGG(ops.PackedModule):
         """x4 f32[B,32,W,4] -> f32[B,1,T,512]"""
         self._check_eval()
         p = self.packed()
-        x = ops.conv2d(x4, p[0]); x = ops.maxpool2d(x, 2, 2, 0)
+        x = ops.conv3x3_relu_pool2(x4, p[0])                                   # conv0 + relu0 + pooling0, fused
         x = ops.conv2d(x, p[1]); x = ops.maxpool2d(x, 2, 2, 0)
         x = ops.conv2d(x, p[2])
         x = ops.conv2d(x, p[3]); x = ops.maxpool2d(x, (2, 2), (2, 1), (0, 1))

@@ -19,6 +19,8 @@ USE_WINOGRAD = _os.environ.get("PTOCR_WINOGRAD", "1") != "0"
 USE_STEM_KERNEL = _os.environ.get("PTOCR_STEM_KERNEL", "1") != "0"
 # 1x1 convolutions with 64 input channels run in the LDS-resident-weights kernel unless PTOCR_PW64_KERNEL=0
 USE_PW64_KERNEL = _os.environ.get("PTOCR_PW64_KERNEL", "1") != "0"
+# CRNN's conv0 + ReLU + 2x2 pool run fused on the VALU unless PTOCR_SMALL_CONV_KERNEL=0
+USE_SMALL_CONV_KERNEL = _os.environ.get("PTOCR_SMALL_CONV_KERNEL", "1") != "0"
 
 
 def _require_cuda(t, what):
@@ -82,6 +84,13 @@ class PackedConv:
         self.pad_h, self.pad_w = conv.padding
         self.relu = _act_code(relu)
         self.convt = False
+        # 3x3 / s1 / p1 layers with <= 4 input channels and 64 outputs followed by ReLU (CRNN conv0): w[(ci*3+ky)*3+kx][cout]
+        self.small_w = None
+        if (kh, kw) == (3, 3) and self.stride == 1 and (self.pad_h, self.pad_w) == (1, 1) and cin <= 4 and cout == 64 \
+                and self.relu == ACT_RELU:
+            self.small_w = w.permute(1, 2, 3, 0).reshape(cin * 9, 64).contiguous().float().to(device)
+            self.small_b = b.float().contiguous().to(device)
+            self.small_cin = cin
         # pointwise layers with 64 input channels (the FPN lateral in2): W[k][cout], k-major, for the LDS-resident-weights kernel
         self.pw_w = None
         if (kh, kw) == (1, 1) and self.stride == 1 and (self.pad_h, self.pad_w) == (0, 0) and cin == 64 and cout % 32 == 0 \
@@ -325,6 +334,20 @@ def lstm_bidir(xproj, w_hh, B, T):
     out = torch.empty((B * T, 2 * H), dtype=torch.float32, device=xproj.device)
     _lib.check(_lib.lib().ptocr_lstm_bidir_f32(_lib.ptr(xproj), _lib.ptr(w_hh), _lib.ptr(out), T, B, H, _lib.cur_stream()),
                "ptocr_lstm_bidir_f32")
+    return out
+
+
+def conv3x3_relu_pool2(x4, pc):
+    """maxpool2x2(relu(conv3x3(x4) + b)) for a layer with <= 4 input channels and 64 outputs (CRNN conv0 + pooling0), fused:
+    x4 f32[N,H,W,4] -> f32[N,H/2,W/2,64]; falls back to the generic conv + pool kernels when PTOCR_SMALL_CONV_KERNEL=0"""
+    _require_cuda(x4, "conv3x3_relu_pool2")
+    if not USE_SMALL_CONV_KERNEL or getattr(pc, "small_w", None) is None or x4.shape[3] != 4:
+        return maxpool2d(conv2d(x4, pc), 2, 2, 0)
+    N, H, W, _ = x4.shape
+    out = torch.empty((N, H // 2, W // 2, 64), dtype=torch.float32, device=x4.device)
+    _lib.check(_lib.lib().ptocr_conv3x3_small_relu_pool_f32(_lib.ptr(x4), _lib.ptr(pc.small_w), _lib.ptr(pc.small_b), _lib.ptr(out),
+                                                            N, H, W, pc.small_cin, _lib.cur_stream()),
+               "ptocr_conv3x3_small_relu_pool_f32")
     return out
 
 

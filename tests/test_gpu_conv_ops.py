@@ -306,3 +306,28 @@ def test_pointwise_k64_kernel(case):
     big = big.cpu()
     assert (big[..., 32:32 + Cout].permute(0, 3, 1, 2) - ref).abs().max().item() <= tol
     assert float((big[..., :32] - 3).abs().max()) == 0 and float((big[..., 32 + Cout:] - 3).abs().max()) == 0
+
+
+@pytest.mark.parametrize("cin,shape", [(1, (3, 32, 320)), (3, (2, 32, 100)), (1, (2, 9, 15))])
+def test_small_cin_conv_relu_pool_fused(cin, shape):
+    """CRNN conv0 + relu0 + pooling0 in one kernel vs torch fp32 (and vs the unfused generic kernels), odd sizes included"""
+    from pytorchocr_amd.modeling import ops
+    N, H, W = shape
+    dev = _dev()
+    conv = nn.Conv2d(cin, 64, 3, 1, 1)
+    with torch.no_grad():
+        conv.weight.copy_(_rand(64, cin, 3, 3, seed=1) * 0.4); conv.bias.copy_(_rand(64, seed=2) * 0.3)
+    x = _rand(N, cin, H, W, seed=7)
+    with torch.no_grad():
+        ref = F.max_pool2d(F.relu(conv(x)), 2, 2)
+    pc = ops.PackedConv(conv, None, dev, relu=True, cin_pad=4)
+    assert pc.small_w is not None
+    x4 = ops.nchw_to_nhwc(x.to(dev), 4)
+    tol = 2e-5 * max(1.0, ref.abs().max().item())
+    for use in (True, False):
+        ops.USE_SMALL_CONV_KERNEL = use
+        try:
+            y = ops.conv3x3_relu_pool2(x4, pc).cpu().permute(0, 3, 1, 2)
+        finally:
+            ops.USE_SMALL_CONV_KERNEL = True
+        assert y.shape == ref.shape and (y - ref).abs().max().item() <= tol, use

@@ -174,3 +174,22 @@ def test_stem_and_pointwise_pack_layouts():
     pc1 = ops.PackedConv(conv1, None, torch.device("cpu"), relu=True)
     assert pc1.pw_w is not None and tuple(pc1.pw_w.shape) == (64, 96)
     assert torch.allclose(pc1.pw_w, conv1.weight.detach().reshape(96, 64).t())
+
+
+def test_small_cin_conv_pack_layout():
+    """w[(ci*3 + ky)*3 + kx][cout] of the fused conv0 + ReLU + pool kernel reproduces conv + bias"""
+    torch.manual_seed(5)
+    conv = nn.Conv2d(3, 64, 3, 1, 1)
+    x = torch.randn(1, 3, 5, 6)
+    with torch.no_grad():
+        ref = conv(x)[0].numpy()
+    pc = ops.PackedConv(conv, None, torch.device("cpu"), relu=True, cin_pad=4)
+    assert pc.small_w is not None and tuple(pc.small_w.shape) == (27, 64) and pc.small_cin == 3
+    w = pc.small_w.numpy().astype(np.float64)
+    xp = np.pad(x[0].numpy().astype(np.float64), ((0, 0), (1, 1), (1, 1)))
+    out = np.zeros((64, 5, 6))
+    for oy in range(5):
+        for ox in range(6):
+            out[:, oy, ox] = xp[:, oy:oy + 3, ox:ox + 3].reshape(27) @ w
+    out += pc.small_b.numpy()[:, None, None]
+    assert np.abs(out - ref).max() < 1e-5
