@@ -111,6 +111,28 @@ def det_cpu_baseline(n_img, H, W):
                       "(single thread, like the GIL-bound reference extension)" % (n_img, H, W, t_model / n_img, t_post / n_img)}
 
 
+def crnn_cpu_baseline(n_lines):
+    """The oracle (torch-CPU fp32 CRNN forward + the reference's CTCLabelDecode restatement) on a bounded sample of lines,
+    one batch of 16 at a time."""
+    from oracle import ctc_oracle, model_oracle
+    from pytorchocr_amd.utils.synth import synth_state_dict, synth_text_lines
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    sd = {k: torch.from_numpy(v) for k, v in synth_state_dict(load_contract("rec_vgg_bilstm_ctc")).items()}
+    chars = ctc_oracle.load_characters(os.path.join(ROOT, "pytorchocr_amd", "utils", "char_dict_6623.txt"))
+    x = torch.from_numpy(synth_text_lines(16, 32, 320, seed=2022))
+    model_oracle.crnn_forward(sd, x[:2])                               # warm-up of the thread pool
+    t0 = time.perf_counter()
+    done = 0
+    while done < n_lines:
+        probs = model_oracle.crnn_forward(sd, x).numpy()
+        ctc_oracle.ctc_label_decode(probs, chars)
+        done += 16
+    dt = time.perf_counter() - t0
+    return {"value": round(done / dt, 3), "unit": "text-lines/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d lines 32x320 in batches of 16: torch-CPU fp32 forward + softmax + CTCLabelDecode restatement, %.1f ms/line"
+                      % (done, dt / done * 1e3)}
+
+
 def run_det(args, rank, local, world, device):
     from pytorchocr_amd.modeling import ops
     from pytorchocr_amd.postprocess import build_post_process
@@ -267,7 +289,7 @@ def run_crnn(args, rank, local, world, device):
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                      "kernel": "whole step (end-to-end FLOP rate; per-kernel split in profiles/)"},
-        "cpu_baseline": None,
+        "cpu_baseline": crnn_cpu_baseline(args.cpu_lines) if world == 1 and args.cpu_lines > 0 else None,
     }
 
 
@@ -288,6 +310,7 @@ def main():
     ap.add_argument("--no-overlap", dest="overlap", action="store_false",
                     help="run the post-process synchronously after each forward instead of overlapping it with the next batch")
     ap.add_argument("--cpu-images", type=int, default=8, help="images in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-lines", type=int, default=256, help="text lines in the CRNN CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
     if args.batch == 0:
         args.batch = 32 if args.workload == "det" else 512

@@ -8,7 +8,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/det -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-images 0 > $O/bench_det_stdout.log 2>&1
 cp $(ls $O/det/*/*kernel_stats.csv | head -1) $O/bench_det_b32_kernel_stats.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/crnn -- python3 $R/bench.py --workload crnn --steps 5 --warmup 2 > $O/bench_crnn_stdout.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/crnn -- python3 $R/bench.py --workload crnn --steps 5 --warmup 2 --cpu-lines 0 > $O/bench_crnn_stdout.log 2>&1
 cp $(ls $O/crnn/*/*kernel_stats.csv | head -1) $O/bench_crnn_b512_kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-images 0 > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-images 0 > $O/pmc_write.log 2>&1
