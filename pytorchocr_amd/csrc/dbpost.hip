@@ -953,7 +953,7 @@ __device__ void contour_body(int img, int k, const float *__restrict__ maps, con
     // at most the diagonal of the bounding box; a diagonal <= sqrt(8) means ssid < 3 (db_postprocess.cpp:265) without
     // computing the rectangle.  Noise maps are made of thousands of such borders.
     if ((bw - 1) * (bw - 1) + (bh - 1) * (bh - 1) <= 8) { if (tid == 0) res->status = ST_SKIP_SSID; return; }
-    if (SMALL && (bw > MW || (long)((bw + 31) >> 5) * bh > PLANE)) { if (tid == 0) res->status = ST_DEFER; return; }
+    if (SMALL && (bw > MW || (long)((bw + 31) >> 5) * bh > PLANE)) { if (tid == 0) { res->status = ST_DEFER; atomicOr(&flags[img], 8); } return; }
 
     // LDS arena: column tables (hull phase) and mask planes (score phase) are never live together
     constexpr int ARENA = 2 * PLANE > 3 * MW ? 2 * PLANE : 3 * MW;
@@ -1052,7 +1052,7 @@ __device__ void contour_body(int img, int k, const float *__restrict__ maps, con
     // ---- 3. min-area rect of the border, mini-box, first size filter (lane 0; a few dozen vertices)
     if (tid == 0) {
         int status = ST_OK;
-        if (sh_n > MH) { if (SMALL) status = ST_DEFER; else { atomicOr(&flags[img], 4); status = ST_NONE; } }
+        if (sh_n > MH) { if (SMALL) { status = ST_DEFER; atomicOr(&flags[img], 8); } else { atomicOr(&flags[img], 4); status = ST_NONE; } }
         else {
             const RRect box = min_area_rect_sorted(cand_pts, sh_n, hull_pts, stack, cal_scratch);
             float ssid;
@@ -1114,7 +1114,7 @@ __device__ void contour_body(int img, int k, const float *__restrict__ maps, con
     for (int i = 0; i < 4; i++) { path[i].X = (long long)(int)sh_mini[i][0]; path[i].Y = (long long)(int)sh_mini[i][1]; }
     const int np = clipper_offset_round(path, (double)distance, cand_pts, MH);
     RRect ub;
-    if (np > MH) { if (SMALL) res->status = ST_DEFER; else { atomicOr(&flags[img], 4); res->status = ST_NONE; } return; }
+    if (np > MH) { if (SMALL) { res->status = ST_DEFER; atomicOr(&flags[img], 8); } else { atomicOr(&flags[img], 4); res->status = ST_NONE; } return; }
     if (np <= 0) { ub.cx = 0; ub.cy = 0; ub.w = 1; ub.h = 1; ub.angle = 0; }
     else {
         for (int i = 1; i < np; i++) {                          // sort by (x, y) like cv::convexHull
@@ -1174,6 +1174,7 @@ __global__ __launch_bounds__(CT_THREADS, 1) void contour_big_kernel(const float 
                                                                     float box_thresh, float unclip_ratio, long slot_words,
                                                                     int use_padding_resize, DbpostDims d) {
     const int img = blockIdx.y;
+    if (!(flags[img] & 8)) return;                        // internal bit 3: the small pass deferred at least one border of this image
     const int num = min(totals[img], MAX_CAND);
     for (int k = blockIdx.x; k < num; k += gridDim.x) {
         if (results[(long)img * MAX_CAND + k].status != ST_DEFER) continue;       // uniform over the workgroup
@@ -1332,6 +1333,7 @@ extern "C" int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, co
     PT_HIP(hipMemcpyAsync(h_flags, h->flags, sizeof(int) * N, hipMemcpyDeviceToHost, s));
     PT_HIP(hipMemcpyAsync(h_boxes, h->boxes, sizeof(short) * 8 * (size_t)N * max_boxes, hipMemcpyDeviceToHost, s));
     PT_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < N; i++) h_flags[i] &= 7;           // bit 3 is internal (deferred borders)
     for (int i = 0; i < N; i++)
         if (h_flags[i] & 4) return fail("ptocr_db_postprocess: internal capacity exceeded on image %d (point pool %ld points or hull "
                                         "candidates %d)", i, h->pool_cap, MAXHULL);
