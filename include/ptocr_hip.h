@@ -64,13 +64,14 @@ int ptocr_conv2d_f32(const ptocr_conv_desc *d, const float *d_x, const float *d_
                      const float *d_res, float *d_y, void *stream);
 
 /* 3x3 / stride 1 / pad 1 convolution by Winograd F(2x2,3x3) on fp32 MFMA (2.25x fewer multiplies, fp32 accuracy).
- * d_u: host-transformed weights U = G g G^T (BN folded), packed f32[Cout/64][Cin/4][16][64][4]; Cin % 16 == 0, Cout % 64 == 0.
+ * d_u: host-transformed weights U = G g G^T (BN folded), packed f32[Cout/64][Cin/4][16][64][4]; Cin % 16 == 0, Cout % 64 == 0
+ * (zero-pad the weights and the bias of a narrower layer; cout_store = channels actually written, a multiple of 4, 0 = Cout).
  * Epilogue: bias, optional pre-ReLU residual (d_res f32[N,H,W,res_ldc]), optional ReLU, store into channels
  * [out_coff, out_coff+Cout) of a tensor with channel stride out_ldc; up > 1 (<= 8, no residual) stores every output pixel
  * to an up x up block of y f32[N,H*up,W*up,out_ldc] (nearest upsample, fpn.py:125-133). */
 int ptocr_conv3x3_wino_f32(const float *d_x, const float *d_u, const float *d_bias, const float *d_res, float *d_y,
-                           int N, int H, int W, int Cin, int Cout, int relu, int res_mode, int res_ldc, int out_ldc,
-                           int out_coff, int up, void *stream);
+                           int N, int H, int W, int Cin, int Cout, int cout_store, int relu, int res_mode, int res_ldc,
+                           int out_ldc, int out_coff, int up, void *stream);
 /* ResNet stem: conv 7x7 / stride 2 / pad 3 of an RGB image stored as f32[N,H,W,4] (4th channel ignored) -> f32[N,Ho,Wo,64],
  * Ho = (H-1)/2+1, Wo = (W-1)/2+1, + bias (folded BN) + optional ReLU (det_resnet.py:193-196).  d_w: f32[7][22][64],
  * w[ky][kx*3 + c][cout], row [ky][21] all zero (K runs over 7 x 22 = 154 instead of the generic kernel's 7*7*4 = 196). */

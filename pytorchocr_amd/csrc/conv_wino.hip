@@ -45,6 +45,7 @@ struct WinoArgs {
     int N, H, W, Cin, Cout;                // stride 1, pad 1: output H x W
     int tiles_x, tiles_y;                  // patches per image group (TN images)
     int relu, res_mode, out_ldc, out_coff, res_ldc, up;
+    int cout_store;                        // output channels actually stored (weights may be zero-padded to a multiple of 64)
     int total;                             // patches x image groups x (Cout / 64)
     long x_bytes, u_bytes;
     unsigned long long *dbg;               // timing probe (ptocr_wino_set_timing_buffer): 4 clock samples per workgroup, or null
@@ -301,6 +302,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs p) {
 #pragma unroll
             for (int w = 0; w < 8; w++) t[w] = *reinterpret_cast<const f32x4 *>(ex + (w * 64 + tile) * W_EL + cq * 4);
             const int col = n0 + cq * 4;
+            if (col >= p.cout_store) continue;                  // channels of the zero padding
             const f32x4 bias4 = *reinterpret_cast<const f32x4 *>(p.bias + col);
             const f32x4 mid = t[2] + t[3];
             const f32x4 y0 = ((t[0] + t[1]) + mid) + (t[4] + t[5]);
@@ -356,23 +358,26 @@ static unsigned long long *g_wino_dbg = nullptr;
 // debug: device buffer of 4 clock samples per workgroup (start, main loop start, main loop end, end); null switches it off
 extern "C" void ptocr_wino_set_timing_buffer(void *d_buf) { g_wino_dbg = (unsigned long long *)d_buf; }
 
-// d_u: weights transformed on the host, packed f32[Cout/64][Cin/4][16][64][4] (U = G g G^T per (cout, cin), BN folded).
+// d_u: weights transformed on the host, packed f32[Cout/64][Cin/4][16][64][4] (U = G g G^T per (cout, cin), BN folded); Cout may be
+// zero-padded to a multiple of 64, then only channels < cout_store (a multiple of 4; 0 = Cout) are stored and d_bias has Cout entries.
 // up > 1 writes every output pixel up x up times (nearest upsample) into y[N][H*up][W*up][out_ldc].
 extern "C" int ptocr_conv3x3_wino_f32(const float *d_x, const float *d_u, const float *d_bias, const float *d_res, float *d_y,
-                                      int N, int H, int W, int Cin, int Cout, int relu, int res_mode, int res_ldc, int out_ldc,
-                                      int out_coff, int up, void *stream) {
+                                      int N, int H, int W, int Cin, int Cout, int cout_store, int relu, int res_mode, int res_ldc,
+                                      int out_ldc, int out_coff, int up, void *stream) {
     PT_CHECK(d_x && d_u && d_bias && d_y, "ptocr_conv3x3_wino_f32: null argument");
     PT_CHECK(N > 0 && H > 0 && W > 0, "ptocr_conv3x3_wino_f32: empty tensor");
     PT_CHECK(Cin % 16 == 0 && Cout % 64 == 0, "ptocr_conv3x3_wino_f32: need Cin %% 16 == 0 and Cout %% 64 == 0");
     PT_CHECK(relu == 0 || relu == 1, "ptocr_conv3x3_wino_f32: activation must be none or ReLU");
     PT_CHECK(res_mode == PTOCR_RES_NONE || (res_mode == PTOCR_RES_ADD_PRE_RELU && d_res), "ptocr_conv3x3_wino_f32: only the pre-ReLU residual add is fused");
     PT_CHECK(up >= 1 && up <= 8 && (up == 1 || res_mode == PTOCR_RES_NONE), "ptocr_conv3x3_wino_f32: up must be 1..8 and excludes the residual");
-    PT_CHECK(out_ldc % 4 == 0 && out_coff % 4 == 0 && out_ldc >= out_coff + Cout && (res_mode == 0 || res_ldc % 4 == 0), "ptocr_conv3x3_wino_f32: channel strides must be multiples of 4");
+    if (cout_store <= 0) cout_store = Cout;
+    PT_CHECK(cout_store <= Cout && cout_store % 4 == 0, "ptocr_conv3x3_wino_f32: cout_store must be a multiple of 4 and <= Cout");
+    PT_CHECK(out_ldc % 4 == 0 && out_coff % 4 == 0 && out_ldc >= out_coff + cout_store && (res_mode == 0 || res_ldc % 4 == 0), "ptocr_conv3x3_wino_f32: channel strides must be multiples of 4");
     WinoArgs a;
     a.x = d_x; a.u = d_u; a.bias = d_bias; a.res = d_res; a.y = d_y;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.relu = relu; a.res_mode = res_mode; a.out_ldc = out_ldc; a.out_coff = out_coff; a.res_ldc = res_ldc > 0 ? res_ldc : Cout;
-    a.up = up;
+    a.up = up; a.cout_store = cout_store;
     a.dbg = g_wino_dbg;
     a.x_bytes = (long)N * H * W * Cin * 4;
     a.u_bytes = (long)Cout * Cin * 16 * 4;

@@ -107,13 +107,18 @@ class PackedConv:
             self.stem_b = b.float().contiguous().to(device)
         # Winograd F(2x2,3x3) form of the same weights for 3x3 / s1 / p1 layers: U = G g G^T, packed [Cout/64][Cin/4][16][64][4]
         self.wino_u = None
-        if (kh, kw) == (3, 3) and self.stride == 1 and (self.pad_h, self.pad_w) == (1, 1) and cin % 16 == 0 and cout % 64 == 0 \
+        if (kh, kw) == (3, 3) and self.stride == 1 and (self.pad_h, self.pad_w) == (1, 1) and cin % 16 == 0 and cout % 4 == 0 \
                 and cin_pad == cin and self.relu in (ACT_NONE, ACT_RELU):
             G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64)
-            U = torch.einsum("ar,ocrs,bs->ocab", G, w, G)                          # [Cout, Cin, 4, 4]
-            U = U.reshape(cout // 64, 64, cin // 4, 4, 16).permute(0, 2, 4, 1, 3)  # [ct, chunk, xi, cout, c4]
+            cw = _rup(cout, 64)                                                    # narrower layers: zero weights up to 64
+            U = torch.zeros(cw, cin, 4, 4, dtype=torch.float64)
+            U[:cout] = torch.einsum("ar,ocrs,bs->ocab", G, w, G)                   # [Cout, Cin, 4, 4]
+            U = U.reshape(cw // 64, 64, cin // 4, 4, 16).permute(0, 2, 4, 1, 3)    # [ct, chunk, xi, cout, c4]
             self.wino_u = U.contiguous().float().to(device)
-            self.wino_b = b.float().contiguous().to(device)
+            bw = torch.zeros(cw, dtype=torch.float64)
+            bw[:cout] = b
+            self.wino_b = bw.float().contiguous().to(device)
+            self.wino_cout = cw
 
 
 class PackedConvT2x2:
@@ -182,13 +187,15 @@ def conv2d(x, pc, res=None, res_mode=RES_NONE, out=None, out_up=1, out_coff=0, s
                 PROFILE_LABELS.append("pw1x1 %dx%dx%dx64->%d" % (N, H, W, pc.cout_real))
         return out
     if USE_WINOGRAD and getattr(pc, "wino_u", None) is not None and (res_mode == RES_NONE or (res_mode == RES_ADD_PRE_RELU and out_up == 1)) \
-            and out_up <= 8 and (store is None or store == pc.cout_real) and N * H * W * Cin * 4 < 2 ** 31:
+            and out_up <= 8 and (store if store is not None else pc.c_tensor) % 4 == 0 and N * H * W * Cin * 4 < 2 ** 31 \
+            and (store if store is not None else pc.c_tensor) <= pc.wino_cout:
+        cs = store if store is not None else pc.c_tensor      # columns written: zero weights / bias beyond the real channels
         if PROFILE is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         _lib.check(_lib.lib().ptocr_conv3x3_wino_f32(_lib.ptr(x), _lib.ptr(pc.wino_u), _lib.ptr(pc.wino_b),
                                                      _lib.ptr(res) if res is not None else C.c_void_p(0), _lib.ptr(out),
-                                                     N, H, W, Cin, pc.cout_real, int(pc.relu), res_mode,
+                                                     N, H, W, Cin, pc.wino_cout, cs, int(pc.relu), res_mode,
                                                      res.shape[3] if res is not None else 0, out.shape[3], out_coff,
                                                      out_up, _lib.cur_stream()), "ptocr_conv3x3_wino_f32")
         if PROFILE is not None:

@@ -331,3 +331,30 @@ def test_small_cin_conv_relu_pool_fused(cin, shape):
         finally:
             ops.USE_SMALL_CONV_KERNEL = True
         assert y.shape == ref.shape and (y - ref).abs().max().item() <= tol, use
+
+
+def test_winograd_narrow_layer_padded_cout():
+    """3x3 96 -> 24 (MobileNetV3's FPN smoothing / head convs): Winograd weights zero-padded to 64 output channels, only the real
+    ones (or the tensor's 32-channel padding, as zeros) are stored; concat slices at 24-channel offsets"""
+    from pytorchocr_amd.modeling import ops
+    dev = _dev()
+    conv = nn.Conv2d(96, 24, 3, 1, 1, bias=False)
+    bn = nn.BatchNorm2d(24).eval()
+    with torch.no_grad():
+        conv.weight.copy_(_rand(24, 96, 3, 3, seed=1) * 0.06)
+        bn.running_mean.copy_(_rand(24, seed=5) * 0.2); bn.running_var.copy_(_rand(24, seed=6) * 0.5 + 1)
+    x = _rand(2, 96, 22, 38, seed=7)
+    with torch.no_grad():
+        ref = F.relu(bn(conv(x)))
+    pc = ops.PackedConv(conv, bn, dev, relu=True)
+    assert pc.wino_u is not None and pc.wino_cout == 64 and pc.c_tensor == 32
+    xd = _nhwc(x).to(dev)
+    tol = 3e-5 * max(1.0, ref.abs().max().item())
+    y = ops.conv2d(xd, pc).cpu()
+    assert y.shape[3] == 32 and float(y[..., 24:].abs().max()) == 0.0
+    assert (y[..., :24].permute(0, 3, 1, 2) - ref).abs().max().item() <= tol
+    fuse = torch.full((2, 44, 76, 96), 3.0, device=dev)
+    ops.conv2d(xd, pc, out=fuse, out_up=2, out_coff=48, store=24)
+    fuse = fuse.cpu()
+    assert (fuse[..., 48:72].permute(0, 3, 1, 2) - F.interpolate(ref, scale_factor=2, mode="nearest")).abs().max().item() <= tol
+    assert float((fuse[..., :48] - 3).abs().max()) == 0 and float((fuse[..., 72:] - 3).abs().max()) == 0
