@@ -178,3 +178,44 @@ def test_use_dilation_and_padding_resize_options():
     z = np.zeros((1, 40, 70), np.float32); z[0, 10, 31] = 0.9; z[0, 0, 0] = 0.9; z[0, 39, 69] = 0.9
     bm = dbpost.dilate2x2(dbpost.binarize(z[0], 0.3))
     assert bm[10:12, 31:33].all() and bm.sum() == 4 + 4 + 1
+
+
+def _random_scene(rng, h, w):
+    """ellipses / rotated boxes / rings / thin strokes / speckle at random scales: exercises borders beyond the quick
+    slot (> 512 points), deferred (wide / large) borders, holes, borders touching the frame and the strip-first labelling"""
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    m = np.full((h, w), 0.05, np.float32)
+    for _ in range(int(rng.integers(3, 40))):
+        cy, cx = rng.uniform(0, h), rng.uniform(0, w)
+        a, b = rng.uniform(2, w / 3), rng.uniform(1, h / 4)
+        th = rng.uniform(0, np.pi)
+        u = (xx - cx) * np.cos(th) + (yy - cy) * np.sin(th)
+        v = -(xx - cx) * np.sin(th) + (yy - cy) * np.cos(th)
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            inside = (u / a) ** 2 + (v / b) ** 2 < 1
+        elif kind == 1:
+            inside = (np.abs(u) < a) & (np.abs(v) < b)
+        elif kind == 2:
+            r = (u / a) ** 2 + (v / b) ** 2
+            inside = (r < 1) & (r > rng.uniform(0.2, 0.8))
+        else:
+            inside = (np.abs(u) < a) & (np.abs(v) < rng.uniform(0.4, 1.6))
+        m[inside] = rng.uniform(0.35, 0.95)
+    if rng.uniform() < 0.5:
+        sp = rng.uniform(size=(h, w)) < rng.uniform(0.0, 0.25)
+        m[sp] = rng.uniform(0.0, 1.0, size=int(sp.sum()))
+    # keep values away from the two thresholds so the comparisons are not rounding-sensitive
+    m = np.where(np.abs(m - 0.3) < 2e-3, 0.31, m)
+    return m.astype(np.float32)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scenes_bit_exact(seed):
+    rng = np.random.default_rng(1000 + seed)
+    h = int(rng.integers(40, 400))
+    w = int(rng.integers(40, 700))
+    n = int(rng.integers(1, 4))
+    maps = np.stack([_random_scene(rng, h, w) for _ in range(n)])
+    src = [[int(rng.integers(20, 2000)), int(rng.integers(20, 2000))] for _ in range(n)]
+    _compare(maps, src, box_thresh=float(rng.choice([0.3, 0.5, 0.7])), ratio=float(rng.choice([1.5, 1.7, 2.0])))
