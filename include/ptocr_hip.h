@@ -82,6 +82,10 @@ int ptocr_conv7x7s2_stem_f32(const float *d_x, const float *d_w, const float *d_
  * x2 AFTER the activation (fpn.py:133-134).  Output channels [out_coff, out_coff+Cout) of a tensor with channel stride out_ldc. */
 int ptocr_conv1x1_k64_f32(const float *d_x, const float *d_w, const float *d_bias, const float *d_res, float *d_y,
                           int N, int H, int W, int Cout, int relu, int res_up2, int out_ldc, int out_coff, void *stream);
+/* The same kernel for Cin = 32 or 64 and act = 0 none / 1 ReLU / 2 Hardswish (MobileNetV3's 1x1 layers on the large maps,
+ * det_mobilenet_v3.py:38-61; pad narrower layers with zero rows / columns). */
+int ptocr_conv1x1_small_k_f32(const float *d_x, const float *d_w, const float *d_bias, const float *d_res, float *d_y,
+                              int N, int H, int W, int Cin, int Cout, int act, int res_up2, int out_ldc, int out_coff, void *stream);
 /* CRNN conv0 + relu0 + pooling0 fused (rec_vgg.py:78-88): y f32[N,H/2,W/2,64] = maxpool2x2(relu(conv3x3/s1/p1(x) + bias)) for an
  * input with 1..4 channels stored as f32[N,H,W,4]; d_w f32[Cin*9][64], row (ci*3 + ky)*3 + kx (BN folded). */
 int ptocr_conv3x3_small_relu_pool_f32(const float *d_x, const float *d_w, const float *d_bias, float *d_y, int N, int H, int W,

@@ -1,5 +1,5 @@
-// Pointwise (1x1) convolution with Cin = 64 and Cout a multiple of 32, up to 256 (+ folded BN, ReLU, optional FPN top-down
-// add) on fp32 MFMA.  The layer it exists for is the FPN lateral `in2` (fpn.py:46-51,112,117): 64 -> 256 channels on the
+// Pointwise (1x1) convolution with Cin = 32 or 64 and Cout a multiple of 32, up to 256 (+ folded BN, ReLU / Hardswish, optional
+// FPN top-down add) on fp32 MFMA.  The layer it exists for is the FPN lateral `in2` (fpn.py:46-51,112,117): 64 -> 256 channels on the
 // 1/4-resolution map -- 61.7 GFLOP per batch of 32 but 1.93 GB of output, i.e. bound by the HBM write, not by the MFMA.  The
 // generic implicit GEMM (conv_mfma.hip) spends 1.56 ms on it (one short K loop per workgroup: all prologue and epilogue);
 // here a persistent workgroup (256 threads, 1 per CU) keeps the whole weight matrix W[64][Cout] in LDS, streams 128-pixel
@@ -15,9 +15,7 @@ namespace ptocr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int PW_K = 64;                        // input channels
 constexpr int PW_TM = 128;                      // pixels per tile
-constexpr int PW_RS = PW_K + 4;                 // LDS row stride of the pixel tile (16-byte aligned rows)
 constexpr int PW_MAXC = 256;
 
 struct Pw64Args {
@@ -28,8 +26,11 @@ struct Pw64Args {
     long x_bytes;
 };
 
-template <int NMT>                              // Cout / 32
+template <int PW_K, int NMT>                    // input channels (32 or 64), Cout / 32
 __global__ __launch_bounds__(256, 1) void conv_pw64_kernel(Pw64Args p) {
+    constexpr int PW_RS = PW_K + 4;             // LDS row stride of the pixel tile (16-byte aligned rows)
+    constexpr int QPP = PW_K / 4;               // 16-byte pieces per pixel
+    constexpr int NPC = PW_TM * QPP / 256;      // pieces per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Wl = smem;                           // [64][Cout]
     float *Xb = smem + PW_K * NMT * 32;         // [2][PW_TM][PW_RS]
@@ -42,21 +43,21 @@ __global__ __launch_bounds__(256, 1) void conv_pw64_kernel(Pw64Args p) {
     for (int i = tid; i < PW_K * COUT / 4; i += 256) reinterpret_cast<f32x4 *>(Wl)[i] = reinterpret_cast<const f32x4 *>(p.w)[i];
     if (tid < COUT) Bl[tid] = p.bias[tid];
 
-    // tile loader: 128 pixels x 16 float4 = 2048 pieces, 8 per thread; piece f = tid + 256 r -> pixel f >> 4, quad f & 15
-    f32x4 xreg[8];
+    // tile loader: 128 pixels x QPP float4 pieces, NPC per thread; piece f = tid + 256 r -> pixel f / QPP, quad f % QPP
+    f32x4 xreg[NPC];
     auto gload = [&](int tile) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
+        for (int r = 0; r < NPC; r++) {
             const int f = tid + 256 * r;
-            const long m = (long)tile * PW_TM + (f >> 4);                 // beyond M: out of range -> zeros
-            xreg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (unsigned)(m * (PW_K * 4) + (f & 15) * 16), 0, 0));
+            const long m = (long)tile * PW_TM + f / QPP;                  // beyond M: out of range -> zeros
+            xreg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (unsigned)(m * (PW_K * 4) + (f % QPP) * 16), 0, 0));
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
+        for (int r = 0; r < NPC; r++) {
             const int f = tid + 256 * r;
-            *reinterpret_cast<f32x4 *>(Xb + buf * PW_TM * PW_RS + (f >> 4) * PW_RS + (f & 15) * 4) = xreg[r];
+            *reinterpret_cast<f32x4 *>(Xb + buf * PW_TM * PW_RS + (f / QPP) * PW_RS + (f % QPP) * 4) = xreg[r];
         }
     };
 
@@ -114,7 +115,11 @@ __global__ __launch_bounds__(256, 1) void conv_pw64_kernel(Pw64Args p) {
                     const int co = 32 * mt + 8 * g + 4 * kh;
                     f32x4 v = f32x4{acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]} +
                               *reinterpret_cast<const f32x4 *>(Bl + co);
-                    if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                    if (p.relu == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                    if (p.relu == 2) {                                  // Hardswish: x * relu6(x + 3) / 6
+#pragma unroll
+                        for (int k = 0; k < 4; k++) v[k] = v[k] * fminf(fmaxf(v[k] + 3.f, 0.f), 6.f) * (1.f / 6.f);
+                    }
                     if (p.res_up2) v += rres[mt][g];
                     *reinterpret_cast<f32x4 *>(yp + co) = v;
                 }
@@ -126,12 +131,12 @@ __global__ __launch_bounds__(256, 1) void conv_pw64_kernel(Pw64Args p) {
     }
 }
 
-template <int NMT>
+template <int PW_K, int NMT>
 static int launch_pw64(const Pw64Args &a, hipStream_t stream) {
-    const size_t lds = sizeof(float) * (PW_K * NMT * 32 + 2 * PW_TM * PW_RS + NMT * 32);
+    const size_t lds = sizeof(float) * (PW_K * NMT * 32 + 2 * PW_TM * (PW_K + 4) + NMT * 32);
     static bool attr_set = false;
     if (!attr_set) {
-        PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pw64_kernel<NMT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pw64_kernel<PW_K, NMT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     static int n_cu = 0;
@@ -141,7 +146,7 @@ static int launch_pw64(const Pw64Args &a, hipStream_t stream) {
         PT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     }
     const int grid = a.ntiles < n_cu ? a.ntiles : n_cu;          // one persistent workgroup per CU
-    hipLaunchKernelGGL((conv_pw64_kernel<NMT>), dim3((unsigned)grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((conv_pw64_kernel<PW_K, NMT>), dim3((unsigned)grid), dim3(256), lds, stream, a);
     return launch_ok("conv_pw64_kernel");
 }
 
@@ -149,30 +154,45 @@ static int launch_pw64(const Pw64Args &a, hipStream_t stream) {
 
 using namespace ptocr;
 
-// d_x: f32[N,H,W,64]; d_w: f32[64][Cout] (k-major, BN folded); d_res (res_up2 = 1): f32[N,H/2,W/2,Cout], added AFTER the
-// activation (fpn.py:133-134), H and W even; d_y: f32[N,H,W,out_ldc], channels [out_coff, out_coff + Cout).
-extern "C" int ptocr_conv1x1_k64_f32(const float *d_x, const float *d_w, const float *d_bias, const float *d_res, float *d_y,
-                                     int N, int H, int W, int Cout, int relu, int res_up2, int out_ldc, int out_coff, void *stream) {
-    PT_CHECK(d_x && d_w && d_bias && d_y, "ptocr_conv1x1_k64_f32: null argument");
-    PT_CHECK(N > 0 && H > 0 && W > 0, "ptocr_conv1x1_k64_f32: empty tensor");
-    PT_CHECK(Cout % 32 == 0 && Cout >= 32 && Cout <= PW_MAXC, "ptocr_conv1x1_k64_f32: Cout must be a multiple of 32 up to %d", PW_MAXC);
-    PT_CHECK(relu == 0 || relu == 1, "ptocr_conv1x1_k64_f32: activation must be none or ReLU");
-    PT_CHECK(!res_up2 || (d_res && H % 2 == 0 && W % 2 == 0), "ptocr_conv1x1_k64_f32: the upsample-add needs d_res and even H, W");
-    PT_CHECK(out_ldc % 4 == 0 && out_coff % 4 == 0 && out_ldc >= out_coff + Cout, "ptocr_conv1x1_k64_f32: channel strides must be multiples of 4");
+template <int PW_K>
+static int dispatch_pw(const Pw64Args &a, hipStream_t s) {
+    switch (a.Cout / 32) {
+        case 1: return launch_pw64<PW_K, 1>(a, s);
+        case 2: return launch_pw64<PW_K, 2>(a, s);
+        case 3: return launch_pw64<PW_K, 3>(a, s);
+        case 4: return launch_pw64<PW_K, 4>(a, s);
+        case 5: return launch_pw64<PW_K, 5>(a, s);
+        case 6: return launch_pw64<PW_K, 6>(a, s);
+        case 7: return launch_pw64<PW_K, 7>(a, s);
+        default: return launch_pw64<PW_K, 8>(a, s);
+    }
+}
+
+// d_x: f32[N,H,W,Cin], Cin = 32 or 64; d_w: f32[Cin][Cout] (k-major, BN folded, zero rows / columns for padded channels);
+// act: 0 none, 1 ReLU, 2 Hardswish; d_res (res_up2 = 1): f32[N,H/2,W/2,Cout], added AFTER the activation (fpn.py:133-134), H and W
+// even; d_y: f32[N,H,W,out_ldc], channels [out_coff, out_coff + Cout).
+extern "C" int ptocr_conv1x1_small_k_f32(const float *d_x, const float *d_w, const float *d_bias, const float *d_res, float *d_y,
+                                         int N, int H, int W, int Cin, int Cout, int act, int res_up2, int out_ldc, int out_coff,
+                                         void *stream) {
+    PT_CHECK(d_x && d_w && d_bias && d_y, "ptocr_conv1x1_small_k_f32: null argument");
+    PT_CHECK(N > 0 && H > 0 && W > 0, "ptocr_conv1x1_small_k_f32: empty tensor");
+    PT_CHECK(Cin == 32 || Cin == 64, "ptocr_conv1x1_small_k_f32: Cin must be 32 or 64 (got %d)", Cin);
+    PT_CHECK(Cout % 32 == 0 && Cout >= 32 && Cout <= PW_MAXC, "ptocr_conv1x1_small_k_f32: Cout must be a multiple of 32 up to %d", PW_MAXC);
+    PT_CHECK(act >= 0 && act <= 2, "ptocr_conv1x1_small_k_f32: activation must be none, ReLU or Hardswish");
+    PT_CHECK(!res_up2 || (d_res && H % 2 == 0 && W % 2 == 0), "ptocr_conv1x1_small_k_f32: the upsample-add needs d_res and even H, W");
+    PT_CHECK(out_ldc % 4 == 0 && out_coff % 4 == 0 && out_ldc >= out_coff + Cout, "ptocr_conv1x1_small_k_f32: channel strides must be multiples of 4");
     Pw64Args a;
     a.x = d_x; a.w = d_w; a.bias = d_bias; a.res = d_res; a.y = d_y;
-    a.M = (long)N * H * W; a.H = H; a.W = W; a.Cout = Cout; a.relu = relu; a.res_up2 = res_up2; a.out_ldc = out_ldc; a.out_coff = out_coff;
-    a.x_bytes = a.M * PW_K * 4;
-    PT_CHECK(a.x_bytes < (1L << 31), "ptocr_conv1x1_k64_f32: tensor larger than 2 GiB");
+    a.M = (long)N * H * W; a.H = H; a.W = W; a.Cout = Cout; a.relu = act; a.res_up2 = res_up2; a.out_ldc = out_ldc; a.out_coff = out_coff;
+    a.x_bytes = a.M * Cin * 4;
+    PT_CHECK(a.x_bytes < (1L << 31), "ptocr_conv1x1_small_k_f32: tensor larger than 2 GiB");
     a.ntiles = (int)((a.M + PW_TM - 1) / PW_TM);
-    switch (Cout / 32) {
-        case 1: return launch_pw64<1>(a, (hipStream_t)stream);
-        case 2: return launch_pw64<2>(a, (hipStream_t)stream);
-        case 3: return launch_pw64<3>(a, (hipStream_t)stream);
-        case 4: return launch_pw64<4>(a, (hipStream_t)stream);
-        case 5: return launch_pw64<5>(a, (hipStream_t)stream);
-        case 6: return launch_pw64<6>(a, (hipStream_t)stream);
-        case 7: return launch_pw64<7>(a, (hipStream_t)stream);
-        default: return launch_pw64<8>(a, (hipStream_t)stream);
-    }
+    return Cin == 32 ? dispatch_pw<32>(a, (hipStream_t)stream) : dispatch_pw<64>(a, (hipStream_t)stream);
+}
+
+// the Cin = 64, ReLU-or-none form under its first name (the FPN lateral in2 of DBNet-r18)
+extern "C" int ptocr_conv1x1_k64_f32(const float *d_x, const float *d_w, const float *d_bias, const float *d_res, float *d_y,
+                                     int N, int H, int W, int Cout, int relu, int res_up2, int out_ldc, int out_coff, void *stream) {
+    PT_CHECK(relu == 0 || relu == 1, "ptocr_conv1x1_k64_f32: activation must be none or ReLU");
+    return ptocr_conv1x1_small_k_f32(d_x, d_w, d_bias, d_res, d_y, N, H, W, 64, Cout, relu, res_up2, out_ldc, out_coff, stream);
 }

@@ -20,6 +20,8 @@ USE_STEM_KERNEL = _os.environ.get("PTOCR_STEM_KERNEL", "1") != "0"
 # 1x1 convolutions with 64 input channels run in the LDS-resident-weights kernel unless PTOCR_PW64_KERNEL=0
 USE_PW64_KERNEL = _os.environ.get("PTOCR_PW64_KERNEL", "1") != "0"
 # CRNN's conv0 + ReLU + 2x2 pool run fused on the VALU unless PTOCR_SMALL_CONV_KERNEL=0
+PW_MIN_PIXELS = 4096       # per image (NOT per batch: kernel choice must not depend on the batch size, results are compared
+                           # bit-exactly across batch sizes); smaller maps go to the generic kernel
 USE_SMALL_CONV_KERNEL = _os.environ.get("PTOCR_SMALL_CONV_KERNEL", "1") != "0"
 
 
@@ -91,12 +93,16 @@ class PackedConv:
             self.small_w = w.permute(1, 2, 3, 0).reshape(cin * 9, 64).contiguous().float().to(device)
             self.small_b = b.float().contiguous().to(device)
             self.small_cin = cin
-        # pointwise layers with 64 input channels (the FPN lateral in2): W[k][cout], k-major, for the LDS-resident-weights kernel
+        # pointwise layers with <= 64 input channels (the FPN lateral in2, MobileNetV3's wide early layers): W[k][cout], k-major,
+        # channels zero-padded to the tensors' widths, for the LDS-resident-weights kernel
         self.pw_w = None
-        if (kh, kw) == (1, 1) and self.stride == 1 and (self.pad_h, self.pad_w) == (0, 0) and cin == 64 and cout % 32 == 0 \
-                and cout <= 256 and self.relu in (ACT_NONE, ACT_RELU):
-            self.pw_w = w.reshape(cout, cin).t().contiguous().float().to(device)
-            self.pw_b = b.float().contiguous().to(device)
+        if (kh, kw) == (1, 1) and self.stride == 1 and (self.pad_h, self.pad_w) == (0, 0) and cin_pad in (32, 64) and c_tensor <= 256:
+            pw = torch.zeros(cin_pad, c_tensor, dtype=torch.float64)
+            pw[:cin, :cout] = w.reshape(cout, cin).t()
+            pb = torch.zeros(c_tensor, dtype=torch.float64)
+            pb[:cout] = b
+            self.pw_w = pw.float().contiguous().to(device)
+            self.pw_b = pb.float().contiguous().to(device)
         # ResNet stem (7x7 / s2 / p3, RGB -> 64): K axis without the padding channel, w[ky][kx*3 + c][cout], one zero row per ky
         self.stem_w = None
         if (kh, kw) == (7, 7) and self.stride == 2 and (self.pad_h, self.pad_w) == (3, 3) and cin == 3 and cout == 64 \
@@ -171,20 +177,20 @@ def conv2d(x, pc, res=None, res_mode=RES_NONE, out=None, out_up=1, out_coff=0, s
                 PROFILE_LABELS.append("stem7x7 %dx%dx%dx3->64" % (N, H, W))
         return out
     if USE_PW64_KERNEL and getattr(pc, "pw_w", None) is not None and out_up == 1 and res_mode in (RES_NONE, RES_ADD_UP2_POST_RELU) \
-            and (store is None or store == pc.cout_real) and N * H * W * 256 < 2 ** 31 \
-            and (res_mode == RES_NONE or (H % 2 == 0 and W % 2 == 0 and res.shape[3] == pc.cout_real)):
+            and (store is None or store == pc.c_tensor) and PW_MIN_PIXELS <= H * W and N * H * W * Cin * 4 < 2 ** 31 \
+            and (res_mode == RES_NONE or (H % 2 == 0 and W % 2 == 0 and res.shape[3] == pc.c_tensor)):
         if PROFILE is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        _lib.check(_lib.lib().ptocr_conv1x1_k64_f32(_lib.ptr(x), _lib.ptr(pc.pw_w), _lib.ptr(pc.pw_b),
-                                                    _lib.ptr(res) if res is not None else C.c_void_p(0), _lib.ptr(out),
-                                                    N, H, W, pc.cout_real, int(pc.relu), int(res_mode == RES_ADD_UP2_POST_RELU),
-                                                    out.shape[3], out_coff, _lib.cur_stream()), "ptocr_conv1x1_k64_f32")
+        _lib.check(_lib.lib().ptocr_conv1x1_small_k_f32(_lib.ptr(x), _lib.ptr(pc.pw_w), _lib.ptr(pc.pw_b),
+                                                        _lib.ptr(res) if res is not None else C.c_void_p(0), _lib.ptr(out),
+                                                        N, H, W, Cin, pc.c_tensor, int(pc.relu), int(res_mode == RES_ADD_UP2_POST_RELU),
+                                                        out.shape[3], out_coff, _lib.cur_stream()), "ptocr_conv1x1_small_k_f32")
         if PROFILE is not None:
             e1.record()
             PROFILE.append((e0, e1))
             if PROFILE_LABELS is not None:
-                PROFILE_LABELS.append("pw1x1 %dx%dx%dx64->%d" % (N, H, W, pc.cout_real))
+                PROFILE_LABELS.append("pw1x1 %dx%dx%dx%d->%d" % (N, H, W, Cin, pc.c_tensor))
         return out
     if USE_WINOGRAD and getattr(pc, "wino_u", None) is not None and (res_mode == RES_NONE or (res_mode == RES_ADD_PRE_RELU and out_up == 1)) \
             and out_up <= 8 and (store if store is not None else pc.c_tensor) % 4 == 0 and N * H * W * Cin * 4 < 2 ** 31 \

@@ -291,6 +291,7 @@ def test_pointwise_k64_kernel(case):
     tol = 2e-5 * max(1.0, ref.abs().max().item())
     for use in (True, False):
         ops.USE_PW64_KERNEL = use
+        ops.PW_MIN_PIXELS = 0                                # the size heuristic would send these small cases to the generic kernel
         try:
             y = ops.conv2d(xd, pc).cpu().permute(0, 3, 1, 2)
             assert (y - ref).abs().max().item() <= tol, use
@@ -301,11 +302,39 @@ def test_pointwise_k64_kernel(case):
                 assert (y - ref_up).abs().max().item() <= tol, use
         finally:
             ops.USE_PW64_KERNEL = True
+    ops.PW_MIN_PIXELS = 0
     big = torch.full((N, H, W, Cout + 96), 3.0, device=dev)
     ops.conv2d(xd, pc, out=big, out_coff=32, store=Cout)
     big = big.cpu()
     assert (big[..., 32:32 + Cout].permute(0, 3, 1, 2) - ref).abs().max().item() <= tol
     assert float((big[..., :32] - 3).abs().max()) == 0 and float((big[..., 32 + Cout:] - 3).abs().max()) == 0
+    ops.PW_MIN_PIXELS = 4096
+
+
+@pytest.mark.parametrize("cin,cout,act", [(16, 72, "hs"), (24, 96, "relu"), (40, 16, "none")])
+def test_pointwise_small_k_padded_channels(cin, cout, act):
+    """the same kernel on MobileNetV3-like layers: input / output channels zero-padded to 32-multiples, Hardswish"""
+    from pytorchocr_amd.modeling import ops
+    dev = _dev()
+    conv = nn.Conv2d(cin, cout, 1, bias=False)
+    bn = nn.BatchNorm2d(cout, eps=1e-3).eval()
+    with torch.no_grad():
+        conv.weight.copy_(_rand(cout, cin, 1, 1, seed=1) * 0.4)
+        bn.running_mean.copy_(_rand(cout, seed=5) * 0.2); bn.running_var.copy_(_rand(cout, seed=6) * 0.5 + 1)
+    x = _rand(2, cin, 21, 37, seed=7)
+    with torch.no_grad():
+        ref = bn(conv(x))
+        ref = F.hardswish(ref) if act == "hs" else (F.relu(ref) if act == "relu" else ref)
+    pc = ops.PackedConv(conv, bn, dev, relu={"hs": ops.ACT_HSWISH, "relu": True, "none": False}[act])
+    assert pc.pw_w is not None and pc.pw_w.shape[0] in (32, 64)
+    xp = torch.zeros(2, 21, 37, pc.cin); xp[..., :cin] = _nhwc(x)
+    ops.PW_MIN_PIXELS = 0
+    try:
+        y = ops.conv2d(xp.to(dev), pc).cpu()
+    finally:
+        ops.PW_MIN_PIXELS = 4096
+    assert y.shape[3] == pc.c_tensor and (pc.c_tensor == cout or float(y[..., cout:].abs().max()) == 0.0)
+    assert (y[..., :cout].permute(0, 3, 1, 2) - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
 
 
 @pytest.mark.parametrize("cin,shape", [(1, (3, 32, 320)), (3, (2, 32, 100)), (1, (2, 9, 15))])
