@@ -101,6 +101,37 @@ class CTCLabelDecode(BaseRecLabelDecode):
         label = self.decode(label)
         return text, label
 
+    def submit(self, greedy):
+        """Asynchronous form for the device-resident fast path: `greedy` = (idx int32[B,T], prob f32[B,T]) from
+        `BaseModel.forward_greedy`.  The two small tensors are copied to pinned host memory on a side stream behind the work
+        already queued on the caller's stream; `.result()` waits for that copy only and runs the (host, Python) string
+        assembly -- so it overlaps with whatever the caller queues next (the next batch's forward pass).  Same return value
+        as `__call__`."""
+        idx, prob = greedy
+        dev = idx.device
+        cur = torch.cuda.current_stream(dev)
+        if getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = torch.cuda.Stream(device=dev)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        h_idx = torch.empty(idx.shape, dtype=idx.dtype, pin_memory=True)
+        h_prob = torch.empty(prob.shape, dtype=prob.dtype, pin_memory=True)
+        with torch.cuda.stream(self._copy_stream):
+            self._copy_stream.wait_event(ready)
+            h_idx.copy_(idx, non_blocking=True)
+            h_prob.copy_(prob, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self._copy_stream)
+        idx.record_stream(self._copy_stream); prob.record_stream(self._copy_stream)
+        decode = self.decode
+
+        class _Pending:
+            def result(self_inner):
+                done.synchronize()
+                ops.lstm_check()
+                return decode(h_idx.numpy(), h_prob.numpy(), is_remove_duplicate=True)
+        return _Pending()
+
     def add_special_char(self, dict_character):
         dict_character = ["blank"] + dict_character
         return dict_character

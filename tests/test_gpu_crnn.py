@@ -80,6 +80,12 @@ def test_crnn_batch_against_oracle_and_decode(contract):
         assert [t for t, _ in got] == [t for t, _ in exp]
         assert np.allclose([c for _, c in got], [c for _, c in exp], atol=1e-4, equal_nan=True)
     assert any(len(t) > 3 for t, _ in exp)
+    # asynchronous form (pinned copy on a side stream, decode at .result()): same texts and confidences
+    with torch.no_grad():
+        fut = post.submit(m.forward_greedy(torch.from_numpy(xs).cuda()))
+    got = fut.result()
+    assert [t for t, _ in got] == [t for t, _ in exp]
+    assert np.allclose([c for _, c in got], [c for _, c in exp], atol=1e-4, equal_nan=True)
 
 
 def test_ctc_decode_known_answers(gold_dir):
