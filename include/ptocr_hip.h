@@ -12,10 +12,15 @@
  *     f32[N,1,H,W] == NHWC with C=1, exactly the tensor the reference model returns under key "maps".
  *
  * What each entry point replaces in the reference (file:line under /root/reference):
- *   ptocr_conv2d_f32 / ptocr_maxpool2d_f32 / ptocr_nchw_to_nhwc_f32 / ptocr_convt2x2_sigmoid_f32
- *       the ATen conv / BN / ReLU / max_pool / conv_transpose / sigmoid calls issued by
- *       pytocr/modeling/backbones/det_resnet.py:66-82,282-309, necks/fpn.py:102-134,
- *       heads/det_db_head.py:9-17,47-50, backbones/rec_vgg.py:78-120 (BN folded into weights/bias at load).
+ *   ptocr_conv2d_f32 / ptocr_conv3x3_wino_f32 (3x3 s1: Winograd) / ptocr_conv7x7s2_stem_f32 (ResNet stem) /
+ *   ptocr_conv1x1_k64_f32, ptocr_conv1x1_small_k_f32 (1x1 with <= 64 inputs) / ptocr_conv3x3_small_relu_pool_f32 (CRNN conv0 +
+ *   pool) / ptocr_maxpool2d_f32 / ptocr_nchw_to_nhwc_f32 / ptocr_convt2x2_sigmoid_f32 / ptocr_db_head_tail_f32 /
+ *   ptocr_dwconv_f32 / ptocr_se_scale_f32
+ *       the ATen conv / BN / ReLU / Hardswish / max_pool / conv_transpose / sigmoid calls issued by
+ *       pytocr/modeling/backbones/det_resnet.py:66-82,282-309, det_mobilenet_v3.py:38-151, necks/fpn.py:102-134,
+ *       heads/det_db_head.py:9-17,47-50, backbones/rec_vgg.py:78-120 (BN folded into weights/bias at load).  The specialised
+ *       entry points compute the same layers as ptocr_conv2d_f32 (same results within fp32 rounding) for the shapes where a
+ *       dedicated kernel is faster; the Python host side picks them per layer.
  *   ptocr_asf_scale_channel_spatial_f32
  *       ScaleChannelSpatialAttention.forward + the re-weighted concat of pytocr/modeling/necks/asf.py:63-75,155-162 (DB++).
  *   ptocr_preprocess_u8_f32, ptocr_warp_crops_u8
