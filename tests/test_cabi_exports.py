@@ -47,3 +47,12 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "dbpost_oracle" in txt:
                     bad.append(fn)
     assert not bad, bad
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    """no CPU fallback: without the built .so the very first call raises and names the build command"""
+    from pytorchocr_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(ROOT, "pytorchocr_amd", "no_such_libptocr_hip.so"))
+    with pytest.raises(RuntimeError, match="pytorchocr_amd.build"):
+        _lib.lib()
