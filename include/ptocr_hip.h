@@ -82,6 +82,9 @@ int ptocr_conv3x3_wino_f32(const float *d_x, const float *d_u, const float *d_bi
  * w[ky][kx*3 + c][cout], row [ky][21] all zero (K runs over 7 x 22 = 154 instead of the generic kernel's 7*7*4 = 196). */
 int ptocr_conv7x7s2_stem_f32(const float *d_x, const float *d_w, const float *d_bias, float *d_y, int N, int H, int W,
                              int relu, void *stream);
+/* the same layer reading the model's input tensor f32[N,3,H,W] directly (saves the NCHW -> NHWC boundary pass) */
+int ptocr_conv7x7s2_stem_nchw_f32(const float *d_x, const float *d_w, const float *d_bias, float *d_y, int N, int H, int W,
+                                  int relu, void *stream);
 /* Pointwise convolution with 64 input channels (the FPN lateral in2, fpn.py:46-51): f32[N,H,W,64] x W[64][Cout] (k-major, BN
  * folded; Cout a multiple of 32, <= 256) + bias + optional ReLU; res_up2 = 1 adds d_res f32[N,H/2,W/2,Cout] nearest-upsampled
  * x2 AFTER the activation (fpn.py:133-134).  Output channels [out_coff, out_coff+Cout) of a tensor with channel stride out_ldc. */

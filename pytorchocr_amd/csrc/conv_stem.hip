@@ -36,6 +36,7 @@ struct StemArgs {
     long x_bytes;
 };
 
+template <bool NCHW>                          // input f32[N,3,H,W] planes (the model's own input tensor) instead of f32[N,H,W,4]
 __global__ __launch_bounds__(256, 2) void stem_conv_kernel(StemArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Wl = smem;                           // [ST_K][64]
@@ -63,8 +64,16 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(StemArgs p) {
             const int pr = f / ST_PC, pc = f - pr * ST_PC;
             const int iy = 2 * oy0 - 3 + pr, ix = 2 * ox0 - 3 + pc;
             const bool ok = f < ST_PR * ST_PC && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const unsigned off = ok ? (unsigned)((((long)n * p.H + iy) * p.W + ix) * 16) : oob;
-            preg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+            if (NCHW) {                         // three plane reads per pixel, consecutive lanes on consecutive x: coalesced
+                const long plane = (long)p.H * p.W * 4;
+                const unsigned off = ok ? (unsigned)((((long)n * 3 * p.H + iy) * p.W + ix) * 4) : oob;
+                preg[r][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off, 0, 0));
+                preg[r][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, ok ? (unsigned)(off + plane) : oob, 0, 0));
+                preg[r][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, ok ? (unsigned)(off + 2 * plane) : oob, 0, 0));
+            } else {
+                const unsigned off = ok ? (unsigned)((((long)n * p.H + iy) * p.W + ix) * 16) : oob;
+                preg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+            }
         }
     };
     auto lstore = [&](int buf) {
@@ -153,25 +162,24 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(StemArgs p) {
 
 using namespace ptocr;
 
-// d_x: f32[N,H,W,4] (RGB + one ignored channel); d_w: f32[7][22][64], w[ky][kx*3 + c][cout] with BN folded, [ky][21][*] = 0;
-// d_y: f32[N,Ho,Wo,64], Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1.
-extern "C" int ptocr_conv7x7s2_stem_f32(const float *d_x, const float *d_w, const float *d_bias, float *d_y, int N, int H, int W,
-                                        int relu, void *stream) {
-    PT_CHECK(d_x && d_w && d_bias && d_y, "ptocr_conv7x7s2_stem_f32: null argument");
-    PT_CHECK(N > 0 && H > 0 && W > 0, "ptocr_conv7x7s2_stem_f32: empty tensor");
-    PT_CHECK(relu == 0 || relu == 1, "ptocr_conv7x7s2_stem_f32: activation must be none or ReLU");
+static int stem_launch(const float *d_x, const float *d_w, const float *d_bias, float *d_y, int N, int H, int W, int relu, bool nchw,
+                       void *stream, const char *who) {
+    PT_CHECK(d_x && d_w && d_bias && d_y, "%s: null argument", who);
+    PT_CHECK(N > 0 && H > 0 && W > 0, "%s: empty tensor", who);
+    PT_CHECK(relu == 0 || relu == 1, "%s: activation must be none or ReLU", who);
     StemArgs a;
     a.x = d_x; a.w = d_w; a.bias = d_bias; a.y = d_y;
     a.N = N; a.H = H; a.W = W; a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1;
     a.tiles_x = cdiv(a.Wo, ST_TW); a.tiles_y = cdiv(a.Ho, ST_TH);
     const long total = (long)N * a.tiles_x * a.tiles_y;
-    a.x_bytes = (long)N * H * W * 16;
-    PT_CHECK(total < (1L << 31) && a.x_bytes < (1L << 31), "ptocr_conv7x7s2_stem_f32: tensor larger than 2 GiB");
+    a.x_bytes = (long)N * H * W * (nchw ? 12 : 16);
+    PT_CHECK(total < (1L << 31) && a.x_bytes < (1L << 31), "%s: tensor larger than 2 GiB", who);
     a.total = (int)total; a.relu = relu;
     const size_t lds = sizeof(float) * (ST_K * 64 + 2 * ST_PATCH);
     static bool attr_set = false;
     if (!attr_set) {
-        PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(stem_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&stem_conv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&stem_conv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     static int n_cu = 0;
@@ -181,6 +189,20 @@ extern "C" int ptocr_conv7x7s2_stem_f32(const float *d_x, const float *d_w, cons
         PT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     }
     const int grid = a.total < 2 * n_cu ? a.total : 2 * n_cu;    // two persistent workgroups per CU
-    hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a);
+    if (nchw) hipLaunchKernelGGL(stem_conv_kernel<true>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(stem_conv_kernel<false>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a);
     return launch_ok("stem_conv_kernel");
+}
+
+// d_x: f32[N,H,W,4] (RGB + one ignored channel); d_w: f32[7][22][64], w[ky][kx*3 + c][cout] with BN folded, [ky][21][*] = 0;
+// d_y: f32[N,Ho,Wo,64], Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1.
+extern "C" int ptocr_conv7x7s2_stem_f32(const float *d_x, const float *d_w, const float *d_bias, float *d_y, int N, int H, int W,
+                                        int relu, void *stream) {
+    return stem_launch(d_x, d_w, d_bias, d_y, N, H, W, relu, false, stream, "ptocr_conv7x7s2_stem_f32");
+}
+
+// the same layer straight from the model's input tensor d_x f32[N,3,H,W] (no NCHW -> NHWC boundary pass)
+extern "C" int ptocr_conv7x7s2_stem_nchw_f32(const float *d_x, const float *d_w, const float *d_bias, float *d_y, int N, int H, int W,
+                                             int relu, void *stream) {
+    return stem_launch(d_x, d_w, d_bias, d_y, N, H, W, relu, true, stream, "ptocr_conv7x7s2_stem_nchw_f32");
 }

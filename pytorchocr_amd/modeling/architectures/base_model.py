@@ -48,7 +48,8 @@ class BaseModel(nn.Module):
             raise RuntimeError("pytorchocr_amd BaseModel.forward: input is on %s; the HIP path has no CPU fallback" % x.device)
         y = dict()
         if self.model_type == "det":
-            feats = self.backbone.forward_nhwc(ops.nchw_to_nhwc(x, 4))
+            feats = self.backbone.forward_from_nchw(x) if hasattr(self.backbone, "forward_from_nchw") \
+                else self.backbone.forward_nhwc(ops.nchw_to_nhwc(x, 4))
             neck = self.neck.forward_nhwc(feats) if self.use_neck else feats
             out = self.head.forward_nhwc(neck)
             if self.return_all_feats:

@@ -89,11 +89,11 @@ class ResNet(ops.PackedModule):
             p["layer%d" % li] = [blk.pack(dev) for blk in getattr(self, "layer%d" % li)]
         return p
 
-    def forward_nhwc(self, x4):
-        """x4: f32[N,H,W,4] (RGB + zero channel) -> [C2, C3, C4, C5] NHWC."""
+    def forward_nhwc(self, x4, x_nchw=None):
+        """x4: f32[N,H,W,4] (RGB + zero channel) -> [C2, C3, C4, C5] NHWC; or the model's NCHW input as `x_nchw` (x4 None)."""
         self._check_eval()
         p = self.packed()
-        x = ops.conv2d(x4, p["stem"])
+        x = ops.conv2d(x4, p["stem"]) if x_nchw is None else ops.stem_from_nchw(x_nchw, p["stem"])
         x = ops.maxpool2d(x, 3, 2, 1)
         outs = []
         for li in (1, 2, 3, 4):
@@ -104,5 +104,9 @@ class ResNet(ops.PackedModule):
 
     def forward(self, x):
         """NCHW in, list of NCHW feature maps out (reference contract, det_resnet.py:282-312)."""
-        feats = self.forward_nhwc(ops.nchw_to_nhwc(x, 4))
+        feats = self.forward_nhwc(None, x_nchw=x)
         return [ops.nhwc_to_nchw(f) for f in feats]
+
+    def forward_from_nchw(self, x):
+        """NCHW model input -> NHWC feature maps (the stem reads the planes itself: no boundary layout pass)"""
+        return self.forward_nhwc(None, x_nchw=x)

@@ -350,6 +350,28 @@ def lstm_bidir(xproj, w_hh, B, T):
     return out
 
 
+def stem_from_nchw(x, pc):
+    """ResNet stem applied to the model's own input tensor x f32[N,3,H,W] -> f32[N,Ho,Wo,64] (the stem kernel reads the three
+    planes itself); falls back to the boundary layout pass + conv2d when the stem kernel does not apply"""
+    _require_cuda(x, "stem_from_nchw")
+    N, Cc, H, W = x.shape
+    if not USE_STEM_KERNEL or getattr(pc, "stem_w", None) is None or Cc != 3 or x.dtype != torch.float32 or N * H * W * 12 >= 2 ** 31:
+        return conv2d(nchw_to_nhwc(x, 4), pc)
+    x = x.contiguous()
+    out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64), dtype=torch.float32, device=x.device)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(_lib.lib().ptocr_conv7x7s2_stem_nchw_f32(_lib.ptr(x), _lib.ptr(pc.stem_w), _lib.ptr(pc.stem_b), _lib.ptr(out),
+                                                        N, H, W, int(pc.relu), _lib.cur_stream()), "ptocr_conv7x7s2_stem_nchw_f32")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((e0, e1))
+        if PROFILE_LABELS is not None:
+            PROFILE_LABELS.append("stem7x7 %dx%dx%dx3->64 (nchw)" % (N, H, W))
+    return out
+
+
 def conv3x3_relu_pool2(x4, pc):
     """maxpool2x2(relu(conv3x3(x4) + b)) for a layer with <= 4 input channels and 64 outputs (CRNN conv0 + pooling0), fused:
     x4 f32[N,H,W,4] -> f32[N,H/2,W/2,64]; falls back to the generic conv + pool kernels when PTOCR_SMALL_CONV_KERNEL=0"""

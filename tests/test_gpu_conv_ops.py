@@ -90,6 +90,10 @@ def test_stem_7x7_cin3(shape):
         got = y.cpu().permute(0, 3, 1, 2)
         assert got.shape == ref.shape
         assert (got - ref).abs().max().item() <= tol, use
+    # the same kernel reading the NCHW model input directly: bit-identical to the NHWC4 form
+    y_nchw = ops.stem_from_nchw(x.to(dev), pc)
+    x4[..., 3] = 0.0
+    assert torch.equal(y_nchw, ops.conv2d(x4, pc))
 
 
 def test_residual_and_upsample_epilogues():
