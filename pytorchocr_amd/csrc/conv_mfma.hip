@@ -1,4 +1,7 @@
-// fp32 implicit-GEMM convolution on CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact f32 FMA chain).
+// fp32 implicit-GEMM convolution on CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact f32 FMA chain) -- the GENERIC kernel.
+// The layers with a dedicated kernel run elsewhere (3x3/s1: conv_wino.hip; 7x7 RGB stem: conv_stem.hip; 1x1 with <= 64 inputs:
+// conv_pw64.hip; CRNN conv0 + pool: conv_small.hip); this file serves every other shape (stride-2 3x3, the remaining 1x1,
+// transposed 2x2, MobileNetV3, the linear layers of the CRNN) and remains the fallback for all of them.
 //
 // Replaces the ATen conv2d / batch_norm / relu / add / interpolate / cat / conv_transpose2d(k2,s2) calls of
 //   pytocr/modeling/backbones/det_resnet.py:66-82,282-309   pytocr/modeling/necks/fpn.py:102-134
