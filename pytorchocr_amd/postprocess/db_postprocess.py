@@ -34,6 +34,17 @@ class _Workspace:
             self.handle, self.dims = hd, dims
         return self.handle
 
+    def host_buffers(self, n):
+        """pinned host buffers for the results of an n-image call (pageable destinations make the runtime stage the 512 KB
+        box array through dozens of small copy kernels)"""
+        hb = getattr(self, "_host", None)
+        if hb is None or hb[0].shape[0] < n:
+            hb = (torch.empty((n, MAX_CANDIDATES, 4, 2), dtype=torch.int16, pin_memory=True),
+                  torch.empty(n, dtype=torch.int32, pin_memory=True), torch.empty(n, dtype=torch.int32, pin_memory=True),
+                  torch.empty((n, 2), dtype=torch.int32, pin_memory=True))
+            self._host = hb
+        return tuple(t[:n].numpy() for t in hb)
+
     def close(self):
         if self.handle is not None:
             _lib.lib().ptocr_dbpost_destroy(self.handle)
@@ -56,11 +67,12 @@ def device_boxes(maps, src_wh, thresh, box_thresh, unclip_ratio, bitmap=None, us
         raise RuntimeError("device_boxes: maps must be on a cuda (ROCm) device; there is no CPU fallback")
     maps = maps.contiguous().float()
     n, h, w = maps.shape
-    hd = (ws or _ws).get(n, h, w)
-    src = np.ascontiguousarray(src_wh, np.int32).reshape(n, 2)
-    boxes = np.empty((n, MAX_CANDIDATES, 4, 2), np.int16)
-    counts = np.zeros(n, np.int32)
-    flags = np.zeros(n, np.int32)
+    wsp = ws or _ws
+    hd = wsp.get(n, h, w)
+    boxes, counts, flags, src = wsp.host_buffers(n)
+    src[...] = np.asarray(src_wh, np.int32).reshape(n, 2)
+    counts[...] = 0
+    flags[...] = 0
     bptr = C.c_void_p(0)
     if bitmap is not None:
         if not bitmap.is_cuda:
@@ -71,7 +83,7 @@ def device_boxes(maps, src_wh, thresh, box_thresh, unclip_ratio, bitmap=None, us
         hd, _lib.ptr(maps), bptr, n, h, w, C.c_float(thresh), C.c_float(box_thresh), C.c_float(unclip_ratio),
         src.ctypes.data_as(C.c_void_p), int(bool(use_padding_resize)), int(bool(use_dilation)), boxes.ctypes.data_as(C.c_void_p), MAX_CANDIDATES,
         counts.ctypes.data_as(C.c_void_p), flags.ctypes.data_as(C.c_void_p), _lib.cur_stream()), "ptocr_db_postprocess")
-    return [boxes[i, :counts[i]].copy() for i in range(n)], flags
+    return [boxes[i, :counts[i]].copy() for i in range(n)], flags.copy()
 
 
 class DBPostProcess(object):
