@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json headline metric on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W            (N > 1: starts its own N ranks, one per GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One step = one pass of the detection hot path over one batch that is already resident in HBM:
@@ -10,30 +10,37 @@ device -> int16 boxes on the host (BASELINE.json configs[1]).  With N > 1 every 
 runs the same per-GPU batch on its own images (weak scaling, no data-path collective); the only collective is
 the RCCL broadcast of the weights from rank 0 before the timed region.  Rank 0 prints ONE JSON line.
 
---workload crnn measures BASELINE.json configs[2] instead (CRNN text-lines/sec, batch 512 of 32x320 crops).
+The second half of BASELINE.json's metric (CRNN text-lines/sec, configs[2]: batch 512 of 32x320 crops) is timed in the same
+run with the same K / W and travels in the same line under "crnn" (--workload crnn prints it as the top-level line instead;
+--workload ocr times configs[4], the run_ocr pipeline).
+
+`value` is wall clock over exactly K steps (barrier + synchronize on both sides, max over ranks); `ms_per_step_median` is the
+median over the K steps of HIP-event step times on the launch stream.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
-DET_GFLOP_PER_IMG = 114.195        # SURVEY.md 8d / BASELINE.md: DBNet-r18 @ 3x736x1280 (2*MAC over conv/deconv)
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # same guide, dense bf16 matrix peak
+PEAK_HBM_GBPS = 8000.0             # same guide, HBM3E spec peak (6.3 TB/s measured achievable)
+WINOGRAD_GAIN = 2.25               # F(2x2,3x3): 16 multiplies instead of 36 per 2x2 output tile and channel pair
 DET_TAIL_GFLOP_PER_IMG = 2.05      # ConvT 64->64 (1.93) + ConvT 64->1 (0.12) run in db_head_tail_kernel, not in the conv kernels
-CRNN_GFLOP_PER_LINE = 4.980
+CRNN_GFLOP_PER_LINE = 4.980        # SURVEY 8d
+POST_BYTES_PER_PIXEL = 18          # SURVEY 8d accounting of the DB post-process
 
 DET_R18 = dict(model_type="det", algorithm="DB", Transform=None,
                Backbone=dict(name="ResNet", layers=18, pretrained=False),
                Neck=dict(name="FPN", out_channels=256, mode="DB", use_asf=False, attention_type="scale_channel_spatial"),
                Head=dict(name="DBHead", k=50))
-# the other detectors of SURVEY 8a, for tools / DESIGN numbers only (--det-model); the metric is DBNet-r18
+# the other detectors of SURVEY 8a (--det-model); the headline metric is DBNet-r18
 DET_VARIANTS = {
     "r18": (DET_R18, "det_r18_db", 114.195),
     "r18pp": (dict(DET_R18, Neck=dict(name="FPN", out_channels=256, mode="DB", use_asf=True, attention_type="scale_channel_spatial")),
@@ -67,9 +74,42 @@ def load_contract(name):
     return {k: (tuple(s), d) for k, (s, d) in c.items()}
 
 
+def median(v):
+    v = sorted(v)
+    n = len(v)
+    return 0.0 if n == 0 else (v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2]))
+
+
+def self_launch(argv, n):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a CHILD `python -m torch.distributed.run`
+    (this parent never touches HIP -- a process that initialised the GPU must not exec, and need not), relay rank 0's JSON
+    line and exit with the child's code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in p.stdout:
+        if out.startswith("{") and '"metric"' in out:
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = p.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        rc = 1
+    raise SystemExit(rc)
+
+
 def build_and_sync_weights(cfg, contract_name, device, rank, world):
     """Random-init weights of the named architecture: rank 0 makes them, RCCL broadcast puts them on every GPU."""
-    import torch.distributed as dist
+    import torch
     from pytorchocr_amd.modeling.architectures import build_model
     from pytorchocr_amd.utils.synth import synth_state_dict
     model = build_model(cfg)
@@ -86,6 +126,7 @@ def build_and_sync_weights(cfg, contract_name, device, rank, world):
 def det_cpu_baseline(n_img, H, W):
     """The oracle (CPU restatement of the reference path: torch-CPU fp32 forward + C post-process with
     cpp_speedup=True semantics) on a bounded sample of the same workload."""
+    import torch
     from oracle import dbpost, model_oracle
     from pytorchocr_amd.utils.synth import synth_images, synth_prob_maps, synth_state_dict
     torch.set_num_threads(min(16, os.cpu_count() or 1))            # the GPU box's CPU share for one GPU is 16 cores
@@ -114,6 +155,7 @@ def det_cpu_baseline(n_img, H, W):
 def crnn_cpu_baseline(n_lines):
     """The oracle (torch-CPU fp32 CRNN forward + the reference's CTCLabelDecode restatement) on a bounded sample of lines,
     one batch of 16 at a time."""
+    import torch
     from oracle import ctc_oracle, model_oracle
     from pytorchocr_amd.utils.synth import synth_state_dict, synth_text_lines
     torch.set_num_threads(min(16, os.cpu_count() or 1))
@@ -133,214 +175,320 @@ def crnn_cpu_baseline(n_lines):
                       % (done, dt / done * 1e3)}
 
 
-def run_det(args, rank, local, world, device):
-    from pytorchocr_amd.modeling import ops
-    from pytorchocr_amd.postprocess import build_post_process
-    from pytorchocr_amd.utils.synth import synth_images, synth_prob_maps
-    B, H, W = args.batch, 736, 1280
-    det_cfg, det_contract, _ = DET_VARIANTS[args.det_model]
-    model = build_and_sync_weights(det_cfg, det_contract, device, rank, world)
-    post = build_post_process(DET_POST, dict(use_gpu=True, seed=2022))
-    # synthetic images: a few distinct seeded images tiled to the batch (the generator is slow on the host)
-    base = synth_images(4, 3, H, W, seed=2022 + rank)
-    x = torch.from_numpy(base).to(device).repeat(B // 4 + 1, 1, 1, 1)[:B].contiguous()
-    shape_list = np.array([[H, W, 1.0, 1.0]] * B)
-    # Random weights give noise-like maps; so that the post-process does realistic work (~130 text boxes per
-    # image) the text-like stress maps are blended into the timed path's post-process input as a SECOND pass
-    stress = torch.from_numpy(synth_prob_maps(4, H, W, seed=7 + rank)).to(device).repeat(B // 4 + 1, 1, 1)[:B, None].contiguous()
-
-    def step(pending):
-        """forward of this batch; its post-process is queued on the post-process stream and collected one step later,
-        so it overlaps with the next batch's convolutions (every batch's boxes are on the host before the clock stops)"""
-        with torch.no_grad():
-            out = model(x)
-        futs = []
-        if args.post_input in ("model", "both"):        # the pipeline's own data flow
-            futs.append(post.submit({"maps": out["maps"]}, shape_list))
-        if args.post_input in ("stress", "both"):       # realistic ~140 boxes/image load (random weights give noise maps)
-            futs.append(post.submit({"maps": stress}, shape_list))
-        res = [f.result() for f in pending] if args.overlap else []
-        if not args.overlap:
-            res = [f.result() for f in futs]
-            futs = []
-        return futs, (res[-1] if res else [])
-
-    pending = []
-    for _ in range(args.warmup):
-        pending, _ = step(pending)
-    for f in pending:
-        f.result()
-    pending = []
+def _sync_all(world):
+    import torch
     torch.cuda.synchronize()
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
         torch.cuda.synchronize()
-    ops.PROFILE = [] if rank == 0 else None
-    ops.PROFILE_LABELS = [] if rank == 0 else None
-    t0 = time.perf_counter()
-    nbox = 0
-    for _ in range(args.steps):
-        pending, res = step(pending)
-        nbox += sum(len(r["points"]) for r in res)
-    for f in pending:                                    # drain: the last batch's boxes
-        res = f.result()
-    nbox += sum(len(r["points"]) for r in res) if pending else 0
-    torch.cuda.synchronize()
+
+
+def _max_over_ranks(dt, world, device):
     if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    prof, labels = ops.PROFILE, ops.PROFILE_LABELS
-    ops.PROFILE = ops.PROFILE_LABELS = None
-    if world > 1:
+        import torch
+        import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    if rank != 0:
-        return None
-    # Dominant kernel = conv_wino_kernel (Winograd F(2x2,3x3) on fp32 MFMA: every 3x3/s1 layer).  `achieved` counts the
-    # ALGORITHMIC (direct-convolution) FLOPs of those launches, as SURVEY 8d defines the work; Winograd executes 2.25x fewer
-    # multiplies, so `executed_*` gives what the matrix pipe really ran (the honest utilisation of the 157.3 TFLOP/s peak).
+    return dt
+
+
+def _conv_profile(prof, labels):
+    """HIP-event durations of the conv launches of the timed region, split into Winograd launches and the rest."""
     ms = [e0.elapsed_time(e1) for e0, e1 in prof]
-    conv_ms = sum(ms)
-    n_launch = len(prof)
     wino_ms, wino_flops, n_wino = 0.0, 0.0, 0
     for lab, t in zip(labels, ms):
         if lab.startswith("wino3x3"):
             n_, h_, w_, ci = [int(v) for v in lab.split()[1].split("->")[0].split("x")]
             co = int(lab.split("->")[1].split()[0])
-            wino_ms += t; n_wino += 1
+            wino_ms += t
+            n_wino += 1
             wino_flops += 2.0 * n_ * h_ * w_ * ci * co * 9
-    conv_flops = (DET_VARIANTS[args.det_model][2] - DET_TAIL_GFLOP_PER_IMG) * 1e9 * B * args.steps
-    conv_all = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    achieved = wino_flops / (wino_ms * 1e-3) / 1e12 if wino_ms > 0 else 0.0
+    return sum(ms), len(ms), wino_ms, wino_flops, n_wino
+
+
+def _profile_json(name):
+    p = os.path.join(ROOT, "profiles", name)
+    if os.path.exists(p):
+        with open(p) as f:
+            return json.load(f)
+    return None
+
+
+def _wino_roofline(wino_ms, wino_flops, n_wino, steps, what):
+    """`achieved` / `frac` = what the matrix pipe EXECUTED (Winograd F(2x2,3x3) runs 1/2.25 of the direct-convolution
+    multiplies): a utilisation, <= 1.  The algorithmic (direct-convolution) rate of the same launches is reported
+    beside it as `algorithmic_tflops` -- it can exceed the peak because of the algorithmic gain, and is not a fraction."""
+    alg = wino_flops / (wino_ms * 1e-3) / 1e12 if wino_ms > 0 else 0.0
+    traffic = (_profile_json("conv_traffic.json") or {}).get("hbm_bytes_per_launch")
+    return {"bound": "mfma", "achieved": round(alg / WINOGRAD_GAIN, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(alg / WINOGRAD_GAIN / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "kernel": "conv_wino_kernel (%s; %d launches per step, %.3f ms avg launch, HIP events on the launch stream); achieved = "
+                      "executed MFMA FLOPs (direct-convolution FLOPs / 2.25) of those launches / their time"
+                      % (what, n_wino // max(steps, 1), wino_ms / max(n_wino, 1)),
+            "algorithmic_tflops": round(alg, 2), "algorithmic_over_peak": round(alg / PEAK_F32_MFMA_TFLOPS, 4)}
+
+
+def run_det(args, rank, local, world, device):
+    import numpy as np
+    import torch
+    from pytorchocr_amd.modeling import ops
+    from pytorchocr_amd.postprocess import build_post_process
+    from pytorchocr_amd.utils.synth import synth_images, synth_prob_maps
+    B, H, W = args.batch or 32, 736, 1280
+    det_cfg, det_contract, gflop_img = DET_VARIANTS[args.det_model]
+    model = build_and_sync_weights(det_cfg, det_contract, device, rank, world)
+    post = build_post_process(DET_POST, dict(use_gpu=True, seed=2022))
+    nd = min(args.distinct_images, B)
+    base = synth_images(nd, 3, H, W, seed=2022 + rank)               # nd distinct seeded images, tiled to the batch
+    x = torch.from_numpy(base).to(device).repeat(B // nd + 1, 1, 1, 1)[:B].contiguous()
+    shape_list = np.array([[H, W, 1.0, 1.0]] * B)
+    # Random weights give noise-like maps; so that the post-process does realistic work (~140 text boxes per
+    # image) text-like stress maps are post-processed inside the timed step as a SECOND pass
+    stress = torch.from_numpy(synth_prob_maps(nd, H, W, seed=7 + rank)).to(device).repeat(B // nd + 1, 1, 1)[:B, None].contiguous()
+    tags = [t for t in ("model", "stress") if args.post_input in (t, "both")]
+
+    def step(pending):
+        """forward of this batch; its post-process is queued on the post-process stream and collected one step later,
+        so it overlaps with the next batch's convolutions (every batch's boxes are on the host before the clock stops)"""
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        with torch.no_grad():
+            out = model(x)
+        futs = []
+        if "model" in tags:                              # the pipeline's own data flow
+            futs.append(post.submit({"maps": out["maps"]}, shape_list))
+        if "stress" in tags:                             # realistic ~140 boxes/image load
+            futs.append(post.submit({"maps": stress}, shape_list))
+        if not args.overlap:
+            return [], [f.result() for f in futs], ev
+        return futs, [f.result() for f in pending], ev
+
+    pending = []
+    for _ in range(args.warmup):
+        pending, _, _ = step(pending)
+    for f in pending:
+        f.result()
+    pending = []
+    _sync_all(world)
+    ops.PROFILE = [] if rank == 0 else None
+    ops.PROFILE_LABELS = [] if rank == 0 else None
+    post.device_ms_log = []
+    nbox = {t: 0 for t in tags}
+    events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pending, res, ev = step(pending)
+        events.append(ev)
+        for t, r in zip(tags, res):
+            nbox[t] += sum(len(i["points"]) for i in r)
+    for t, f in zip(tags, pending):                      # drain: the last batch's boxes
+        nbox[t] += sum(len(i["points"]) for i in f.result())
+    ev_end = torch.cuda.Event(enable_timing=True)
+    ev_end.record()
+    _sync_all(world)
+    dt = time.perf_counter() - t0
+    prof, labels = ops.PROFILE, ops.PROFILE_LABELS
+    ops.PROFILE = ops.PROFILE_LABELS = None
+    post_ms = post.device_ms_log
+    post.device_ms_log = None
+    dt = _max_over_ranks(dt, world, device)
+    if rank != 0:
+        return None
+    events.append(ev_end)
+    step_ms = [events[i].elapsed_time(events[i + 1]) for i in range(len(events) - 1)]
+    conv_ms, n_launch, wino_ms, wino_flops, n_wino = _conv_profile(prof, labels)
+    conv_flops = (gflop_img - DET_TAIL_GFLOP_PER_IMG) * 1e9 * B * args.steps
+    # post-process stage: device time of every call (HIP events on the post-process stream, inside the timed region, i.e. while
+    # the next batch's convolutions share the chip), and the same call alone on an idle chip
+    by_tag = {t: post_ms[i::len(tags)] for i, t in enumerate(tags)} if tags else {}
+    alone = []
+    if "stress" in tags or "model" in tags:
+        src = stress if "stress" in tags else None
+        if src is not None:
+            post.device_ms_log = alone
+            for _ in range(12):
+                post({"maps": src}, shape_list)
+            post.device_ms_log = None
+            alone = alone[2:]
+    post_bytes = float(POST_BYTES_PER_PIXEL) * H * W * B
+    pk = "stress" if "stress" in tags else ("model" if tags else None)
+    roofline_post = None
+    if pk:
+        ms_in = median(by_tag[pk])
+        ms_alone = median(alone) if alone else None
+        best = ms_alone or ms_in
+        roofline_post = {
+            "bound": "hbm", "achieved": round(post_bytes / (best * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+            "frac": round(post_bytes / (best * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+            "traffic": (_profile_json("post_traffic.json") or {}).get("hbm_bytes_per_call"),
+            "stage": "DB post-process of %d maps %dx%d (%s maps): %d B/pixel accounting (SURVEY 8d) = %.1f MB per call / median device "
+                     "time of the call's kernels alone on the chip (HIP events on its stream)" % (B, H, W, pk, POST_BYTES_PER_PIXEL, post_bytes / 1e6),
+            "ms_per_call_alone": round(ms_alone, 4) if ms_alone else None,
+            "ms_per_call_overlapped": {t: round(median(v), 4) for t, v in by_tag.items()},
+            "per_kernel": (_profile_json("post_traffic.json") or {}).get("per_kernel"),
+        }
     cpu = det_cpu_baseline(args.cpu_images, H, W) if world == 1 and args.cpu_images > 0 else None
-    traffic = None
-    tp = os.path.join(ROOT, "profiles", "conv_traffic.json")       # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
-    if os.path.exists(tp):
-        with open(tp) as f:
-            traffic = json.load(f).get("hbm_bytes_per_launch")
-    line = {
+    roof = _wino_roofline(wino_ms, wino_flops, n_wino, args.steps, "every 3x3/s1 layer")
+    roof["all_conv"] = {"launches_per_step": n_launch // max(args.steps, 1), "ms_per_step": round(conv_ms / max(args.steps, 1), 3),
+                        "algorithmic_tflops": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2) if conv_ms > 0 else 0.0,
+                        "kernels": "conv_wino_kernel (3x3 s1) + stem_conv_kernel (7x7 s2) + conv_pw64_kernel (FPN in2) + conv_mfma_v2_kernel (3x3 s2, other 1x1)"}
+    return {
         "metric": "images/sec end-to-end (DBNet-r18 det+post, 736x1280)" if args.det_model == "r18"
                   else "images/sec end-to-end (%s det+post, 736x1280; NOT the BASELINE metric)" % args.det_model,
         "value": round(world * B * args.steps / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "DBNet r18 fp32, batch %d synthetic 736x1280 per GPU, HIP conv + HIP DBPostProcess "
-                               "(BASELINE.json configs[1])" % B,
-                   "global_batch": world * B, "post_input": args.post_input, "post_overlap": bool(args.overlap), "boxes_per_image": round(nbox / (B * args.steps), 1),
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "ms_per_step_median": round(median(step_ms), 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "DBNet %s fp32, batch %d synthetic 736x1280 per GPU (%d distinct images tiled), HIP conv + HIP DBPostProcess "
+                               "(BASELINE.json configs[1])" % (args.det_model, B, nd),
+                   "global_batch": world * B, "post_input": args.post_input, "post_overlap": bool(args.overlap),
+                   "boxes_per_image": {t: round(v / (B * args.steps), 1) for t, v in nbox.items()},
                    "parallelism": "image-sharded x%d, RCCL weight broadcast only" % world},
-        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                     "kernel": "conv_wino_kernel (%d launches per step, %.3f ms avg launch, HIP events on the launch stream); "
-                               "achieved = direct-convolution FLOPs of those launches / their time"
-                               % (n_wino // max(args.steps, 1), wino_ms / max(n_wino, 1)),
-                     "executed_tflops": round(achieved / 2.25, 2), "executed_frac": round(achieved / 2.25 / PEAK_F32_MFMA_TFLOPS, 4),
-                     "all_conv": {"launches_per_step": n_launch // max(args.steps, 1), "ms_per_step": round(conv_ms / max(args.steps, 1), 3),
-                                  "algorithmic_tflops": round(conv_all, 2),
-                                  "kernels": "conv_wino_kernel (3x3 s1) + stem_conv_kernel (7x7 s2) + conv_pw64_kernel (FPN in2) + conv_mfma_v2_kernel (3x3 s2, other 1x1)"}},
-        "cpu_baseline": cpu,
+        "roofline": roof, "roofline_post": roofline_post, "cpu_baseline": cpu,
     }
-    return line
 
 
 def run_crnn(args, rank, local, world, device):
+    import torch
+    from pytorchocr_amd.modeling import ops
     from pytorchocr_amd.postprocess import build_post_process
     from pytorchocr_amd.utils.synth import synth_text_lines
-    B = args.batch
+    B = args.crnn_batch
     model = build_and_sync_weights(crnn_cfg(), "rec_vgg_bilstm_ctc", device, rank, world)
     post = build_post_process(dict(name="CTCLabelDecode"), dict(character_dict_path=os.path.join(
         ROOT, "pytorchocr_amd", "utils", "char_dict_6623.txt"), use_space_char=False))
-    base = synth_text_lines(16, 32, 320, seed=2022 + rank)
-    x = torch.from_numpy(base).to(device).repeat(B // 16 + 1, 1, 1, 1)[:B].contiguous()
+    nd = min(max(args.distinct_images, 16), B)
+    base = synth_text_lines(nd, 32, 320, seed=2022 + rank)
+    x = torch.from_numpy(base).to(device).repeat(B // nd + 1, 1, 1, 1)[:B].contiguous()
 
     def step(pending):
         """forward + CTC arg-max of this batch on the GPU; its label ids / confidences travel to pinned host memory behind it
         and are decoded to text (host Python, as in the reference) one step later, i.e. while the next batch computes.  Every
         batch's texts are on the host before the clock stops."""
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
         with torch.no_grad():
-            fut = post.submit(model.forward_greedy(x)) if args.overlap else None
-            res = pending.result() if pending is not None else None
             if not args.overlap:
-                res = post(model.forward_greedy(x))
-        return fut, res
+                return None, post(model.forward_greedy(x)), ev
+            fut = post.submit(model.forward_greedy(x))
+            res = pending.result() if pending is not None else None
+        return fut, res, ev
 
     pending = None
     for _ in range(args.warmup):
-        pending, _ = step(pending)
+        pending, _, _ = step(pending)
     if pending is not None:
         pending.result()
     pending = None
-    torch.cuda.synchronize()
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    _sync_all(world)
+    ops.PROFILE = [] if rank == 0 else None
+    ops.PROFILE_LABELS = [] if rank == 0 else None
     nchar = 0
+    events = []
+    t0 = time.perf_counter()
     for _ in range(args.steps):
-        pending, res = step(pending)
+        pending, res, ev = step(pending)
+        events.append(ev)
         nchar += sum(len(t) for t, _ in res) if res else 0
     if pending is not None:
-        res = pending.result()                               # drain: the last batch's texts
-        nchar += sum(len(t) for t, _ in res)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier(); torch.cuda.synchronize()
+        nchar += sum(len(t) for t, _ in pending.result())    # drain: the last batch's texts
+    ev_end = torch.cuda.Event(enable_timing=True)
+    ev_end.record()
+    _sync_all(world)
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    prof, labels = ops.PROFILE, ops.PROFILE_LABELS
+    ops.PROFILE = ops.PROFILE_LABELS = None
+    dt = _max_over_ranks(dt, world, device)
     if rank != 0:
         return None
-    achieved = CRNN_GFLOP_PER_LINE * 1e9 * B * args.steps / dt / 1e12
+    events.append(ev_end)
+    step_ms = [events[i].elapsed_time(events[i + 1]) for i in range(len(events) - 1)]
+    conv_ms, n_launch, wino_ms, wino_flops, n_wino = _conv_profile(prof, labels)
+    roof = _wino_roofline(wino_ms, wino_flops, n_wino, args.steps, "VGG conv1..conv5")
+    roof["traffic"] = (_profile_json("crnn_traffic.json") or {}).get("hbm_bytes_per_launch")
+    roof["whole_step_algorithmic_tflops"] = round(CRNN_GFLOP_PER_LINE * 1e9 * B * args.steps / dt / 1e12, 2)
+    roof["all_conv"] = {"launches_per_step": n_launch // max(args.steps, 1), "ms_per_step": round(conv_ms / max(args.steps, 1), 3)}
     return {
         "metric": "CRNN text-lines/sec (vgg_v1_x1.0 + BiLSTM + CTC greedy, 32x320)",
         "value": round(world * B * args.steps / dt, 2), "unit": "text-lines/sec", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "ms_per_step_median": round(median(step_ms), 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "CRNN vgg_v1_x1.0 + CTC greedy, batch %d synthetic 32x320 gray crops per GPU (BASELINE.json configs[2])" % B,
                    "global_batch": world * B, "decode_overlap": bool(args.overlap), "chars_per_line": round(nchar / (B * args.steps), 1),
                    "parallelism": "line-sharded x%d" % world},
-        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                     "kernel": "whole step (end-to-end FLOP rate; per-kernel split in profiles/)"},
+        "roofline": roof,
         "cpu_baseline": crnn_cpu_baseline(args.cpu_lines) if world == 1 and args.cpu_lines > 0 else None,
     }
+
+
+def run_dry(args, rank, world):
+    """PTOCR_BENCH_DRY=1: control-flow rehearsal without a GPU (tests/test_bench_launch.py): rendezvous over gloo, barrier,
+    K timed sleeps, max over ranks, one JSON line from rank 0.  Nothing is measured; the line says so."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", init_method="env://")
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (control flow only, nothing measured)", "value": 0.0, "unit": "images/sec", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none (dry run)",
+                          "config": {"workload": "PTOCR_BENCH_DRY rehearsal"}, "roofline": {"frac": 0.0}, "cpu_baseline": None}), flush=True)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="det", choices=["det", "crnn"])
-    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 32 det / 512 crnn)")
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (SURVEY 8d: >= 100 for the median)")
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="det", choices=["det", "crnn", "ocr"],
+                    help="det = the headline line (with the CRNN configs[2] result embedded under \"crnn\"); crnn = configs[2] alone; "
+                         "ocr = configs[4] (DB++ r18 -> crops -> CRNN over 64 images of 1280x960)")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 32 det / 512 crnn / 64 ocr)")
+    ap.add_argument("--crnn-steps", type=int, default=-1, help="steps of the embedded CRNN measurement (default: --steps; 0 = skip it)")
+    ap.add_argument("--distinct-images", type=int, default=8, help="distinct synthetic images / maps tiled to the batch")
     ap.add_argument("--post-input", default="both", choices=["both", "stress", "model", "none"],
                     help="maps post-processed inside the timed step: the model's own maps (true data flow; random weights "
-                         "give noise-like maps), text-like stress maps with ~130 boxes per image, or both (default: "
+                         "give noise-like maps), text-like stress maps with ~140 boxes per image, or both (default: "
                          "strictly more work than the real pipeline); none = forward only, a diagnostic that is NOT the metric")
     ap.add_argument("--det-model", default="r18", choices=sorted(DET_VARIANTS),
-                    help="r18 = BASELINE configs[1] (the metric); r18pp (DB++ / ASF) and mbv3s (MobileNetV3-small, fp32) are the "
-                         "other detectors of the hot path, timed for DESIGN.md only")
+                    help="r18 = BASELINE configs[1] (the metric); r18pp (DB++ / ASF) and mbv3s (MobileNetV3-small) are the "
+                         "other detectors of the hot path")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false",
                     help="run the post-process synchronously after each forward instead of overlapping it with the next batch")
     ap.add_argument("--cpu-images", type=int, default=8, help="images in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-lines", type=int, default=256, help="text lines in the CRNN CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
-    if args.batch == 0:
-        args.batch = 32 if args.workload == "det" else 512
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(sys.argv[1:], args.gpus)               # never returns
     rank, local, world = dist_env()
     if world != args.gpus:
-        if args.gpus == 1 and world == 1:
-            pass
-        else:
-            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if os.environ.get("PTOCR_BENCH_DRY") == "1":
+        return run_dry(args, rank, world)
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
     ndev = torch.cuda.device_count()
-    local = local % max(ndev, 1)          # one process per GPU; the modulo only matters for the 2-ranks-on-1-GPU rehearsal
+    if world > ndev:
+        # more ranks than GPUs is only the one-GPU rehearsal of the launch path: the split LSTM needs every CU for one
+        # process, and RCCL wants one device per rank
+        os.environ.setdefault("PTOCR_LSTM_SPLIT", "0")
+        os.environ.setdefault("PTOCR_DIST_BACKEND", "gloo")
+    local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
@@ -351,7 +499,24 @@ def main():
             dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
         else:
             dist.init_process_group(backend=backend, init_method="env://")
-    line = (run_det if args.workload == "det" else run_crnn)(args, rank, local, world, device)
+    args.crnn_batch = (args.batch or 512) if args.workload == "crnn" else 512
+    if args.workload == "det":
+        line = run_det(args, rank, local, world, device)
+        crnn_steps = args.steps if args.crnn_steps < 0 else args.crnn_steps
+        if crnn_steps > 0 and args.det_model == "r18":
+            import copy
+            a2 = copy.copy(args)
+            a2.steps = crnn_steps
+            a2.warmup = min(args.warmup, 10)
+            torch.cuda.empty_cache()
+            crnn = run_crnn(a2, rank, local, world, device)
+            if rank == 0:
+                line["crnn"] = crnn
+    elif args.workload == "crnn":
+        line = run_crnn(args, rank, local, world, device)
+    else:
+        from pytorchocr_amd.deploy.bench_ocr import run_ocr_bench
+        line = run_ocr_bench(args, rank, local, world, device)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

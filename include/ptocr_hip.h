@@ -164,6 +164,10 @@ int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, const uint8_t
                             int use_padding_resize, int use_dilation, int16_t *h_boxes, int max_boxes, int32_t *h_counts,
                             int32_t *h_flags, void *stream);
 
+/* Measurement hook (no reference counterpart): device time in ms, by HIP events on the call's own stream, from the first to
+ * the last kernel of the LAST ptocr_db_postprocess call on this workspace (the call has synchronised that stream). */
+int ptocr_dbpost_last_device_ms(ptocr_dbpost_t h, float *ms);
+
 /* Inspection hook for the parity tests: per-candidate records of the LAST ptocr_db_postprocess call for image `img`
  * (synchronises the device).  h_total: number of border starts found -- exact below 1000; for an image with more, the
  * count of the bottom strip that already holds the 1000 used ones (>= 1000, the rest of the image is not labelled).  h_results: 1000 x {int status; int box[8]; float score; float rect[5]; int npix;

@@ -1217,6 +1217,8 @@ struct ptocr_dbpost {
     unsigned *gslots; int *slot_locks; long slot_words; Result *results; int *flags; int *src_wh; short *boxes; int *counts;
     int boxes_cap;
     long pool_cap;
+    hipEvent_t ev0, ev1;          // device time of the last call's kernels (ptocr_dbpost_last_device_ms)
+    int timed;
 };
 
 extern "C" int ptocr_dbpost_create(ptocr_dbpost_t *out, int max_n, int max_h, int max_w) {
@@ -1247,6 +1249,8 @@ extern "C" int ptocr_dbpost_create(ptocr_dbpost_t *out, int max_n, int max_h, in
     PT_HIP(hipMalloc(&h->src_wh, sizeof(int) * 2 * max_n));
     PT_HIP(hipMalloc(&h->boxes, sizeof(short) * 8 * max_n * MAX_CAND));
     PT_HIP(hipMalloc(&h->counts, sizeof(int) * max_n));
+    PT_HIP(hipEventCreate(&h->ev0));
+    PT_HIP(hipEventCreate(&h->ev1));
     *out = h;
     return 0;
 }
@@ -1256,6 +1260,8 @@ extern "C" int ptocr_dbpost_destroy(ptocr_dbpost_t h) {
     void *bufs[] = {h->bits, h->bits2, h->labels, h->chunk_cnt, h->totals, h->strip_totals, h->cands, h->info, h->pool, h->gslots, h->slot_locks,
                     h->results, h->flags, h->src_wh, h->boxes, h->counts};
     for (void *b : bufs) (void)hipFree(b);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
     return 0;
 }
@@ -1269,6 +1275,13 @@ extern "C" int ptocr_dbpost_debug_results(ptocr_dbpost_t h, int img, int32_t *h_
     PT_HIP(hipMemcpy(h_results, h->results + (long)img * MAX_CAND, sizeof(Result) * MAX_CAND, hipMemcpyDeviceToHost));
     PT_HIP(hipMemcpy(h_cands, h->cands + (long)img * MAX_CAND, sizeof(Cand) * MAX_CAND, hipMemcpyDeviceToHost));
     PT_HIP(hipMemcpy(h_info, h->info + (long)img * MAX_CAND, sizeof(CandInfo) * MAX_CAND, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// device time (HIP events on the call's stream) from the first to the last kernel of the last call on this workspace
+extern "C" int ptocr_dbpost_last_device_ms(ptocr_dbpost_t h, float *ms) {
+    PT_CHECK(h && ms && h->timed, "ptocr_dbpost_last_device_ms: no completed call on this workspace");
+    PT_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));
     return 0;
 }
 
@@ -1296,6 +1309,7 @@ extern "C" int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, co
     d.pool_cap = h->pool_cap;
     d.pool_stride = QOFF + h->pool_cap;
     PT_HIP(hipMemcpyAsync(h->src_wh, h_src_wh, sizeof(int) * 2 * N, hipMemcpyHostToDevice, s));
+    PT_HIP(hipEventRecord(h->ev0, s));
     PT_HIP(hipMemsetAsync(h->flags, 0, sizeof(int) * N, s));
     const dim3 row_grid(cdiv(W, 1024), H, N);
     if (d_bitmap) hipLaunchKernelGGL(pack_u8_kernel, row_grid, dim3(256), 0, s, d_bitmap, h->bits, d);
@@ -1329,6 +1343,8 @@ extern "C" int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, co
                        h->slot_locks, h->results, h->flags, h->src_wh, box_thresh, unclip_ratio, h->slot_words, use_padding_resize, d);
     hipLaunchKernelGGL(compact_kernel, dim3(N), dim3(1024), 0, s, h->results, h->totals, h->boxes, h->counts, max_boxes);
     if (int e = launch_ok("dbpost kernels")) return e;
+    PT_HIP(hipEventRecord(h->ev1, s));
+    h->timed = 1;
     PT_HIP(hipMemcpyAsync(h_counts, h->counts, sizeof(int) * N, hipMemcpyDeviceToHost, s));
     PT_HIP(hipMemcpyAsync(h_flags, h->flags, sizeof(int) * N, hipMemcpyDeviceToHost, s));
     PT_HIP(hipMemcpyAsync(h_boxes, h->boxes, sizeof(short) * 8 * (size_t)N * max_boxes, hipMemcpyDeviceToHost, s));

@@ -45,6 +45,12 @@ class _Workspace:
             self._host = hb
         return tuple(t[:n].numpy() for t in hb)
 
+    def last_device_ms(self):
+        """device time of the last call's kernels on this workspace (HIP events on the call's stream)"""
+        ms = C.c_float(0)
+        _lib.check(_lib.lib().ptocr_dbpost_last_device_ms(self.handle, C.byref(ms)), "ptocr_dbpost_last_device_ms")
+        return float(ms.value)
+
     def close(self):
         if self.handle is not None:
             _lib.lib().ptocr_dbpost_destroy(self.handle)
@@ -86,6 +92,21 @@ def device_boxes(maps, src_wh, thresh, box_thresh, unclip_ratio, bitmap=None, us
     return [boxes[i, :counts[i]].copy() for i in range(n)], flags.copy()
 
 
+_FLAG_TEXT = {1: "a candidate's unclip distance was below 0.75 px (sub-pixel sliver: Clipper's union clean-up is not "
+                  "reproduced for it, DESIGN.md section 4)",
+              2: "a box score within 1e-6 of box_thresh was re-summed in the reference's raster order"}
+
+
+def _warn_flags(flags):
+    """The per-image exception flags of ptocr_db_postprocess are never silent: one warning per call that raised any."""
+    import warnings
+    bits = int(np.bitwise_or.reduce(np.asarray(flags, np.int64)))
+    imgs = [int(i) for i in np.nonzero(flags)[0][:8]]
+    warnings.warn("DBPostProcess: images %s%s raised exception flags: %s (see DBPostProcess.last_flags)" % (
+        imgs, "..." if int(np.count_nonzero(flags)) > 8 else "", "; ".join(t for b, t in _FLAG_TEXT.items() if bits & b)),
+        RuntimeWarning, stacklevel=3)
+
+
 class DBPostProcess(object):
     """The post process for Differentiable Binarization (DB) -- same constructor and call contract as the reference."""
 
@@ -93,6 +114,8 @@ class DBPostProcess(object):
                  score_mode="poly", cpp_speedup=False, out_polygon=False, **kwargs):
         self.thresh = thresh
         self.box_thresh = box_thresh
+        # kept for the contract only: the C++ path this class follows hard-codes 1000 (db_postprocess.cpp:238-239) and never
+        # reads the Python attribute (db_postprocess.py:57-63 passes no max_candidates to cpp_boxes_from_bitmap)
         self.max_candidates = max_candidates
         self.unclip_ratio = unclip_ratio
         self.min_size = 3
@@ -102,6 +125,7 @@ class DBPostProcess(object):
         self.use_dilation = use_dilation
         self.cpp_speedup = cpp_speedup
         self.last_flags = None
+        self.device_ms_log = None        # bench.py sets this to a list: device ms of every call, in submission order
         self._ws = _Workspace()          # per-instance workspace: instances may run on different streams / threads
         self._pool = None
         self._stream = None
@@ -155,6 +179,10 @@ class DBPostProcess(object):
         boxes, flags = device_boxes(pred, src_wh, self.thresh, self.box_thresh, self.unclip_ratio,
                                     use_padding_resize=use_padding_resize, ws=self._ws, use_dilation=self.use_dilation)
         self.last_flags = flags
+        if self.device_ms_log is not None:
+            self.device_ms_log.append(self._ws.last_device_ms())
+        if flags.any():
+            _warn_flags(flags)
         return [{"points": b, "scores": [1.0] * len(b)} for b in boxes]
 
 

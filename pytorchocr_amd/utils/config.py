@@ -1,49 +1,54 @@
-"""YAML config loading: mirror of reference deploy/utils.py:8-62 (AttrDict, load_config, merge_config with dotted keys)."""
+"""YAML config loading with the semantics of the reference's deploy/utils.py:8-62: `load_config(path)` returns an
+attribute-style top-level dict seeded with Global.debug = False; `merge_config(overrides, cfg)` merges one level deep
+for plain keys and walks dotted keys ("Global.use_gpu") down existing sections."""
 import os
 
 import yaml
 
 
 class AttrDict(dict):
-    """Single level attribute dict, NOT recursive"""
+    """dict whose TOP-LEVEL keys can also be read as attributes (nested dicts stay plain dicts, as in the reference)."""
 
     def __init__(self, **kwargs):
-        super(AttrDict, self).__init__()
-        super(AttrDict, self).update(kwargs)
+        dict.__init__(self, **kwargs)
 
-    def __getattr__(self, key):
-        if key in self:
-            return self[key]
-        raise AttributeError("object has no attribute '{}'".format(key))
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError("object has no attribute '{}'".format(name)) from None
+
+
+def _set_dotted(cfg, dotted, value):
+    head, *rest = dotted.split(".")
+    if head not in cfg:
+        raise AssertionError("the sub_keys can only be one of global_config: {}, but get: {}, "
+                             "please check your running command".format(cfg.keys(), head))
+    node = cfg[head]
+    for part in rest[:-1]:
+        node = node[part]
+    node[rest[-1]] = value
 
 
 def merge_config(config, global_config):
+    """Merge `config` into `global_config` in place and return it.  A dict value under an existing plain key updates that
+    section (one level); anything else replaces; "A.b.c" keys assign into the existing section A."""
     for key, value in config.items():
-        if "." not in key:
-            if isinstance(value, dict) and key in global_config:
-                global_config[key].update(value)
-            else:
-                global_config[key] = value
+        if "." in key:
+            _set_dotted(global_config, key, value)
+        elif isinstance(value, dict) and key in global_config:
+            global_config[key].update(value)
         else:
-            sub_keys = key.split(".")
-            assert sub_keys[0] in global_config, \
-                "the sub_keys can only be one of global_config: {}, but get: {}, please check your running command".format(
-                    global_config.keys(), sub_keys[0])
-            cur = global_config[sub_keys[0]]
-            for idx, sub_key in enumerate(sub_keys[1:]):
-                if idx == len(sub_keys) - 2:
-                    cur[sub_key] = value
-                else:
-                    cur = cur[sub_key]
+            global_config[key] = value
     return global_config
 
 
 def load_config(file_path):
-    """Load config from yml/yaml file (yaml.Loader: the reference's ymls use !!python/tuple, det_r18_db.yml:50)."""
-    global_config = AttrDict()
-    merge_config({"Global": {"debug": False}}, global_config)
-    _, ext = os.path.splitext(file_path)
-    assert ext in [".yml", ".yaml"], "only support yaml files for now"
+    """Read a .yml / .yaml config.  yaml.Loader (not safe_load): the reference's ymls carry python tags such as
+    !!python/tuple (det_r18_db.yml:50)."""
+    if os.path.splitext(file_path)[1] not in (".yml", ".yaml"):
+        raise AssertionError("only support yaml files for now")
+    cfg = AttrDict(Global={"debug": False})
     with open(file_path, "rb") as f:
-        merge_config(yaml.load(f, Loader=yaml.Loader), global_config)
-    return global_config
+        loaded = yaml.load(f, Loader=yaml.Loader)
+    return merge_config(loaded, cfg)

@@ -1,17 +1,17 @@
-"""Host utilities on the path.  `sort_boxes` mirrors reference pytocr/utils/utility.py:32-50 (row P8 of SURVEY 8a)."""
-import numpy as np
+"""Host utilities on the path.  `sort_boxes` has the semantics of reference pytocr/utils/utility.py:32-50 (row P8 of
+SURVEY 8a); `get_part_img` (:53-78) lives in utils/warp.py and is re-exported here under the reference's module path."""
+from .warp import get_part_img  # noqa: F401
 
 
 def sort_boxes(dt_boxes):
-    """Sort text boxes top-to-bottom, left-to-right: stable sort by (y0, x0) of vertex 0, then ONE pass of adjacent
-    swaps when two neighbours are within 10 px in y and out of order in x.  Arithmetic stays in the array's dtype
-    (int16 from DBPostProcess), like the reference."""
-    num_boxes = dt_boxes.shape[0]
-    sorted_boxes = sorted(dt_boxes, key=lambda x: (x[0][1], x[0][0]))
-    _boxes = list(sorted_boxes)
-    for i in range(num_boxes - 1):
-        if abs(_boxes[i + 1][0][1] - _boxes[i][0][1]) < 10 and (_boxes[i + 1][0][0] < _boxes[i][0][0]):
-            tmp = _boxes[i]
-            _boxes[i] = _boxes[i + 1]
-            _boxes[i + 1] = tmp
-    return _boxes
+    """Reading order for text boxes [K,4,2]: a STABLE sort on vertex 0 by (y, x), followed by exactly one left-to-right pass
+    that swaps neighbours whose vertex-0 rows are closer than 10 px while their x order is inverted (one pass only: a box
+    moves at most one place per earlier neighbour, as in the reference).  Returns a list of the K [4,2] arrays; comparisons
+    and the |dy| run in the array's own dtype (int16 from DBPostProcess), like the reference."""
+    order = sorted(range(dt_boxes.shape[0]), key=lambda i: (dt_boxes[i][0][1], dt_boxes[i][0][0]))
+    boxes = [dt_boxes[i] for i in order]
+    for i in range(1, len(boxes)):
+        upper, lower = boxes[i - 1], boxes[i]
+        if abs(lower[0][1] - upper[0][1]) < 10 and lower[0][0] < upper[0][0]:
+            boxes[i - 1], boxes[i] = lower, upper
+    return boxes

@@ -193,3 +193,22 @@ def test_small_cin_conv_pack_layout():
             out[:, oy, ox] = xp[:, oy:oy + 3, ox:ox + 3].reshape(27) @ w
     out += pc.small_b.numpy()[:, None, None]
     assert np.abs(out - ref).max() < 1e-5
+
+
+def test_pytocr_alias_package_resolves_the_reference_import_lines():
+    """the five import lines of the reference's deploy scripts (infer_det.py:18-22, run_ocr.py:18-22), unchanged"""
+    from pytocr.data import create_operators, transform  # noqa: F401
+    from pytocr.modeling.architectures import build_model
+    from pytocr.postprocess import build_post_process
+    from pytocr.utils.save_load import load_pretrained_params
+    from pytocr.utils.utility import sort_boxes, get_part_img  # noqa: F401
+    import pytorchocr_amd.modeling.architectures as real
+    import pytorchocr_amd.postprocess as realp
+    import pytorchocr_amd.utils.save_load as reals
+    assert build_model is real.build_model and build_post_process is realp.build_post_process
+    assert load_pretrained_params is reals.load_pretrained_params
+    import pytocr.modeling.ops as o1
+    import pytorchocr_amd.modeling.ops as o2
+    assert o1 is o2                                        # an alias, not a second copy of the module state
+    with pytest.raises(ModuleNotFoundError):
+        import pytocr.losses  # noqa: F401
