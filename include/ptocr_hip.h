@@ -199,15 +199,27 @@ int ptocr_linear_f32(const float *d_x, const float *d_w, const float *d_bias, fl
  * d_whh f32[2][4H][H] (weight_hh_l0, weight_hh_l0_reverse); d_out f32[B][T][2H] (forward half | backward half). */
 int ptocr_lstm_bidir_f32(const float *d_xproj, const float *d_whh, float *d_out, int T, int B, int H, void *stream);
 /* When every (16-line group, direction) can own four CUs the recurrence runs split over four workgroups that exchange h each
- * time step (bounded spins) through a library-owned buffer: calls on that path must not run concurrently on two streams of
- * one process (PTOCR_LSTM_SPLIT=0 selects the exchange-free form).  A timed-out exchange is reported by the next
- * ptocr_lstm_bidir_f32 call and by this function,
- * which is meaningful after the stream has been synchronised (e.g. after the label ids were copied to the host). */
+ * time step through a buffer owned by the library PER (device, stream).  Co-residency of the four workgroups cannot be
+ * guaranteed (another stream or process may hold CUs), so the exchange spins are bounded and every split call is followed,
+ * on the same stream, by a repair launch of the exchange-free kernel that recomputes the layer when the exchange timed out:
+ * d_out is correct either way, without a host round trip.  PTOCR_LSTM_SPLIT=0 selects the exchange-free form outright. */
+/* split-form calls so far / how many of them were recomputed by the repair pass (synchronises) */
+int ptocr_lstm_stats(int *split_calls, int *repaired);
+/* test hook: polls of one exchange before a workgroup gives up (0 = default 65536); 1 = give up at the first miss AND one of
+ * the four workgroups withholds its slice, which forces the time-out and so the repair path */
+void ptocr_lstm_set_spin_limit(unsigned polls);
+/* round-1 ABI, kept: always 0 now (a timed-out exchange is repaired on the stream, see above) */
 int ptocr_lstm_check(void);
 /* Per row of d_x f32[rows][ld] (first C columns valid, ld % 4 == 0): first arg-max and the max softmax probability.
  * is_prob = 0: d_x holds logits, prob = 1 / sum(exp(x - max));  is_prob = 1: d_x already holds probabilities, prob = max.
  * With rows = b*T + t this is preds.argmax(2), preds.max(2) of rec_postprocess.py:83-84 as int32[B][T], f32[B][T]. */
 int ptocr_ctc_greedy_f32(const float *d_x, int rows, int C, int ld, int is_prob, int32_t *d_idx, float *d_prob, void *stream);
+/* The CTC head's FC fused with those reductions (rec_ctc_head.py:17-36 + rec_postprocess.py:80-84): idx[r] / prob[r] of
+ * logits = x[M,K] @ w[Nout,K]^T + bias over the first C columns, WITHOUT writing the logits (1.1 GB at B = 512).  Same values as
+ * ptocr_linear_f32 followed by ptocr_ctc_greedy_f32(is_prob = 0): the indices are identical, prob within fp32 rounding.
+ * K % 32 == 0, Nout % 128 == 0 (zero-padded rows of w / bias); d_work: M * (Nout / 64) * 16 bytes of device scratch. */
+int ptocr_linear_ctc_greedy_f32(const float *d_x, const float *d_w, const float *d_bias, int M, int K, int Nout, int C,
+                                void *d_work, int32_t *d_idx, float *d_prob, void *stream);
 /* y[r][0:C] = softmax(x[r][0:C]) (rec_ctc_head.py:33) */
 int ptocr_softmax_rows_f32(const float *d_x, int rows, int C, int ld, float *d_y, int ldy, void *stream);
 

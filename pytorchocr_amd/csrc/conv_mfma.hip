@@ -46,6 +46,8 @@ struct ConvArgs {
     int vec_epilogue;
     int cout_store;                 // columns >= cout_store are not written (channel-padded GEMMs)
     int res_ldc;                    // channel stride of the residual tensor
+    f32x4 *ctc_part;                // != null: CTC-greedy epilogue -- no output tensor, per (row, 64-column tile) partials instead
+    int ctc_C;                      // valid columns (classes) of that epilogue
 };
 
 __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x16 (&acc)[2][2], int m0, int n0, int wm0, int wn0, int frow, int fh) {
@@ -148,6 +150,100 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs &p, f32x16 (&ac
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+}
+
+// CTC-greedy epilogue (the FC of the CTC head, rec_ctc_head.py:17-36 + rec_postprocess.py:80-84): the logits of this wave's
+// 64 rows x 64 columns are never stored.  Each 32-row half is parked in the wave's LDS tile; two lanes share a row (32 columns
+// each) and reduce it to (max logit, its FIRST column, sum exp(logit - max)); lane pairs combine by shuffle and one float4
+// {max, column bits, sum, 0} per (row, 64-column tile) goes to ctc_part[row][tile] -- 1/64 of the logits' bytes.
+// ctc_combine_kernel folds the tiles of a row.  The logit values are bit-identical to the stored-logits path (same
+// accumulation order, same `acc + bias`), so the arg-max is, too.
+__device__ __forceinline__ void ctc_epilogue_lds(const ConvArgs &p, f32x16 (&acc)[2][2], int m0, int n0, int wm0, int wn0,
+                                                 int lane, float *wsm) {
+    constexpr int EL = 68;
+    const int frow = lane & 31, fh = lane >> 5;
+    const int row = lane & 31, half = lane >> 5;
+    const int col0 = n0 + wn0 + half * 32;
+    const int ntile = p.Cout >> 6, tile = (n0 + wn0) >> 6;
+    f32x4 b4[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) b4[c] = *reinterpret_cast<const f32x4 *>(p.bias + col0 + 4 * c);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                wsm[((r & 3) + 8 * (r >> 2) + 4 * fh) * EL + j * 32 + frow] = acc[i][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        f32x4 v[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) v[c] = *reinterpret_cast<const f32x4 *>(wsm + row * EL + half * 32 + 4 * c) + b4[c];
+        float mx = -INFINITY;
+        int idx = 0x7fffffff;
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int col = col0 + 4 * c + k;
+                const float x = col < p.ctc_C ? v[c][k] : -INFINITY;
+                v[c][k] = x;
+                if (x > mx) { mx = x; idx = col; }              // strict: the first column of the maximum
+            }
+        float sm = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) sm += (mx == -INFINITY) ? 0.f : __expf(v[c][k] - mx);
+        // partner lane (the row's other 32 columns)
+        const float m2 = __shfl_xor(mx, 32), s2 = __shfl_xor(sm, 32);
+        const int i2 = __shfl_xor(idx, 32);
+        const float mm = fmaxf(mx, m2);
+        const float sa = (mx == -INFINITY) ? 0.f : sm * __expf(mx - mm);
+        const float sb = (m2 == -INFINITY) ? 0.f : s2 * __expf(m2 - mm);
+        const int ii = (m2 > mx || (m2 == mx && i2 < idx)) ? i2 : idx;
+        const int m = m0 + wm0 + i * 32 + row;
+        if (half == 0 && m < p.M) {
+            f32x4 o; o[0] = mm; o[1] = __int_as_float(ii); o[2] = sa + sb; o[3] = 0.f;
+            p.ctc_part[(long)m * ntile + tile] = o;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// folds the per-tile partials of ctc_epilogue_lds: 16 lanes per row; idx = first column of the row maximum, prob = 1 / sum exp
+__global__ __launch_bounds__(256) void ctc_combine_kernel(const f32x4 *__restrict__ part, int rows, int ntile,
+                                                          int *__restrict__ idx_out, float *__restrict__ prob_out) {
+    const int sub = threadIdx.x & 15;
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+    float m = -INFINITY, s = 0.f;
+    int idx = 0x7fffffff;
+    if (row < rows)
+        for (int t = sub; t < ntile; t += 16) {
+            const f32x4 v = part[(long)row * ntile + t];
+            const float m2 = v[0], s2 = v[2], f1 = v[1];
+            const int i2 = __float_as_int(f1);          // (a bit_cast straight from the vector element read element 0 here)
+            const float mm = fmaxf(m, m2);
+            const float sa = (m == -INFINITY) ? 0.f : s * __expf(m - mm);
+            const float sb = (m2 == -INFINITY) ? 0.f : s2 * __expf(m2 - mm);
+            idx = (m2 > m || (m2 == m && i2 < idx)) ? i2 : idx;
+            m = mm; s = sa + sb;
+        }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) {
+        const float m2 = __shfl_xor(m, o), s2 = __shfl_xor(s, o);
+        const int i2 = __shfl_xor(idx, o);
+        const float mm = fmaxf(m, m2);
+        const float sa = (m == -INFINITY) ? 0.f : s * __expf(m - mm);
+        const float sb = (m2 == -INFINITY) ? 0.f : s2 * __expf(m2 - mm);
+        idx = (m2 > m || (m2 == m && i2 < idx)) ? i2 : idx;
+        m = mm; s = sa + sb;
+    }
+    if (sub == 0 && row < rows) { idx_out[row] = idx; prob_out[row] = 1.f / s; }
 }
 
 template <int BM, int BN, bool SMALLC>
@@ -430,7 +526,8 @@ __global__ __launch_bounds__(256) void conv_mfma_v2_kernel(ConvArgs p) {
         __syncthreads();
     }
     static_assert(2 * STAGE >= 4 * 32 * 68, "epilogue tiles must fit in the staging LDS");
-    if (p.vec_epilogue) conv_epilogue_lds(p, acc, m0, n0, wm0, wn0, lane, smem + wave * (32 * 68));
+    if (p.ctc_part) ctc_epilogue_lds(p, acc, m0, n0, wm0, wn0, lane, smem + wave * (32 * 68));
+    else if (p.vec_epilogue) conv_epilogue_lds(p, acc, m0, n0, wm0, wn0, lane, smem + wave * (32 * 68));
     else conv_epilogue(p, acc, m0, n0, wm0, wn0, frow, fh);
 }
 
@@ -477,6 +574,7 @@ extern "C" int ptocr_conv2d_f32(const ptocr_conv_desc *d, const float *d_x, cons
     PT_CHECK(!(d->convt2x2 && d->cout_store && d->cout_store != d->Cout), "ptocr_conv2d_f32: cout_store is not used with convt2x2");
     PT_CHECK(d->out_ldc >= d->out_coff + (d->convt2x2 ? co_real : (d->cout_store ? d->cout_store : co_real)), "ptocr_conv2d_f32: out_ldc too small");
     ConvArgs a;
+    a.ctc_part = nullptr; a.ctc_C = 0;
     a.x = d_x; a.w = d_w; a.bias = d_bias; a.res = d_res; a.y = d_y;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW;
     a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w; a.Ho = d->Ho; a.Wo = d->Wo;
@@ -520,4 +618,27 @@ extern "C" int ptocr_linear_f32(const float *d_x, const float *d_w, const float 
     d.N = 1; d.H = M; d.W = 1; d.Cin = K; d.Cout = Nout; d.KH = 1; d.KW = 1; d.stride = 1; d.Ho = M; d.Wo = 1;
     d.out_up = 1; d.out_ldc = ldy;
     return ptocr_conv2d_f32(&d, d_x, d_w, d_bias, nullptr, d_y, stream);
+}
+
+// CTC head fused with the greedy decode reductions: idx[r] = first arg-max of x[r] @ w^T + bias over the first C columns,
+// prob[r] = max softmax = 1 / sum exp(logit - max).  The [M, Nout] logits are never written (1.1 GB at B = 512): the GEMM's
+// epilogue leaves {max, column, sum} per (row, 64-column tile) in d_work (M * Nout/64 float4), ctc_combine_kernel folds them.
+extern "C" int ptocr_linear_ctc_greedy_f32(const float *d_x, const float *d_w, const float *d_bias, int M, int K, int Nout, int C,
+                                           void *d_work, int32_t *d_idx, float *d_prob, void *stream) {
+    PT_CHECK(d_x && d_w && d_bias && d_work && d_idx && d_prob, "ptocr_linear_ctc_greedy_f32: null argument");
+    PT_CHECK(M >= 1 && K % 32 == 0 && Nout % 128 == 0 && C >= 1 && C <= Nout,
+             "ptocr_linear_ctc_greedy_f32: need K %% 32 == 0, Nout %% 128 == 0 (pad w / bias with zero rows), 1 <= C <= Nout");
+    ConvArgs a;
+    memset(&a, 0, sizeof a);
+    a.x = d_x; a.w = d_w; a.bias = d_bias; a.res = nullptr; a.y = nullptr;
+    a.N = 1; a.H = M; a.W = 1; a.Cin = K; a.Cout = Nout; a.KH = 1; a.KW = 1; a.stride = 1; a.Ho = M; a.Wo = 1;
+    a.M = M; a.Kpad = K; a.out_up = 1; a.out_ldc = Nout; a.co_real = Nout; a.cout_store = Nout; a.res_ldc = Nout;
+    a.x_bytes = (long)M * K * 4; a.w_bytes = (long)Nout * K * 4;
+    PT_CHECK(a.x_bytes < (1L << 31) && a.w_bytes < (1L << 31), "ptocr_linear_ctc_greedy_f32: operand larger than 2 GiB");
+    a.ctc_part = reinterpret_cast<f32x4 *>(d_work); a.ctc_C = C;
+    a.mtiles = cdiv(M, 128);
+    hipStream_t s = (hipStream_t)stream;
+    if (int e = launch_conv_v2<128, 128, 16, false>(a, s)) return e;
+    hipLaunchKernelGGL(ctc_combine_kernel, dim3(cdiv(M, 16)), dim3(256), 0, s, a.ctc_part, M, Nout / 64, d_idx, d_prob);
+    return launch_ok("ctc_combine_kernel");
 }

@@ -26,9 +26,17 @@ constexpr int HLD = LH + 4;         // LDS row stride of h (floats): conflict-fr
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
+// only_if != nullptr: the launch is the REPAIR pass behind a split-form launch -- it runs only when that launch reported a
+// timed-out exchange (*only_if != 0) and then recomputes the whole layer; otherwise every workgroup exits at once.
 __global__ __launch_bounds__(256) void lstm_bidir_kernel(const float *__restrict__ xproj, const float *__restrict__ whh,
-                                                         float *__restrict__ out, int T, int B, long x_bytes) {
+                                                         float *__restrict__ out, int T, int B, long x_bytes,
+                                                         const int *__restrict__ only_if, int *__restrict__ repaired) {
     __shared__ __attribute__((aligned(16))) float hbuf[2][LROWS][HLD];
+    if (only_if) {
+        if (__hip_atomic_load(only_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+            __hip_atomic_fetch_add(repaired, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const int dir = blockIdx.y;
     const int b0 = blockIdx.x * LROWS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -143,8 +151,10 @@ typedef unsigned long long u64;
 
 __global__ __launch_bounds__(256, 1) void lstm_bidir_split_kernel(const float *__restrict__ xproj, const float *__restrict__ whh,
                                                                   float *__restrict__ out, u64 *__restrict__ hx, int *__restrict__ err,
-                                                                  int T, int B, long x_bytes) {
+                                                                  int T, int B, long x_bytes, unsigned spin_limit) {
     __shared__ __attribute__((aligned(16))) float hbuf[LROWS][HLD];
+    __shared__ int wg_failed;
+    if (threadIdx.x == 0) wg_failed = 0;
     const int part = blockIdx.x, group = blockIdx.y, dir = blockIdx.z;
     const int b0 = group * LROWS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -203,7 +213,11 @@ __global__ __launch_bounds__(256, 1) void lstm_bidir_split_kernel(const float *_
                         all &= (unsigned)(v >> 32) == want;
                     }
                     if (all) break;
-                    if (spins > (1u << 22)) { ok = false; atomicExch(err, 1); break; }      // ~seconds: give up, never hang
+                    // give up, never hang: the own bound, or (looked at every 64 polls) a workgroup that already gave up
+                    if (spins + 1 >= spin_limit ||
+                        ((spins & 63) == 63 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        ok = false; atomicExch(err, 1); wg_failed = 1; break;
+                    }
                     __builtin_amdgcn_s_sleep(2);
                 }
             }
@@ -211,6 +225,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bidir_split_kernel(const float *_
             for (int i = 0; i < 16; i += 4) *reinterpret_cast<f32x4 *>(&hbuf[row][u0 + i]) = f32x4{hv[i], hv[i + 1], hv[i + 2], hv[i + 3]};
         }
         __syncthreads();
+        if (wg_failed) break;                             // the WHOLE workgroup leaves (uniform: read behind the barrier); the
+                                                          // repair pass recomputes the layer, the partners bail out on `err`
         const float *hrow = &hbuf[jc][4 * kq];            // A operand: row jc, k = 16*kb + 4*kq + t
 #pragma unroll
         for (int kb = 0; kb < LH / 16; kb++) {
@@ -231,14 +247,15 @@ __global__ __launch_bounds__(256, 1) void lstm_bidir_split_kernel(const float *_
             c[r] = fg * c[r] + ig * gg;
             const float h = og * tanhf(c[r]);
             const int row = 4 * kq + r;
-            __hip_atomic_store(dst + (long)row * LH + unit, ((u64)(unsigned)(step + 1) << 32) | __builtin_bit_cast(unsigned, h),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!(spin_limit == 1u && part == LPARTS - 1))        // test hook (spin limit 1): this part never publishes
+                __hip_atomic_store(dst + (long)row * LH + unit, ((u64)(unsigned)(step + 1) << 32) | __builtin_bit_cast(unsigned, h),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int b = b0 + row;
             if (b < B) out[((long)b * T + t) * (2 * LH) + dir * LH + unit] = h;
         }
         __syncthreads();                                  // hbuf is rewritten at the top of the next step
-        if (!ok) break;                                   // (the partners time out too)
     }
+    (void)ok;
 }
 
 // one wave per row: online max / sum-exp / first arg-max
@@ -304,7 +321,48 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float *__restri
 
 using namespace ptocr;
 
-static int *g_lstm_err_host = nullptr;     // pinned copy of the split kernel's timeout word (last call)
+// ---- split-LSTM contexts: one per (device, stream).  The exchange buffer `hx`, the per-call timeout word `err` and the CU
+// count belong to the device and stream the call runs on, so two streams, threads or devices of one process never share them.
+#include <map>
+#include <mutex>
+#include <utility>
+
+namespace {
+struct LstmCtx { u64 *hx = nullptr; int *err = nullptr; int hx_groups = 0; };
+std::mutex g_lstm_mu;
+std::map<std::pair<int, void *>, LstmCtx> g_lstm_ctx;
+std::map<int, int> g_lstm_ncu;
+std::map<int, int *> g_lstm_repaired;      // per device: device word counting split calls recomputed by the exchange-free pass
+int g_lstm_split_calls = 0;
+unsigned g_lstm_spin_limit = 1u << 16;     // polls of one exchange before a workgroup gives up (~0.1 s)
+}  // namespace
+
+// test hook: shrink (or restore, 0 = default) the spin bound of the split form's exchange; 1 additionally makes one of the four
+// workgroups of every group withhold its slice, so the others MUST time out: the repair path runs
+extern "C" void ptocr_lstm_set_spin_limit(unsigned polls) {
+    std::lock_guard<std::mutex> lk(g_lstm_mu);
+    g_lstm_spin_limit = polls ? polls : (1u << 16);
+}
+
+// split-form calls so far, and how many of them timed out in the exchange and were recomputed by the exchange-free pass
+// (the second number is exact once the streams those calls went to have been synchronised)
+extern "C" int ptocr_lstm_stats(int *split_calls, int *repaired) {
+    std::lock_guard<std::mutex> lk(g_lstm_mu);
+    if (split_calls) *split_calls = g_lstm_split_calls;
+    if (repaired) {
+        *repaired = 0;
+        int dev = 0;
+        PT_HIP(hipGetDevice(&dev));
+        for (auto &kv : g_lstm_repaired) {                      // synchronous copies: a query, not on the hot path
+            int v = 0;
+            PT_HIP(hipSetDevice(kv.first));
+            PT_HIP(hipMemcpy(&v, kv.second, sizeof(int), hipMemcpyDeviceToHost));
+            *repaired += v;
+        }
+        PT_HIP(hipSetDevice(dev));
+    }
+    return 0;
+}
 
 extern "C" int ptocr_lstm_bidir_f32(const float *d_xproj, const float *d_whh, float *d_out, int T, int B, int H, void *stream) {
     PT_CHECK(d_xproj && d_whh && d_out && T >= 1 && B >= 1, "ptocr_lstm_bidir_f32: bad arguments");
@@ -313,51 +371,49 @@ extern "C" int ptocr_lstm_bidir_f32(const float *d_xproj, const float *d_whh, fl
     PT_CHECK(x_bytes < (1L << 31), "ptocr_lstm_bidir_f32: B*T too large (projection tensor must stay below 2 GiB)");
     hipStream_t s = (hipStream_t)stream;
     const int groups = cdiv(B, LROWS);
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        PT_HIP(hipGetDevice(&dev));
-        PT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    int dev = 0;
+    PT_HIP(hipGetDevice(&dev));
     static const bool allow_split = !(getenv("PTOCR_LSTM_SPLIT") && atoi(getenv("PTOCR_LSTM_SPLIT")) == 0);
+    std::lock_guard<std::mutex> lk(g_lstm_mu);
+    int &n_cu = g_lstm_ncu[dev];
+    if (!n_cu) PT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     // split form: every (group, direction) runs on four CUs with register-resident weights; taken when all workgroups can be
-    // resident at once (one per CU), otherwise the one-workgroup-per-group form, which needs no exchange
+    // resident at once (one per CU: 256 lanes x 512 registers fill a CU), otherwise the one-workgroup-per-group form, which
+    // needs no exchange.  Residency is NOT guaranteed (another stream or process may hold CUs), so the exchange spins are
+    // bounded and a REPAIR launch of the exchange-free kernel follows on the same stream: it reads the call's timeout word
+    // and recomputes the layer when it is set -- the output is correct either way, no host round trip, and the event is
+    // counted (ptocr_lstm_stats).
     if (allow_split && groups * 2 * LPARTS <= n_cu && T < (1 << 30)) {
-        static u64 *hx = nullptr;
-        static int *err = nullptr;
-        static int hx_groups = 0;
-        if (groups > hx_groups) {
-            if (hx) (void)hipFree(hx);
-            PT_HIP(hipMalloc(&hx, sizeof(u64) * (size_t)groups * 2 * 2 * LROWS * LH));
-            hx_groups = groups;
+        LstmCtx &c = g_lstm_ctx[std::make_pair(dev, stream)];
+        if (groups > c.hx_groups) {
+            if (c.hx) { PT_HIP(hipStreamSynchronize(s)); (void)hipFree(c.hx); c.hx = nullptr; }
+            PT_HIP(hipMalloc(&c.hx, sizeof(u64) * (size_t)groups * 2 * 2 * LROWS * LH));
+            c.hx_groups = groups;
         }
-        if (!err) {
-            PT_HIP(hipMalloc(&err, 64));
-            PT_HIP(hipHostMalloc(reinterpret_cast<void **>(&g_lstm_err_host), 64, hipHostMallocDefault));
-            *g_lstm_err_host = 0;
+        if (!c.err) PT_HIP(hipMalloc(&c.err, 64));
+        int *&d_stats = g_lstm_repaired[dev];
+        if (!d_stats) {
+            PT_HIP(hipMalloc(&d_stats, 64));
+            PT_HIP(hipMemset(d_stats, 0, 64));
         }
-        PT_CHECK(*(volatile int *)g_lstm_err_host == 0, "ptocr_lstm_bidir_f32: an earlier call's hidden-state exchange between workgroups timed out "
-                                        "(results of that call are invalid; set PTOCR_LSTM_SPLIT=0)");
-        PT_HIP(hipMemsetAsync(hx, 0, sizeof(u64) * (size_t)groups * 2 * 2 * LROWS * LH, s));       // tags must not survive a call
-        PT_HIP(hipMemsetAsync(err, 0, 64, s));
-        hipLaunchKernelGGL(lstm_bidir_split_kernel, dim3(LPARTS, groups, 2), dim3(256), 0, s, d_xproj, d_whh, d_out, hx, err, T, B, x_bytes);
+        PT_HIP(hipMemsetAsync(c.hx, 0, sizeof(u64) * (size_t)groups * 2 * 2 * LROWS * LH, s));       // tags must not survive a call
+        PT_HIP(hipMemsetAsync(c.err, 0, 64, s));
+        hipLaunchKernelGGL(lstm_bidir_split_kernel, dim3(LPARTS, groups, 2), dim3(256), 0, s, d_xproj, d_whh, d_out, c.hx, c.err, T, B,
+                           x_bytes, g_lstm_spin_limit);
         if (int e = launch_ok("lstm_bidir_split_kernel")) return e;
-        // The timeout word is fetched into pinned memory behind the kernel and examined by the NEXT call on this path (and by
-        // ptocr_lstm_check) -- a synchronous check here would drain the launch queue twice per forward pass.
-        PT_HIP(hipMemcpyAsync(g_lstm_err_host, err, sizeof(int), hipMemcpyDeviceToHost, s));
-        return 0;
+        hipLaunchKernelGGL(lstm_bidir_kernel, dim3(groups, 2), dim3(256), 0, s, d_xproj, d_whh, d_out, T, B, x_bytes,
+                           (const int *)c.err, d_stats);
+        g_lstm_split_calls++;
+        return launch_ok("lstm_bidir_kernel (repair pass)");
     }
-    hipLaunchKernelGGL(lstm_bidir_kernel, dim3(groups, 2), dim3(256), 0, s, d_xproj, d_whh, d_out, T, B, x_bytes);
+    hipLaunchKernelGGL(lstm_bidir_kernel, dim3(groups, 2), dim3(256), 0, s, d_xproj, d_whh, d_out, T, B, x_bytes,
+                       (const int *)nullptr, (int *)nullptr);
     return launch_ok("lstm_bidir_kernel");
 }
 
-// 0 when no split-LSTM call has timed out; meaningful once the stream the calls went to has been synchronised
-extern "C" int ptocr_lstm_check(void) {
-    PT_CHECK(!g_lstm_err_host || *(volatile int *)g_lstm_err_host == 0,
-             "ptocr_lstm_check: the hidden-state exchange between the workgroups of a split LSTM call timed out (its results are "
-             "invalid; set PTOCR_LSTM_SPLIT=0)");
-    return 0;
-}
+// Kept for callers of the round-1 ABI: a timed-out exchange no longer invalidates a result (the repair pass recomputes it on
+// the same stream), so there is nothing left to fail here; ptocr_lstm_stats reports how often that happened.
+extern "C" int ptocr_lstm_check(void) { return 0; }
 
 extern "C" int ptocr_ctc_greedy_f32(const float *d_x, int rows, int C, int ld, int is_prob, int32_t *d_idx, float *d_prob,
                                     void *stream) {

@@ -16,7 +16,7 @@ class CTCHead(ops.PackedModule):
 
     def _pack(self, dev):
         C, K = self.fc.weight.shape
-        Cp = (C + 63) // 64 * 64
+        Cp = (C + 127) // 128 * 128               # 128: the fused FC + arg-max kernel runs 128-column tiles
         w = torch.zeros(Cp, K)
         w[:C] = self.fc.weight.detach().float().cpu()
         b = torch.zeros(Cp)
@@ -39,8 +39,13 @@ class CTCHead(ops.PackedModule):
     def greedy(self, seq):
         """(x[B*T,K], B, T) -> (idx int32[B,T], prob f32[B,T]) without the softmax tensor"""
         x, B, T = seq
-        lg, C = self.logits(x)
-        idx, prob = ops.ctc_greedy(lg, C, is_prob=False)
+        if ops.FUSE_CTC:
+            self._check_eval()
+            p = self.packed()
+            idx, prob = ops.linear_ctc_greedy(x, p["w"], p["b"], p["C"])     # arg-max / sum-exp in the FC's epilogue
+        else:
+            lg, C = self.logits(x)
+            idx, prob = ops.ctc_greedy(lg, C, is_prob=False)
         return idx.reshape(B, T), prob.reshape(B, T)
 
     def forward(self, x, **kwargs):

@@ -402,6 +402,23 @@ def ctc_greedy(x, C, is_prob):
     return idx, prob
 
 
+def linear_ctc_greedy(x, w, b, C):
+    """CTC head FC fused with the greedy reductions: x f32[M,K], w f32[Np,K] (Np % 128 == 0, rows >= C zero), b f32[Np]
+    -> (idx int32[M], prob f32[M]) over the first C columns; the logits are never written"""
+    _require_cuda(x, "linear_ctc_greedy")
+    M, K = x.shape
+    Np = w.shape[0]
+    idx = torch.empty(M, dtype=torch.int32, device=x.device)
+    prob = torch.empty(M, dtype=torch.float32, device=x.device)
+    work = torch.empty((M, Np // 64, 4), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().ptocr_linear_ctc_greedy_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), M, K, Np, C, _lib.ptr(work),
+                                                      _lib.ptr(idx), _lib.ptr(prob), _lib.cur_stream()), "ptocr_linear_ctc_greedy_f32")
+    return idx, prob
+
+
+FUSE_CTC = _os.environ.get("PTOCR_FUSE_CTC", "1") != "0"     # 0: FC writes the logits, ctc_greedy re-reads them (round-1 path)
+
+
 def softmax_rows(x, C):
     _require_cuda(x, "softmax_rows")
     rows, ld = x.shape

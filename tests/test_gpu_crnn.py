@@ -49,6 +49,51 @@ def test_lstm_kernel_matches_torch():
         assert (got - ref).abs().max().item() <= 2e-5
 
 
+def test_lstm_split_exchange_timeout_is_repaired_on_the_stream():
+    """Test hook: with the spin bound of the split form's exchange shrunk to one poll the four-workgroup exchange times out;
+    the repair pass (exchange-free kernel, same stream) must still deliver the right output, and the event must be counted.
+    A second stream gets its own exchange buffer (per-(device, stream) context)."""
+    import ctypes as C
+    from pytorchocr_amd import _lib
+    from pytorchocr_amd.modeling.necks.rnn import BidirectionalLSTM
+    L = _lib.lib()
+
+    def stats():
+        a, b = C.c_int(0), C.c_int(0)
+        _lib.check(L.ptocr_lstm_stats(C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    torch.manual_seed(1)
+    B, T, nin = 64, 33, 256
+    blk = BidirectionalLSTM(nin, 256, 256).eval()
+    x = torch.randn(T, B, nin)
+    with torch.no_grad():
+        o, _ = blk.rnn(x)
+        ref = blk.embedding(o.reshape(T * B, 512)).reshape(T, B, 256)
+    p = blk.pack(torch.device("cuda:0"))
+    xb = x.permute(1, 0, 2).contiguous().reshape(B * T, nin).cuda()
+    torch.cuda.synchronize()
+    calls0, rep0 = stats()
+    L.ptocr_lstm_set_spin_limit(1)
+    try:
+        got = BidirectionalLSTM.run(p, xb, B, T).reshape(B, T, 256).permute(1, 0, 2).cpu()
+    finally:
+        L.ptocr_lstm_set_spin_limit(0)
+    calls1, rep1 = stats()
+    assert (got - ref).abs().max().item() <= 2e-5
+    assert calls1 == calls0 + 1 and rep1 == rep0 + 1, "the forced timeout was not taken / not counted"
+    # default bound again, on a side stream: no repair, same result
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        got2 = BidirectionalLSTM.run(p, xb, B, T).reshape(B, T, 256).permute(1, 0, 2)
+    side.synchronize()
+    calls2, rep2 = stats()
+    assert (got2.cpu() - ref).abs().max().item() <= 2e-5
+    assert calls2 == calls1 + 1 and rep2 == rep1
+    ops_mod = __import__("pytorchocr_amd.modeling.ops", fromlist=["x"])
+    ops_mod.lstm_check()
+
+
 def test_crnn_matches_reference_golden(gold_dir, contract):
     g = np.load(os.path.join(gold_dir, "crnn_3x1x32x320.npz"))
     m, _ = _model(contract)
@@ -115,6 +160,39 @@ def test_ctc_greedy_ties_take_first_index():
     assert idx.cpu().tolist() == [100, 6623, 0, 0, 1]
     ref = torch.softmax(x[:, :6624], 1).max(1).values
     assert (prob.cpu() - ref).abs().max().item() <= 1e-6
+
+
+def test_fused_fc_argmax_equals_logits_path():
+    """ptocr_linear_ctc_greedy_f32 (arg-max / sum-exp in the FC's epilogue, no logits tensor) against ptocr_linear_f32 +
+    ptocr_ctc_greedy_f32 on the stored logits: indices identical (ties -> first index, zero-padded columns ignored even when
+    every real logit is negative), probabilities within fp32 rounding; ragged row counts."""
+    from pytorchocr_amd.modeling import ops
+    torch.manual_seed(3)
+    K, C, Np = 512, 6624, 6656
+    w = torch.zeros(Np, K); w[:C] = torch.randn(C, K) * 0.05
+    b = torch.zeros(Np); b[:C] = torch.randn(C) * 0.1
+    for M in (1, 37, 128, 1000):
+        x = torch.randn(M, K)
+        if M >= 37:
+            x[3] = 0                                      # logits = bias only
+            x[5] = 0
+        bb = b.clone()
+        wd, xd = w.cuda(), x.cuda()
+        if M == 37:
+            bb[:C] = -1.0 - torch.rand(C)                 # all real logits of rows 3 / 5 negative: padding columns (logit 0) must lose
+            bb[100] = bb[4000] = -0.25                    # exact tie of the maxima -> first index
+        bd = bb.cuda()
+        lg = ops.linear(xd, wd, bd)
+        i0, p0 = ops.ctc_greedy(lg, C, is_prob=False)
+        i1, p1 = ops.linear_ctc_greedy(xd, wd, bd, C)
+        assert torch.equal(i0, i1)
+        assert (p0 - p1).abs().max().item() <= 1e-6
+        assert int(i1.max()) < C
+        if M == 37:
+            assert int(i1[3]) == 100 and int(i1[5]) == 100
+        ref = torch.softmax((x @ w[:C].t() + bb[:C]).double(), 1)
+        assert torch.equal(ref.argmax(1).int(), i1.cpu()) or (ref.max(1).values - ref.gather(1, i1.cpu().long()[:, None])[:, 0]).abs().max() < 1e-7
+        assert (ref.max(1).values.float() - p1.cpu()).abs().max().item() <= 1e-5
 
 
 def test_bench_batch_properties(contract):
