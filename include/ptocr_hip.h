@@ -183,9 +183,10 @@ typedef struct { long src_off; int sh, sw; int rh, rw; long dst_off; int dh, dw;
  * mode 1: BGR2GRAY then (x/255 - 0.5)/0.5 in channel 0                (resize_norm_img, rec_img_aug.py:108-134) */
 int ptocr_preprocess_u8_f32(const uint8_t *d_src, float *d_dst, const void *d_items, int n_items, int max_dst_pixels,
                             int mode, int swap_rb, int cpad, const float *h_mean3, const float *h_std3, void *stream);
-typedef struct { double minv[9]; int left, top; int cw, ch; int rot90; long dst_off; } ptocr_warp_item;
-/* Batched get_part_img (utils/utility.py:53-78): perspective warp (INTER_LINEAR, BORDER_REPLICATE) of n text boxes of one
- * u8 HxWx3 image into packed u8 crops; rot90 = np.rot90(crop, 1) when h >= 1.5 w (run_ocr.py:189-191). */
+typedef struct { double minv[9]; int left, top; int cw, ch; int rot90; int img; long dst_off; } ptocr_warp_item;
+/* Batched get_part_img (utils/utility.py:53-78): perspective warp (INTER_LINEAR, BORDER_REPLICATE) of n text boxes into packed
+ * u8 crops; d_img is a stack of equally sized u8 HxWx3 images and item.img selects the source image (0 for a single image);
+ * rot90 = np.rot90(crop, 1) when h >= 1.5 w (run_ocr.py:189-191). */
 int ptocr_warp_crops_u8(const uint8_t *d_img, int H, int W, uint8_t *d_dst, const void *d_items, int n_items,
                         int max_crop_pixels, void *stream);
 

@@ -82,6 +82,7 @@ struct WarpItem {           // one text box of the source image
     int left, top;          // origin of the axis-aligned source crop
     int cw, ch;             // size of the source crop (clamp range) == size of the warped crop before rotation
     int rot90;              // 1: store rotated 90 degrees counter-clockwise (np.rot90(img, 1)) -> output is cw rows x ch cols
+    int img;                // index of the source image inside d_img (a stack of equally sized u8 HxWx3 images; 0 for one image)
     long dst_off;           // byte offset of the u8 output crop (HxWx3) inside d_dst
 };
 
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(256) void warp_crops_kernel(const uint8_t *__restri
     const WarpItem it = items[blockIdx.y];
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= it.cw * it.ch) return;
+    img += (long)it.img * H * W * 3;
     const int y = p / it.cw, x = p - y * it.cw;
     const double den0 = it.minv[6] * x + it.minv[7] * y + it.minv[8];
     const double den = den0 != 0 ? 1.0 / den0 : 0.0;
@@ -120,19 +122,25 @@ using namespace ptocr;
 
 extern "C" int ptocr_preprocess_u8_f32(const uint8_t *d_src, float *d_dst, const void *d_items, int n_items, int max_dst_pixels,
                                        int mode, int swap_rb, int cpad, const float *h_mean3, const float *h_std3, void *stream) {
-    PT_CHECK(d_src && d_dst && d_items && n_items >= 1 && n_items <= 65535 && cpad >= 1 && (mode == 0 || mode == 1), "ptocr_preprocess_u8_f32: bad arguments");
+    PT_CHECK(d_src && d_dst && d_items && n_items >= 1 && cpad >= 1 && (mode == 0 || mode == 1), "ptocr_preprocess_u8_f32: bad arguments");
     PT_CHECK(mode == 1 || (h_mean3 && h_std3 && cpad >= 3), "ptocr_preprocess_u8_f32: mode 0 needs mean/std and cpad >= 3");
     const float m[3] = {mode ? 0.f : h_mean3[0], mode ? 0.f : h_mean3[1], mode ? 0.f : h_mean3[2]};
     const float s[3] = {mode ? 1.f : h_std3[0], mode ? 1.f : h_std3[1], mode ? 1.f : h_std3[2]};
-    hipLaunchKernelGGL(preprocess_kernel, dim3(cdiv(max_dst_pixels, 256), n_items), dim3(256), 0, (hipStream_t)stream, d_src, d_dst,
-                       (const PreItem *)d_items, mode, swap_rb, cpad, m[0], m[1], m[2], s[0], s[1], s[2]);
+    for (int first = 0; first < n_items; first += 65535) {          // grid.y limit
+        const int n = n_items - first < 65535 ? n_items - first : 65535;
+        hipLaunchKernelGGL(preprocess_kernel, dim3(cdiv(max_dst_pixels, 256), n), dim3(256), 0, (hipStream_t)stream, d_src, d_dst,
+                           (const PreItem *)d_items + first, mode, swap_rb, cpad, m[0], m[1], m[2], s[0], s[1], s[2]);
+    }
     return launch_ok("preprocess_kernel");
 }
 
 extern "C" int ptocr_warp_crops_u8(const uint8_t *d_img, int H, int W, uint8_t *d_dst, const void *d_items, int n_items,
                                    int max_crop_pixels, void *stream) {
-    PT_CHECK(d_img && d_dst && d_items && n_items >= 1 && n_items <= 65535, "ptocr_warp_crops_u8: bad arguments");
-    hipLaunchKernelGGL(warp_crops_kernel, dim3(cdiv(max_crop_pixels, 256), n_items), dim3(256), 0, (hipStream_t)stream, d_img, H, W, d_dst,
-                       (const WarpItem *)d_items);
+    PT_CHECK(d_img && d_dst && d_items && n_items >= 1, "ptocr_warp_crops_u8: bad arguments");
+    for (int first = 0; first < n_items; first += 65535) {          // grid.y limit
+        const int n = n_items - first < 65535 ? n_items - first : 65535;
+        hipLaunchKernelGGL(warp_crops_kernel, dim3(cdiv(max_crop_pixels, 256), n), dim3(256), 0, (hipStream_t)stream, d_img, H, W, d_dst,
+                           (const WarpItem *)d_items + first);
+    }
     return launch_ok("warp_crops_kernel");
 }

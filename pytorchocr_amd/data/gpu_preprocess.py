@@ -8,7 +8,6 @@ import numpy as np
 import torch
 
 from .. import _lib
-from ..utils.warp import get_perspective_transform
 
 
 class PreItem(C.Structure):
@@ -18,7 +17,7 @@ class PreItem(C.Structure):
 
 class WarpItem(C.Structure):
     _fields_ = [("minv", C.c_double * 9), ("left", C.c_int), ("top", C.c_int), ("cw", C.c_int), ("ch", C.c_int),
-                ("rot90", C.c_int), ("dst_off", C.c_long)]
+                ("rot90", C.c_int), ("img", C.c_int), ("dst_off", C.c_long)]
 
 
 def _to_dev(arr, device):
@@ -32,17 +31,39 @@ def _u8_dev(img, device):
     return img.contiguous()
 
 
+PRE_DT = np.dtype([("src_off", "<i8"), ("sh", "<i4"), ("sw", "<i4"), ("rh", "<i4"), ("rw", "<i4"), ("dst_off", "<i8"),
+                   ("dh", "<i4"), ("dw", "<i4")], align=True)
+WARP_DT = np.dtype([("minv", "<f8", (9,)), ("left", "<i4"), ("top", "<i4"), ("cw", "<i4"), ("ch", "<i4"), ("rot90", "<i4"),
+                    ("img", "<i4"), ("dst_off", "<i8")], align=True)
+assert PRE_DT.itemsize == C.sizeof(PreItem) and WARP_DT.itemsize == C.sizeof(WarpItem)
+
+
+def _items_dev(arr, device):
+    """numpy structured descriptor array -> device bytes"""
+    return torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1)).to(device)
+
+
 def det_preprocess(img_bgr, target_hw, mean, std, device, swap_rb=True):
     """u8 HxWx3 BGR (ndarray or device tensor) -> f32[1, rh, rw, 4] NHWC4 network input (channel 3 zero)."""
     src = _u8_dev(img_bgr, device)
-    sh, sw = int(src.shape[0]), int(src.shape[1])
+    return det_preprocess_batch(src[None], target_hw, mean, std, swap_rb)
+
+
+def det_preprocess_batch(imgs_dev, target_hw, mean, std, swap_rb=True):
+    """u8[N,H,W,3] BGR device tensor (equally sized images) -> f32[N, rh, rw, 4]: resize + normalise + layout of the whole
+    batch in ONE launch (DetResizeForTest + ToTensor + Normalize, operators.py:41-112,155-252)."""
+    imgs_dev = imgs_dev.contiguous()
+    n, sh, sw = int(imgs_dev.shape[0]), int(imgs_dev.shape[1]), int(imgs_dev.shape[2])
     rh, rw = int(target_hw[0]), int(target_hw[1])
-    out = torch.empty((1, rh, rw, 4), dtype=torch.float32, device=device)
-    items = (PreItem * 1)(PreItem(0, sh, sw, rh, rw, 0, rh, rw))
-    d_items = _to_dev(items, device)
+    out = torch.empty((n, rh, rw, 4), dtype=torch.float32, device=imgs_dev.device)
+    items = np.zeros(n, PRE_DT)
+    items["src_off"] = np.arange(n, dtype=np.int64) * (sh * sw * 3)
+    items["sh"], items["sw"], items["rh"], items["rw"], items["dh"], items["dw"] = sh, sw, rh, rw, rh, rw
+    items["dst_off"] = np.arange(n, dtype=np.int64) * (rh * rw * 4)
+    d_items = _items_dev(items, imgs_dev.device)
     m = (C.c_float * 3)(*[float(v) for v in mean])
     s = (C.c_float * 3)(*[float(v) for v in std])
-    _lib.check(_lib.lib().ptocr_preprocess_u8_f32(_lib.ptr(src), _lib.ptr(out), _lib.ptr(d_items), 1, rh * rw, 0, int(swap_rb), 4, m, s,
+    _lib.check(_lib.lib().ptocr_preprocess_u8_f32(_lib.ptr(imgs_dev), _lib.ptr(out), _lib.ptr(d_items), n, rh * rw, 0, int(swap_rb), 4, m, s,
                                                   _lib.cur_stream()), "ptocr_preprocess_u8_f32")
     return out
 
@@ -50,33 +71,52 @@ def det_preprocess(img_bgr, target_hw, mean, std, device, swap_rb=True):
 def warp_crops(img_dev, boxes):
     """img_dev: u8[H,W,3] device tensor; boxes: list of int (4,2) arrays -> (packed u8 device buffer, [(off, h, w)] per crop)
     with get_part_img + the h >= 1.5 w rotation of run_ocr applied."""
-    H, W = int(img_dev.shape[0]), int(img_dev.shape[1])
-    items, metas, off, maxpix = [], [], 0, 1
-    for box in boxes:
-        pts = np.asarray(box).astype(np.float32)
-        left, right = int(np.min(pts[:, 0])), int(np.max(pts[:, 0]))
-        top, bottom = int(np.min(pts[:, 1])), int(np.max(pts[:, 1]))
-        left, top = max(left, 0), max(top, 0)
-        right, bottom = min(right, W), min(bottom, H)
-        cw, ch = right - left, bottom - top
-        if cw <= 1 or ch <= 1:
-            metas.append(None)
-            continue
-        p = pts - np.array([left, top], np.float32)
-        dst = np.array([[0, 0], [cw - 1, 0], [cw - 1, ch - 1], [0, ch - 1]], np.float32)
-        minv = np.linalg.inv(get_perspective_transform(p, dst))
-        rot = 1 if ch >= 1.5 * cw else 0
-        it = WarpItem((C.c_double * 9)(*minv.reshape(-1).tolist()), left, top, cw, ch, rot, off)
-        items.append(it)
-        metas.append((off, cw, ch) if rot else (off, ch, cw))          # (offset, rows, cols) of the stored crop
-        off += cw * ch * 3
-        maxpix = max(maxpix, cw * ch)
-    buf = torch.empty(max(off, 1), dtype=torch.uint8, device=img_dev.device)
-    if items:
-        arr = (WarpItem * len(items))(*items)
-        d_items = _to_dev(arr, img_dev.device)
-        _lib.check(_lib.lib().ptocr_warp_crops_u8(_lib.ptr(img_dev), H, W, _lib.ptr(buf), _lib.ptr(d_items), len(items), maxpix,
-                                                  _lib.cur_stream()), "ptocr_warp_crops_u8")
+    buf, metas = warp_crops_batch(img_dev[None], [boxes])
+    return buf, metas[0]
+
+
+def warp_crops_batch(imgs_dev, boxes_per_image):
+    """imgs_dev: u8[N,H,W,3] device tensor; boxes_per_image: N lists of int (4,2) boxes -> (packed u8 device buffer, per image a
+    list of (off, rows, cols) / None per box): the perspective crops of ALL boxes of ALL images in one launch.  The 8x8 solves
+    of cv2.getPerspectiveTransform and the 3x3 inverses run batched on the host (LAPACK, one call each)."""
+    from ..utils.warp import get_perspective_transforms
+    H, W = int(imgs_dev.shape[1]), int(imgs_dev.shape[2])
+    counts = [len(b) for b in boxes_per_image]
+    total = int(sum(counts))
+    metas = [[None] * c for c in counts]
+    if total == 0:
+        return torch.empty(1, dtype=torch.uint8, device=imgs_dev.device), metas
+    pts = np.concatenate([np.asarray(b, np.float32).reshape(-1, 4, 2) for b in boxes_per_image if len(b)]).astype(np.float32)
+    img_of = np.repeat(np.arange(len(counts)), counts)
+    left = np.maximum(pts[:, :, 0].min(1).astype(np.int64), 0)
+    top = np.maximum(pts[:, :, 1].min(1).astype(np.int64), 0)
+    right = np.minimum(pts[:, :, 0].max(1).astype(np.int64), W)
+    bottom = np.minimum(pts[:, :, 1].max(1).astype(np.int64), H)
+    cw, ch = right - left, bottom - top
+    ok = (cw > 1) & (ch > 1)
+    if not ok.any():
+        return torch.empty(1, dtype=torch.uint8, device=imgs_dev.device), metas
+    sel = np.nonzero(ok)[0]
+    p = pts[sel] - np.stack([left[sel], top[sel]], 1).astype(np.float32)[:, None, :]
+    cwf, chf = cw[sel].astype(np.float32), ch[sel].astype(np.float32)
+    z = np.zeros_like(cwf)
+    dst = np.stack([np.stack([z, z], 1), np.stack([cwf - 1, z], 1), np.stack([cwf - 1, chf - 1], 1), np.stack([z, chf - 1], 1)], 1)
+    minv = np.linalg.inv(get_perspective_transforms(p, dst))
+    rot = (ch[sel] >= 1.5 * cw[sel]).astype(np.int32)
+    sizes = cw[sel] * ch[sel] * 3
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    items = np.zeros(len(sel), WARP_DT)
+    items["minv"] = minv.reshape(-1, 9)
+    items["left"], items["top"], items["cw"], items["ch"] = left[sel], top[sel], cw[sel], ch[sel]
+    items["rot90"], items["img"], items["dst_off"] = rot, img_of[sel], offs
+    first = np.concatenate([[0], np.cumsum(counts)])
+    for k, g in enumerate(sel):
+        im = int(img_of[g])
+        metas[im][int(g - first[im])] = (int(offs[k]), int(cw[g]), int(ch[g])) if rot[k] else (int(offs[k]), int(ch[g]), int(cw[g]))
+    buf = torch.empty(int(sizes.sum()), dtype=torch.uint8, device=imgs_dev.device)
+    d_items = _items_dev(items, imgs_dev.device)
+    _lib.check(_lib.lib().ptocr_warp_crops_u8(_lib.ptr(imgs_dev.contiguous()), H, W, _lib.ptr(buf), _lib.ptr(d_items), len(sel),
+                                              int((cw[sel] * ch[sel]).max()), _lib.cur_stream()), "ptocr_warp_crops_u8")
     return buf, metas
 
 
@@ -89,13 +129,16 @@ def rec_preprocess(buf, metas, image_shape, device):
     out = torch.empty((max(n, 1), imgH, imgW, 4), dtype=torch.float32, device=device)
     if n == 0:
         return out[:0]
-    items = []
-    for i, (off, h, w) in enumerate(valid):
-        ratio = w / float(h)
-        rw = imgW if math.ceil(imgH * ratio) > imgW else int(math.ceil(imgH * ratio))
-        items.append(PreItem(off, h, w, imgH, max(rw, 1), i * imgH * imgW * 4, imgH, imgW))
-    arr = (PreItem * n)(*items)
-    d_items = _to_dev(arr, device)
+    v = np.asarray(valid, np.int64)                                   # (off, rows, cols)
+    ratio = v[:, 2] / v[:, 1].astype(np.float64)
+    need = np.ceil(imgH * ratio)                                      # math.ceil(imgH * ratio), rec_img_aug.py:119-123
+    rw = np.where(need > imgW, imgW, need).astype(np.int64)
+    items = np.zeros(n, PRE_DT)
+    items["src_off"], items["sh"], items["sw"] = v[:, 0], v[:, 1], v[:, 2]
+    items["rh"], items["rw"] = imgH, np.maximum(rw, 1)
+    items["dst_off"] = np.arange(n, dtype=np.int64) * (imgH * imgW * 4)
+    items["dh"], items["dw"] = imgH, imgW
+    d_items = _items_dev(items, device)
     _lib.check(_lib.lib().ptocr_preprocess_u8_f32(_lib.ptr(buf), _lib.ptr(out), _lib.ptr(d_items), n, imgH * imgW, 1, 0, 4, None, None,
                                                   _lib.cur_stream()), "ptocr_preprocess_u8_f32")
     return out

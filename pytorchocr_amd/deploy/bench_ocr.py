@@ -1,0 +1,96 @@
+"""bench.py --workload ocr: BASELINE.json configs[4] -- run_ocr end to end (DBNet++ r18 detect -> perspective crops -> CRNN
+recognise) over 64 source images of 1280x960, image-sharded over the ranks (no data-path collective; RCCL weight broadcast
+only).  One step = `OCRer.run_batch` over this rank's shard, the u8 images already resident in HBM; every image's
+[box, text, prob] list is on the host when the step ends.
+
+Synthetic data: the detector carries the hand-made brightness checkpoint of utils/synth.py (its probability map is a soft
+threshold of the image brightness), the images are text-like scenes (~140 bright bars each), so the post-process, the crop
+stage and the CRNN see a realistic number of boxes; the CRNN has random-init weights (texts are gibberish, the work is real)."""
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def make_ocrer(device_index, rank=0, world=1):
+    from ..parallel import broadcast_model_
+    from ..utils.config import load_config
+    from ..utils.synth import synth_brightness_detector_state_dict, synth_state_dict
+    from .run_ocr import OCRer
+    cfgs = os.path.join(ROOT, "pytorchocr_amd", "configs")
+    with open(os.path.join(ROOT, "tests", "golden", "state_dict_contract.json")) as f:
+        contract = {m: {k: (tuple(s), d) for k, (s, d) in v.items()} for m, v in json.load(f).items()}
+    ocr = OCRer(load_config(os.path.join(cfgs, "det", "det_r18_dbpp.yml")), None,
+                load_config(os.path.join(cfgs, "rec", "rec_vgg_bilstm_ctc.yml")), None, gpu_id=device_index, gpu_preprocess=True)
+    if rank == 0:
+        det_sd = synth_brightness_detector_state_dict(contract["detpp_r18_db"], use_asf=True)
+        ocr.det.deter.load_state_dict({k: torch.from_numpy(v) for k, v in det_sd.items()}, strict=True)
+        rec_sd = synth_state_dict(contract["rec_vgg_bilstm_ctc"])
+        ocr.rec.recer.load_state_dict({k: torch.from_numpy(v) for k, v in rec_sd.items()}, strict=True)
+    if world > 1:
+        broadcast_model_(ocr.det.deter, src=0)
+        broadcast_model_(ocr.rec.recer, src=0)
+    return ocr
+
+
+def run_ocr_bench(args, rank, local, world, device):
+    from ..parallel import shard_range
+    from ..utils.synth import synth_scene_images
+    total = args.batch or 64
+    H, W = 960, 1280
+    ocr = make_ocrer(device.index, rank, world)
+    lo, hi = shard_range(total, rank, world)
+    nd = max(1, min(args.distinct_images, hi - lo))
+    base = synth_scene_images(nd, H, W, seed=100 + rank)
+    imgs = torch.from_numpy(base).to(device).repeat((hi - lo) // nd + 1, 1, 1, 1)[:hi - lo].contiguous()
+    stats = {}
+    for _ in range(args.warmup):
+        ocr.run_batch(imgs)
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        torch.cuda.synchronize()
+    step_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        t1 = time.perf_counter()
+        ocr.run_batch(imgs, stats=stats)
+        step_ms.append((time.perf_counter() - t1) * 1e3)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return None
+    step_ms.sort()
+    n_local = hi - lo
+    boxes_img = stats.get("boxes", 0) / max(args.steps * n_local, 1)
+    return {
+        "metric": "images/sec end-to-end run_ocr (DBNet++ r18 detect -> crop -> CRNN recognise, 1280x960 sources)",
+        "value": round(total * args.steps / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "ms_per_step_median": round(step_ms[len(step_ms) // 2], 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "run_ocr: DBNet++ r18 (736x992 from 1280x960 u8 sources, GPU pre-process) -> DBPostProcess -> batched "
+                               "perspective crops -> CRNN in 512-line chunks -> CTC decode; %d images total (BASELINE.json configs[4])" % total,
+                   "global_batch": total, "images_per_gpu": n_local, "boxes_per_image": round(boxes_img, 1),
+                   "lines_per_sec": round(stats.get("lines", 0) * world / dt, 1),
+                   "parallelism": "image-sharded x%d, RCCL weight broadcast only" % world},
+        "roofline": {"bound": "mfma", "achieved": round((101.98 * n_local + 4.98 * stats.get("lines", 0) / max(args.steps, 1)) * 1e9 * args.steps
+                                                       / dt / 1e12 / 2.25, 2),
+                     "peak": 157.3, "unit": "TFLOP/s",
+                     "frac": round((101.98 * n_local + 4.98 * stats.get("lines", 0) / max(args.steps, 1)) * 1e9 * args.steps / dt / 1e12 / 2.25 / 157.3, 4),
+                     "traffic": None,
+                     "kernel": "whole pipeline: algorithmic FLOPs (101.98 GFLOP/image DB++ @736x992 + 4.98 GFLOP/line CRNN, SURVEY 8d) / 2.25 "
+                               "(lower bound of the executed MFMA rate: 85 % of the FLOPs run as Winograd) / wall time, host stages included"},
+        "cpu_baseline": None,
+    }

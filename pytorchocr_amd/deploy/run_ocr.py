@@ -44,6 +44,62 @@ class OCRer(object):
         return [[box, t, round(p, 2)] for box, (t, p) in zip(keep, res)]
 
     @torch.no_grad()
+    def run_batch(self, images, rec_batch=512, stats=None):
+        """The reference's per-image `run` (run_ocr.py:167-231) over a LIST of images as one batched pipeline on the GPU:
+        ONE detector forward per group of equally sized images (pre-process of the whole group in one launch), ONE perspective
+        crop launch over all boxes of all images, the CRNN over the crops in chunks of at most `rec_batch` lines, results
+        regrouped per image: [[box, text, prob], ...] per image, equal to [self.run_gpu(i) for i in images].
+        `images`: paths, u8 BGR arrays, or ONE u8[N,H,W,3] device tensor (already resident in HBM)."""
+        from ..data.gpu_preprocess import det_preprocess_batch, rec_preprocess, warp_crops_batch
+        from ..data.imaug import RecResizeImg
+        from ..utils.utility import sort_boxes
+        if self.rec.rec_img_mode != "GRAY":
+            raise NotImplementedError("the GPU recognition pre-process implements the GRAY CRNN input")
+        dev = self.det.det_device
+        if torch.is_tensor(images):
+            groups = [(list(range(images.shape[0])), images.to(dev))]
+            n_img = int(images.shape[0])
+        else:
+            arrs = [read_image_bgr(i) for i in images]
+            n_img = len(arrs)
+            by_shape = {}
+            for k, a in enumerate(arrs):
+                by_shape.setdefault(a.shape, []).append(k)
+            groups = [(idx, torch.from_numpy(np.stack([arrs[k] for k in idx])).to(dev)) for idx in by_shape.values()]
+        rs, nm = self.det._gpu_ops()
+        shape = [o for o in self.rec.rec_ops if isinstance(o, RecResizeImg)][0].image_shape
+        out = [None] * n_img
+        n_boxes = n_lines = 0
+        for idx, stack in groups:
+            src_h, src_w = int(stack.shape[1]), int(stack.shape[2])
+            rh, rw = rs.target_size(src_h, src_w)
+            x4 = det_preprocess_batch(stack, (rh, rw), nm.mean, nm.std, swap_rb=self.det.det_img_mode == "RGB")
+            shapes = np.array([[src_h, src_w, rh / float(src_h), rw / float(src_w)]] * len(idx))
+            res = self.det.det_post_process_class(self.det.deter.forward_nhwc4(x4), shapes)
+            boxes = [sort_boxes(r["points"]) for r in res]
+            buf, metas = warp_crops_batch(stack, boxes)
+            flat = [m for per in metas for m in per]
+            x_rec = rec_preprocess(buf, flat, shape, dev)
+            texts = []
+            pend = None
+            for c0 in range(0, int(x_rec.shape[0]), rec_batch):          # decode of chunk i overlaps the forward of chunk i+1
+                fut = self.rec.rec_post_process_class.submit(self.rec.recer.forward_greedy_nhwc4(x_rec[c0:c0 + rec_batch]))
+                if pend is not None:
+                    texts += pend.result()
+                pend = fut
+            if pend is not None:
+                texts += pend.result()
+            it = iter(texts)
+            for k, bx, per in zip(idx, boxes, metas):
+                out[k] = [[b, t, round(p, 2)] for b, m in zip(bx, per) if m is not None for (t, p) in (next(it),)]
+                n_boxes += len(bx)
+            n_lines += len(texts)
+        if stats is not None:
+            stats["boxes"] = stats.get("boxes", 0) + n_boxes
+            stats["lines"] = stats.get("lines", 0) + n_lines
+        return out
+
+    @torch.no_grad()
     def run(self, img_path):
         if self.gpu_preprocess:
             return self.run_gpu(img_path)

@@ -176,3 +176,44 @@ def synth_prob_maps(n, h, w, seed=0, noise=0.0):
             m[near] = np.float32(t + 4e-3)
         out[i] = m.astype(np.float32)
     return out
+
+
+def synth_brightness_detector_state_dict(ref_shapes, use_asf=False, gain=14.0, level=0.45):
+    """A hand-made DBNet / DBNet++ ResNet-18 checkpoint (reference key contract, strict) whose probability map is
+    sigmoid(gain * (brightness - level)) of the input image, at 1/4 resolution upsampled x4: the stem's centre tap averages the
+    de-normalised RGB, the residual blocks of layer1 pass it through (zero conv weights), FPN in2 -> out2 -> head carry channel 0,
+    both transposed convs replicate it and the last one applies gain / level.  Every other weight is zero, every BatchNorm is
+    the identity.  With random weights a detector's maps are speckle; this one turns images whose BRIGHTNESS is a text-like
+    map (synth_scene_images) into text-like probability maps, so run_ocr has real boxes to crop (BASELINE configs[4])."""
+    out = {}
+    bn_prefixes = {k[: -len(".running_var")] for k in ref_shapes if k.endswith(".running_var")}
+    for key, (shape, dtype) in ref_shapes.items():
+        prefix = key.rsplit(".", 1)[0]
+        if key.endswith("num_batches_tracked"):
+            out[key] = np.zeros(shape, dtype=np.int64)
+        elif prefix in bn_prefixes and (key.endswith(".weight") or key.endswith(".running_var")):
+            out[key] = np.ones(shape, np.float32)
+        else:
+            out[key] = np.zeros(shape, np.float32)
+    mean = np.array([0.485, 0.456, 0.406], np.float32)
+    std = np.array([0.229, 0.224, 0.225], np.float32)
+    out["backbone.conv1.weight"][0, :, 3, 3] = std / np.float32(3.0)
+    out["backbone.bn1.bias"][0] = mean.mean()
+    out["neck.in2.0.weight"][0, 0, 0, 0] = 1.0
+    out["neck.out2.0.weight"][0, 0, 1, 1] = 1.0
+    fuse_ch = ref_shapes["head.binarize.0.weight"][0][1] - ref_shapes["neck.out2.0.weight"][0][0]     # p2 is the last slice of the concat
+    out["head.binarize.0.weight"][0, fuse_ch, 1, 1] = 1.0
+    out["head.binarize.3.weight"][0, 0, :, :] = 1.0
+    g = 0.5 if use_asf else 1.0                     # ASF with zero weights scales every feature by sigmoid(0) = 0.5
+    out["head.binarize.6.weight"][0, 0, :, :] = np.float32(gain / g)
+    out["head.binarize.6.bias"][0] = np.float32(-gain * level)
+    return out
+
+
+def synth_scene_images(n, h, w, seed=0):
+    """n synthetic 'document photos' u8[n,h,w,3] (BGR): brightness = 255 x a text-like map (synth_prob_maps: ~150 bright rotated
+    bars on black), plus +-4 levels of per-pixel noise.  With synth_brightness_detector_state_dict the detector finds the bars."""
+    maps = synth_prob_maps(n, h, w, seed=seed)
+    noise = (uniform01(n * h * w * 3, seed ^ 0xC0FFEE).reshape(n, h, w, 3) - np.float32(0.5)) * np.float32(8.0)
+    img = maps[..., None] * np.float32(255.0) + noise
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)

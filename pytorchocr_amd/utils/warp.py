@@ -5,22 +5,31 @@ cv2's remap tables do); UNPINNED against OpenCV (absent from this image)."""
 import numpy as np
 
 
+def get_perspective_transforms(src, dst):
+    """n 3x3 matrices mapping src[i][k] -> dst[i][k] (k = 0..3), each solved in double like cv2.getPerspectiveTransform
+    (one batched LAPACK call: every 8x8 system is factorised on its own, so a batch gives the single-box result bit for bit)."""
+    src = np.asarray(src, np.float64).reshape(-1, 4, 2)
+    dst = np.asarray(dst, np.float64).reshape(-1, 4, 2)
+    n = src.shape[0]
+    a = np.zeros((n, 8, 8), np.float64)
+    b = np.zeros((n, 8), np.float64)
+    for i in range(4):
+        a[:, i, 0] = a[:, i + 4, 3] = src[:, i, 0]
+        a[:, i, 1] = a[:, i + 4, 4] = src[:, i, 1]
+        a[:, i, 2] = a[:, i + 4, 5] = 1
+        a[:, i, 6] = -src[:, i, 0] * dst[:, i, 0]
+        a[:, i, 7] = -src[:, i, 1] * dst[:, i, 0]
+        a[:, i + 4, 6] = -src[:, i, 0] * dst[:, i, 1]
+        a[:, i + 4, 7] = -src[:, i, 1] * dst[:, i, 1]
+        b[:, i] = dst[:, i, 0]
+        b[:, i + 4] = dst[:, i, 1]
+    x = np.linalg.solve(a, b[:, :, None])[:, :, 0]
+    return np.concatenate([x, np.ones((n, 1))], 1).reshape(n, 3, 3)
+
+
 def get_perspective_transform(src, dst):
     """3x3 matrix mapping src[i] -> dst[i] (4 points), solved in double like cv2.getPerspectiveTransform."""
-    a = np.zeros((8, 8), np.float64)
-    b = np.zeros(8, np.float64)
-    for i in range(4):
-        a[i, 0] = a[i + 4, 3] = src[i][0]
-        a[i, 1] = a[i + 4, 4] = src[i][1]
-        a[i, 2] = a[i + 4, 5] = 1
-        a[i, 6] = -src[i][0] * dst[i][0]
-        a[i, 7] = -src[i][1] * dst[i][0]
-        a[i + 4, 6] = -src[i][0] * dst[i][1]
-        a[i + 4, 7] = -src[i][1] * dst[i][1]
-        b[i] = dst[i][0]
-        b[i + 4] = dst[i][1]
-    x = np.linalg.solve(a, b)
-    return np.append(x, 1.0).reshape(3, 3)
+    return get_perspective_transforms(np.asarray(src)[None], np.asarray(dst)[None])[0]
 
 
 def warp_perspective_replicate(img, M, dsize):
