@@ -175,6 +175,15 @@ int ptocr_dbpost_last_device_ms(ptocr_dbpost_t h, float *ms);
  * short xmin, xmax, ymin, ymax;}  status: 0 box, 1 <=2 points, 2 ssid<3, 3 score<box_thresh, 4 unclip<1.001, 5 ssid<5. */
 int ptocr_dbpost_debug_results(ptocr_dbpost_t h, int img, int32_t *h_total, void *h_results, void *h_cands, void *h_info);
 
+/* Second inspection hook: the border STATES of candidate k of image img of the last call (one word per state: x | y << 11 |
+ * s_out << 26 | s_in << 29, directions 0=E 1=NE .. 7=SE); *h_n = their number (0 when the border has <= 2 contour points). */
+int ptocr_dbpost_debug_states(ptocr_dbpost_t h, int img, int k, uint32_t *h_states, int cap, int32_t *h_n);
+
+/* Third inspection hook: label image int32[H][W] (entries valid at run starts: component root = its raster-first pixel index,
+ * -1 = background connected to the frame, -2 - k = root selected as candidate k) and per-word labels int32[H][ceil(W/32)] (root of
+ * the run covering the word's first pixel) of image img of the last call, which must have been H x W. */
+int ptocr_dbpost_debug_labels(ptocr_dbpost_t h, int img, int H, int W, int32_t *h_labels, int32_t *h_word_labels);
+
 /* ---- pre-process next to the path --------------------------------------------------------------
  * Item descriptors live in device memory (arrays of the structs below, natural C layout). */
 typedef struct { long src_off; int sh, sw; int rh, rw; long dst_off; int dh, dw; } ptocr_pre_item;

@@ -1,6 +1,6 @@
 // DB probability-map post-process on MI355X: threshold -> bit-packed bitmap -> run-based union-find CC labelling
-// (foreground 8-connected, background 4-connected) -> border following of the 1000 bottom-most borders ->
-// per-border min-area box, polygon-mask score, Clipper round-offset unclip, final integer box.
+// (foreground 8-connected, background 4-connected) -> ORDER-FREE enumeration of the border states of the 1000 bottom-most
+// borders -> per-border min-area box, polygon-mask score, Clipper round-offset unclip, final integer box.
 //
 // Replaces (bit-exact boxes on identical maps; see DESIGN.md for the two documented sub-pixel exceptions):
 //   pytocr/postprocess/db_postprocess.py:45-46          pred > thresh (float32 compare)
@@ -14,13 +14,21 @@
 //    each 4-connected background component that is not connected to the image frame.  So the start points are
 //    the union-find roots (root = minimum pixel index), found fully in parallel.  RETR_LIST returns borders in
 //    reverse discovery order and the reference keeps the first 1000 => the 1000 largest root indices.
-//  * Each border is then traced by one thread (the trace only reads the binary image), twice: count, then
-//    write the direction-change points (CHAIN_APPROX_SIMPLE) into an exactly-sized slot of a point pool.
-//  * One workgroup per border does the rest: column-extreme + Akl-Toussaint pre-filter and Sklansky hull,
-//    float32 rotating calipers, fillPoly rasterisation into bit planes (edge lines 4-connected, even-odd fill
-//    via per-row prefix-xor of crossing toggles), masked mean in double, unclip and final box.
-// Memory: everything is integer/bit work bound by HBM/L2 latency, not by MFMA; the bitmap is 1 bit/pixel so the
-// trace works out of L2.
+//  * The border walk itself is NOT replayed.  A walk is a closed chain of states (pixel p, gap): a gap is a maximal
+//    counter-clockwise run of background 8-neighbours of p between two foreground neighbours s_in (where the walk came
+//    from) and s_out (where it goes), and the walk visits exactly the gaps that contain a 4-neighbour.  Every such
+//    (pixel, gap) pair of the image lies on exactly one border: the border between p's foreground component F and the
+//    background component B of the gap -- the outer border of F when B is the component surrounding F (the one left
+//    of F's raster-first pixel), else the hole border of B.  Everything the reference takes from a contour is a
+//    function of the SET of its states: the number of CHAIN_APPROX_SIMPLE points (states with s_out != s_in + 4),
+//    the bounding box, the convex hull (column extremes of the state pixels), and the fillPoly mask (each unit step
+//    contributes its crossing toggle and its 4-connected edge pixels; a polygon edge is a run of equal unit steps).
+//    So one thread per 32-pixel bitmap word lists the states of its pixels, looks up F and B in the CC labels and adds
+//    the state to its border: no sequential walk, no dependence on border length.
+//  * Per border: column extremes + exact strict-hull filter (a workgroup), Sklansky + float32 rotating calipers
+//    (one LANE per border, 64 borders per wave: the arithmetic is the reference's sequential float32 code), fillPoly bit
+//    planes + masked mean in double (a workgroup), unclip + second rectangle + final box (one lane per border).
+// Memory: everything is integer/bit work bound by HBM/L2 latency, not by MFMA; the bitmap is 1 bit/pixel.
 #include "common.h"
 
 namespace ptocr {
@@ -28,15 +36,13 @@ namespace ptocr {
 constexpr int MAX_CAND = 1000;          // reference db_postprocess.cpp:239 (hard-coded max_candidates)
 constexpr int CHUNK = 1024;             // pixels per root-count chunk
 constexpr int FRAME = -1;               // label of background connected to the image frame
-constexpr int QCAP = 512;               // points of a border's quick slot: borders up to QCAP points are traced once
-constexpr long QOFF = (long)MAX_CAND * QCAP;   // start of the exact-size region inside an image's pool
 
 struct DbpostDims {
     int N, H, W, WW;                    // WW = 32-bit words per bitmap row
     long HW;
     int nchunks;                        // chunks per image
-    long pool_cap;                      // points per image in the exact-size region of the point pool
-    long pool_stride;                   // points per image: quick slots (MAX_CAND x QCAP) + exact-size region
+    long pool_cap;                      // border states per image the pool holds
+    int strip_y;                        // first row of the bottom strip labelled first (0: whole image in one pass)
 };
 
 // ------------------------------------------------------------------------------------------ binarize
@@ -123,6 +129,17 @@ __device__ __forceinline__ int uf_find(int *lab, int v) {
             const int gp = lab[p];
             if (gp != p) lab[v] = gp;
         }
+        v = p;
+    }
+    return v;
+}
+
+// read-only root (the flatten pass: every thread stores the FINAL root of its own run starts, and a path-halving write of a
+// concurrent find -- parent read before that store, written after it -- would put a stale ancestor back)
+__device__ __forceinline__ int uf_root(const int *lab, int v) {
+    while (v >= 0) {
+        const int p = __hip_atomic_load(&lab[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p == v) break;
         v = p;
     }
     return v;
@@ -253,9 +270,11 @@ __global__ __launch_bounds__(256) void ccl_merge_kernel(const unsigned *__restri
     }
 }
 
-// label[s] = root for every run start s; counts border starts (roots) per 1024-pixel chunk (chunk_cnt zeroed by the host)
+// label[s] = root for every run start s; word_lab[word] = root of the run that covers bit 0 of the word (so that the root of
+// ANY pixel is two loads away: the run start inside its word, or the word's entry); counts border starts (roots) per
+// 1024-pixel chunk (chunk_cnt zeroed by the host)
 __global__ __launch_bounds__(256) void ccl_flatten_kernel(const unsigned *__restrict__ bits, int *__restrict__ labels,
-                                                          int *__restrict__ chunk_cnt, DbpostDims d, CclPass ps) {
+                                                          int *__restrict__ word_lab, int *__restrict__ chunk_cnt, DbpostDims d, CclPass ps) {
     const int img = blockIdx.y;
     if (ccl_skip(ps, img)) return;
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -263,16 +282,21 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(const unsigned *__rest
     const int y = ps.y_first + idx / d.WW, wi = idx % d.WW;
     const unsigned *row = bits + ((long)img * d.H + y) * d.WW;
     int *lab = labels + (long)img * d.HW;
-    unsigned m = word_ctx(row, wi, d).starts;
+    const unsigned starts = word_ctx(row, wi, d).starts;
+    unsigned m = starts;
     const int base = y * d.W + wi * 32;
+    int r0 = 0;
     while (m) {
         const int i = __ffs(m) - 1;
         m &= m - 1;
         const int s = base + i;
-        const int r = uf_find(lab, s);
+        const int r = uf_root(lab, s);
         lab[s] = r;
+        if (i == 0) r0 = r;
         if (r == s) atomicAdd(&chunk_cnt[(long)img * d.nchunks + s / CHUNK], 1);
     }
+    if (!(starts & 1u)) r0 = uf_root(lab, y * d.W + run_start(row, wi * 32));       // the run reaches in from the left
+    word_lab[((long)img * d.H + y) * d.WW + wi] = r0;
 }
 
 // suffix sums over chunks (one block per image): chunk_cnt[c] := number of starts in chunks > c; total per image
@@ -308,14 +332,21 @@ __global__ __launch_bounds__(1024) void chunk_suffix_kernel(int *__restrict__ ch
 
 // candidate k (0 = bottom-most start) of an image: trigger pixel and kind
 struct Cand { int p; int is_hole; };
+// what the border-state pass accumulates per candidate
+struct Acc { int nstates, npts, xmin, xmax, ymin, ymax, cursor, off; };
 
-__global__ __launch_bounds__(256) void gather_starts_kernel(const unsigned *__restrict__ bits, const int *__restrict__ labels,
-                                                            const int *__restrict__ chunk_after, Cand *__restrict__ cands,
-                                                            DbpostDims d) {
+// Ranks the roots (border starts) of an image from the bottom: candidate k = the start with the k-th largest pixel index.
+// A selected root r is MARKED in the label image, lab[r] = -2 - k, which is how the border-state pass finds a component's
+// candidate (roots that are not selected keep lab[r] == r; FRAME stays -1).
+__global__ __launch_bounds__(256) void select_starts_kernel(const unsigned *__restrict__ bits, int *__restrict__ labels,
+                                                            const int *__restrict__ chunk_after, const int *__restrict__ totals,
+                                                            Cand *__restrict__ cands, Acc *__restrict__ acc, DbpostDims d) {
     const int img = blockIdx.y, chunk = blockIdx.x;
     const int after = chunk_after[(long)img * d.nchunks + chunk];
     if (after >= MAX_CAND) return;                              // every start here ranks beyond the first 1000
-    const int *lab = labels + (long)img * d.HW;
+    const int upto = chunk ? chunk_after[(long)img * d.nchunks + chunk - 1] : totals[img];
+    if (upto == after) return;                                  // no start in this chunk (most chunks of a clean map)
+    int *lab = labels + (long)img * d.HW;
     __shared__ int wave_cnt[4];
     __shared__ int base;                                        // starts already ranked in this chunk (from the top index down)
     if (threadIdx.x == 0) base = 0;
@@ -342,6 +373,9 @@ __global__ __launch_bounds__(256) void gather_starts_kernel(const unsigned *__re
                 const unsigned *row = bits + ((long)img * d.H + y) * d.WW;
                 Cand c; c.p = (int)p; c.is_hole = !pix(row, x);
                 cands[(long)img * MAX_CAND + rank] = c;
+                Acc a; a.nstates = 0; a.npts = 0; a.xmin = 0x7fffffff; a.xmax = -1; a.ymin = 0x7fffffff; a.ymax = -1; a.cursor = 0; a.off = -1;
+                acc[(long)img * MAX_CAND + rank] = a;
+                lab[p] = -2 - rank;
             }
         }
         __syncthreads();
@@ -350,158 +384,210 @@ __global__ __launch_bounds__(256) void gather_starts_kernel(const unsigned *__re
     }
 }
 
-// ------------------------------------------------------------------------------------------ border following
-// direction k (0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE) -> step, from 2-bit fields (value + 1) so that no table load sits in the walk
+// ------------------------------------------------------------------------------------------ border states
+// direction k (0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE) -> step, from 2-bit fields (value + 1) so that no table load is needed
 __device__ __forceinline__ int dir_dx(int k) { return (int)((0x901Au >> (2 * k)) & 3u) - 1; }    // {1,1,0,-1,-1,-1,0,1}
 __device__ __forceinline__ int dir_dy(int k) { return (int)((0xA901u >> (2 * k)) & 3u) - 1; }    // {0,-1,-1,-1,0,1,1,1}
 
-struct TraceOut { int npts, xmin, xmax, ymin, ymax; };
+// a label entry read at run start rs -> component root (FRAME = -1); a marked root (-2 - k) names itself
+__device__ __forceinline__ int canon_root(int v, int rs) { return v >= 0 ? v : (v == FRAME ? FRAME : rs); }
 
-// One WAVE per border.  The walk itself is sequential, so all 64 lanes execute it redundantly on wave-uniform state while
-// the bitmap around the current pixel sits in registers: an 8-row x 8-word (256-pixel) window, lane l = word (l & 7) of
-// row (l >> 3), fetched with one coalesced load and re-centred when the walk leaves it.  A step then costs a few readlanes
-// instead of six dependent global loads per lane, and the kernel holds no LDS (it has to co-reside with the convolution
-// workgroups of the next batch, which take almost a whole CU's LDS).  What remains is the dependent instruction chain of
-// the walk itself (~1200 cycles per step for a lone wave), i.e. latency, not bandwidth.
-struct BitWindow {
-    const unsigned *bits; int H, W, WW;
-    int y0, wx0;                 // window origin: row, word column (may lie outside the image: those words read 0)
-    unsigned word;               // this lane's word
-    __device__ __forceinline__ void load(int x, int y, int lane) {
-        y0 = y - 3;
-        wx0 = (x >> 5) - 4 + ((x & 31) >= 16);
-        const int r = y0 + (lane >> 3), wi = wx0 + (lane & 7);
-        word = ((unsigned)r < (unsigned)H && (unsigned)wi < (unsigned)WW) ? bits[(long)r * WW + wi] : 0u;
+__device__ __forceinline__ int root_of_pixel(const unsigned *bimg, const int *lab, const int *wl, const DbpostDims &d, int x, int y) {
+    const int wi = x >> 5, b = x & 31;
+    const unsigned w = bimg[(long)y * d.WW + wi];
+    const unsigned m = (((w >> b) & 1u) ? ~w : w) & ((1u << b) - 1u);      // pixels of the other class left of x in this word
+    if (m) {
+        const int rs = y * d.W + wi * 32 + (32 - __clz(m));
+        return canon_root(lab[rs], rs);
     }
-    __device__ __forceinline__ bool inside(int x, int y) const {
-        return y >= y0 + 1 && y <= y0 + 6 && x >= wx0 * 32 + 1 && x <= wx0 * 32 + 254;
-    }
-    // 3 pixels (x-1, x, x+1) of window row rr as bits 0..2
-    __device__ __forceinline__ unsigned row3(int rr, int x) const {
-        const int xs = x - 1 - wx0 * 32;                        // 0 .. 253
-        const int l = __builtin_amdgcn_readfirstlane(rr * 8 + (xs >> 5));
-        const unsigned lo = __builtin_amdgcn_readlane(word, l);
-        const unsigned hi = __builtin_amdgcn_readlane(word, (l + 1) & 63);   // next row's word only when xs & 31 <= 29: unused bits
-        const unsigned long long c = lo | ((unsigned long long)hi << 32);
-        return (unsigned)(c >> (xs & 31)) & 7u;
-    }
-    // 8-neighbour mask, bit k = neighbour in direction k (0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE); pixels outside the image = 0
-    __device__ __forceinline__ unsigned nbr8(int x, int y, int lane) {
-        if (!inside(x, y)) load(x, y, lane);
-        const int rr = y - y0;
-        const unsigned a = row3(rr - 1, x), b = row3(rr, x), c = row3(rr + 1, x);
-        return ((b >> 2) & 1) | (((a >> 2) & 1) << 1) | (((a >> 1) & 1) << 2) | ((a & 1) << 3) |
-               ((b & 1) << 4) | ((c & 1) << 5) | (((c >> 1) & 1) << 6) | (((c >> 2) & 1) << 7);
-    }
-};
+    return wl[(long)y * d.WW + wi];
+}
 
-// Suzuki-Abe border following from (sx, sy) with the direction-change points of CHAIN_APPROX_SIMPLE, executed by a whole
-// wave on uniform state.  WRITE: points are stored as (x | y << 16), 64 at a time (lane i keeps point i of the batch).
+__device__ __forceinline__ int cand_of_root(const int *lab, int r) {
+    if (r < 0) return -1;
+    const int v = lab[r];
+    return v <= -2 ? -2 - v : -1;
+}
+
+// state word: x (11 bits) | y (15 bits) << 11 | s_out << 26 | s_in << 29
+__device__ __forceinline__ int st_x(unsigned s) { return (int)(s & 0x7ffu); }
+__device__ __forceinline__ int st_y(unsigned s) { return (int)((s >> 11) & 0x7fffu); }
+__device__ __forceinline__ int st_out(unsigned s) { return (int)((s >> 26) & 7u); }
+__device__ __forceinline__ int st_in(unsigned s) { return (int)(s >> 29); }
+
+// One thread per bitmap word lists the border states of its foreground pixels (see the file header) and books each one to
+// its border's candidate.  WRITE = false: counts (states, CHAIN_APPROX_SIMPLE points, bounding box) into acc[];
+// WRITE = true: stores the states into the border's slot of the pool (acc[].off, sized by the count pass).
 template <bool WRITE>
-__device__ TraceOut trace_border(BitWindow &im, int sx, int sy, int is_hole, unsigned *out, int cap, int lane) {
-    TraceOut t; t.npts = 0; t.xmin = t.xmax = sx; t.ymin = t.ymax = sy;
-    im.load(sx, sy, lane);
-    unsigned nb = im.nbr8(sx, sy, lane);
-    // first neighbour clockwise from W (outer) or from E (hole)
-    int s = is_hole ? 0 : 4, s_end = s;
-    do { s = (s - 1) & 7; } while (!((nb >> s) & 1) && s != s_end);
-    if (s == s_end) {                            // single pixel domain
-        if (WRITE && lane == 0) out[0] = (unsigned)sx | ((unsigned)sy << 16);
-        t.npts = 1;
-        return t;
-    }
-    const int i1x = sx + dir_dx(s), i1y = sy + dir_dy(s);
-    int prev_s = s ^ 4;
-    int x = sx, y = sy;
-    unsigned mine = 0;                           // the batch point held by this lane
-    // every wave must terminate: a border has fewer steps than 4 per pixel; a longer walk means a broken start
-    for (long guard = 4L * im.H * im.W + 16; guard > 0; guard--) {
-        // counter-clockwise search for the next border pixel starting after direction s
-        const unsigned rot = ((nb | (nb << 8)) >> (s + 1)) & 0xffu;     // bit j = direction s+1+j
-        if (rot == 0) break;                                              // isolated pixel: cannot happen after a valid start
-        const int j = __ffs(rot) - 1;
-        s = __builtin_amdgcn_readfirstlane((s + 1 + j) & 7);   // wave-uniform: keep the walk on the scalar unit
-        if (s != prev_s) {
-            if (WRITE && t.npts < cap) {                        // cap is a multiple of 64: whole batches only
-                if (lane == (t.npts & 63)) mine = (unsigned)x | ((unsigned)y << 16);
-                if ((t.npts & 63) == 63) out[(t.npts & ~63) + lane] = mine;
+__global__ __launch_bounds__(256) void border_states_kernel(const unsigned *__restrict__ bits, const int *__restrict__ labels,
+                                                            const int *__restrict__ word_lab, const int *__restrict__ strip_totals,
+                                                            Acc *__restrict__ acc, unsigned *__restrict__ pool,
+                                                            const int *__restrict__ flags, DbpostDims d) {
+    const int img = blockIdx.y;
+    const int y_first = (d.strip_y && strip_totals[img] >= MAX_CAND) ? d.strip_y : 0;     // rows above carry no labels (and no candidate)
+    const int idx0 = blockIdx.x * 256 + threadIdx.x;
+    const bool in_range = idx0 < (d.H - y_first) * d.WW && !(WRITE && (flags[img] & 4));
+    const int idx = in_range ? idx0 : 0;                        // out-of-range lanes idle along (the wave reduction below wants all lanes)
+    const int y = y_first + idx / d.WW, wi = idx % d.WW;
+    const unsigned *bimg = bits + (long)img * d.H * d.WW;
+    const unsigned w = in_range ? bimg[(long)y * d.WW + wi] : 0u;
+    auto ld = [&](int yy, int ww) -> unsigned {
+        return ((unsigned)yy < (unsigned)d.H && (unsigned)ww < (unsigned)d.WW) ? bimg[(long)yy * d.WW + ww] : 0u;
+    };
+    const unsigned cl = ld(y, wi - 1), cr = ld(y, wi + 1);
+    const unsigned up = ld(y - 1, wi), ul = ld(y - 1, wi - 1), ur = ld(y - 1, wi + 1);
+    const unsigned dn = ld(y + 1, wi), dl = ld(y + 1, wi - 1), dr = ld(y + 1, wi + 1);
+    // neighbour planes: bit i = the neighbour of pixel (32 wi + i) in that direction (outside the image = background)
+    const unsigned pE = (w >> 1) | (cr << 31), pW = (w << 1) | (cl >> 31);
+    const unsigned pNE = (up >> 1) | (ur << 31), pNW = (up << 1) | (ul >> 31);
+    const unsigned pSE = (dn >> 1) | (dr << 31), pSW = (dn << 1) | (dl >> 31);
+    unsigned border = w & ~(up & dn & pE & pW);                 // border points: a background pixel among the 4-neighbours
+    const int *lab = labels + (long)img * d.HW;
+    const int *wl = word_lab + (long)img * d.H * d.WW;
+    Acc *ac = acc + (long)img * MAX_CAND;
+    unsigned *pl = pool + (long)img * d.pool_cap;
+    int f_key = -2, F = FRAME, S = -3;                          // cached: run of the current pixel -> its component, its surround
+    int n_key = -2, BN = FRAME, s_key = -2, BS = FRAME;         // cached: background run above / below the current pixel -> its component
+    int ak = -1, an = 0, ap = 0, ax0 = 0, ax1 = 0;              // count mode: pending totals of candidate ak
+    unsigned buf[8]; int bn = 0, bk = -1;                       // write mode: pending states of candidate bk (one slot reservation per 8)
+    auto wflush = [&]() {
+        if (bn) {
+            const int off = ac[bk].off;
+            if (off >= 0) {
+                const int pos = off + atomicAdd(&ac[bk].cursor, bn);
+#pragma unroll
+                for (int j = 0; j < 8; j++) if (j < bn) pl[pos + j] = buf[j];
             }
-            t.npts++;
-            prev_s = s;
-            t.xmin = min(t.xmin, x); t.xmax = max(t.xmax, x); t.ymin = min(t.ymin, y); t.ymax = max(t.ymax, y);
+            bn = 0;
         }
-        const int nx = x + dir_dx(s), ny = y + dir_dy(s);
-        if (nx == sx && ny == sy && x == i1x && y == i1y) break;
-        x = __builtin_amdgcn_readfirstlane(nx); y = __builtin_amdgcn_readfirstlane(ny);
-        s = (s + 4) & 7;
-        nb = im.nbr8(x, y, lane);
+    };
+    auto flush = [&]() {
+        if (ak >= 0) {
+            atomicAdd(&ac[ak].nstates, an); atomicAdd(&ac[ak].npts, ap);
+            atomicMin(&ac[ak].xmin, ax0); atomicMax(&ac[ak].xmax, ax1);
+            atomicMin(&ac[ak].ymin, y); atomicMax(&ac[ak].ymax, y);
+        }
+    };
+    while (border) {
+        const int i = __ffs(border) - 1;
+        border &= border - 1;
+        const int x = wi * 32 + i;
+        const unsigned nb = ((pE >> i) & 1u) | (((pNE >> i) & 1u) << 1) | (((up >> i) & 1u) << 2) | (((pNW >> i) & 1u) << 3) |
+                            (((pW >> i) & 1u) << 4) | (((pSW >> i) & 1u) << 5) | (((dn >> i) & 1u) << 6) | (((pSE >> i) & 1u) << 7);
+        // component of this pixel (cached per run) and the background component that surrounds it
+        {
+            const unsigned m = ~w & ((1u << i) - 1u);
+            const int key = m ? 32 - __clz(m) : -1;
+            if (key != f_key) {
+                f_key = key;
+                if (m) { const int rs = y * d.W + wi * 32 + key; F = canon_root(lab[rs], rs); }
+                else F = wl[(long)y * d.WW + wi];
+                if (F < 0) S = -3;                              // (strip mode) component reaches above the strip: never a candidate
+                else {
+                    const int fy = F / d.W, fx = F - fy * d.W;
+                    S = fx == 0 ? FRAME : root_of_pixel(bimg, lab, wl, d, fx - 1, fy);
+                }
+            }
+        }
+        // gaps: for every foreground neighbour s_in whose counter-clockwise successor direction is background
+        unsigned starts = nb & ~((nb >> 1) | (nb << 7)) & 0xffu;   // bit s set: neighbour s foreground, neighbour s+1 background
+        const bool lone = nb == 0;
+        if (lone) starts = 1u;                                  // isolated pixel: one state (a one-point contour)
+        while (starts) {
+            const int s_in = __ffs(starts) - 1;
+            starts &= starts - 1;
+            int s_out, g4;
+            bool has4;
+            if (lone) { s_out = 0; g4 = 4; has4 = true; }
+            else {
+                const unsigned rot = ((nb | (nb << 8)) >> (s_in + 1)) & 0xffu;    // bit j = direction s_in + 1 + j
+                const int L = __ffs(rot) - 1;                    // background neighbours in the gap
+                s_out = (s_in + 1 + L) & 7;
+                g4 = ((s_in + 1) & 1) ? ((s_in + 2) & 7) : ((s_in + 1) & 7);      // first 4-direction at or after s_in + 1
+                has4 = L >= 2 || (L == 1 && ((s_in + 1) & 1) == 0);
+            }
+            if (!has4) continue;                                // a lone diagonal background pixel: the walk passes by
+            const int zx = x + dir_dx(g4), zy = y + dir_dy(g4);
+            int B;
+            if (!((unsigned)zx < (unsigned)d.W && (unsigned)zy < (unsigned)d.H && zy >= y_first)) B = FRAME;
+            else if (g4 == 2 || g4 == 6) {
+                // the background run above / below: found in the row word this thread already holds, cached per run (the states
+                // along the top or the bottom edge of a text line share it)
+                const unsigned rw = g4 == 2 ? up : dn;
+                const unsigned m = rw & ((1u << i) - 1u);
+                const int key = m ? 32 - __clz(m) : -1;
+                int &ck = g4 == 2 ? n_key : s_key;
+                int &cb = g4 == 2 ? BN : BS;
+                if (key != ck) {
+                    ck = key;
+                    if (m) { const int rs = zy * d.W + wi * 32 + key; cb = canon_root(lab[rs], rs); }
+                    else cb = wl[(long)zy * d.WW + wi];
+                }
+                B = cb;
+            } else B = root_of_pixel(bimg, lab, wl, d, zx, zy);
+            const int k = (B == S) ? cand_of_root(lab, F) : cand_of_root(lab, B);
+            if (k < 0) continue;
+            const int emit = lone || s_out != (s_in ^ 4);       // the chain turns here: a CHAIN_APPROX_SIMPLE point
+            if (WRITE) {
+                if (k != bk || bn == 8) wflush();
+                bk = k;
+#pragma unroll
+                for (int j = 7; j > 0; j--) buf[j] = buf[j - 1];
+                buf[0] = (unsigned)x | ((unsigned)y << 11) | ((unsigned)s_out << 26) | ((unsigned)s_in << 29);
+                bn++;
+            } else {
+                if (k != ak) { flush(); ak = k; an = 0; ap = 0; ax0 = x; }
+                an++; ap += emit; ax1 = x;
+            }
+        }
     }
-    if (WRITE && t.npts < cap && lane < (t.npts & 63)) out[(t.npts & ~63) + lane] = mine;      // the last partial batch
-    return t;
+    if (WRITE) { wflush(); return; }
+    // count mode: the totals still pending are combined across the wave first -- the 64 words of a wave mostly belong to one or
+    // two borders, and the six atomics of a border are all-to-one (every thread of a border hits the same words)
+    for (;;) {
+        const unsigned long long pend = __ballot(ak >= 0);
+        if (!pend) break;
+        const int k0 = __shfl(ak, __ffsll((long long)pend) - 1);
+        const bool mine = ak == k0;
+        int vn = mine ? an : 0, vp = mine ? ap : 0;
+        int v0 = mine ? ax0 : 0x7fffffff, v1 = mine ? ax1 : -1, y0 = mine ? y : 0x7fffffff, y1 = mine ? y : -1;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            vn += __shfl_xor(vn, o); vp += __shfl_xor(vp, o);
+            v0 = min(v0, __shfl_xor(v0, o)); v1 = max(v1, __shfl_xor(v1, o));
+            y0 = min(y0, __shfl_xor(y0, o)); y1 = max(y1, __shfl_xor(y1, o));
+        }
+        if (mine) {
+            if ((__ballot(true) & ((1ull << (threadIdx.x & 63)) - 1)) == 0) {      // first lane of the group books the sums
+                atomicAdd(&ac[k0].nstates, vn); atomicAdd(&ac[k0].npts, vp);
+                atomicMin(&ac[k0].xmin, v0); atomicMax(&ac[k0].xmax, v1);
+                atomicMin(&ac[k0].ymin, y0); atomicMax(&ac[k0].ymax, y1);
+            }
+            ak = -1;
+        }
+    }
 }
 
-struct CandInfo {          // per candidate, filled by the count pass
-    int npts, off;         // number of approx points, offset into the image's point pool
-    short xmin, xmax, ymin, ymax;
-};
-
-// first pass: counts the points of every border and stores them in the border's quick slot as long as they fit (<= QCAP:
-// every text-like border); only longer borders are traced a second time into an exact-size slot
-__global__ __launch_bounds__(64) void trace_count_kernel(const unsigned *__restrict__ bits, const Cand *__restrict__ cands,
-                                                         const int *__restrict__ totals, CandInfo *__restrict__ info,
-                                                         unsigned *__restrict__ pool, DbpostDims d) {
-    const int img = blockIdx.y, k = blockIdx.x;
-    const int lane = threadIdx.x;
-    const int num = min(totals[img], MAX_CAND);
-    if (k >= num) return;
-    const Cand c = cands[(long)img * MAX_CAND + k];
-    BitWindow im; im.bits = bits + (long)img * d.H * d.WW; im.H = d.H; im.W = d.W; im.WW = d.WW;
-    const int p = __builtin_amdgcn_readfirstlane(c.p), hole = __builtin_amdgcn_readfirstlane(c.is_hole);
-    const int y = p / d.W, x = p - y * d.W;
-    const TraceOut t = trace_border<true>(im, x - hole, y, hole, pool + (long)img * d.pool_stride + (long)k * QCAP, QCAP, lane);
-    if (lane == 0) {
-        CandInfo ci; ci.npts = t.npts; ci.off = k * QCAP;
-        ci.xmin = (short)t.xmin; ci.xmax = (short)t.xmax; ci.ymin = (short)t.ymin; ci.ymax = (short)t.ymax;
-        info[(long)img * MAX_CAND + k] = ci;
-    }
-}
-
-// exclusive scan of npts over the candidates of one image (borders with <= 2 points are dropped by the
+// exclusive scan of the state counts over the candidates of one image (borders with <= 2 points are dropped by the
 // reference, db_postprocess.cpp:255, and get no pool space)
-__global__ __launch_bounds__(1024) void pool_offsets_kernel(CandInfo *__restrict__ info, const int *__restrict__ totals,
+__global__ __launch_bounds__(1024) void pool_offsets_kernel(Acc *__restrict__ acc, const int *__restrict__ totals,
                                                             int *__restrict__ flags, DbpostDims d) {
     const int img = blockIdx.x, k = threadIdx.x;
-    __shared__ int sh[1024];
+    __shared__ long sh[1024];
     const int num = min(totals[img], MAX_CAND);
     int n = 0;
-    if (k < num) { n = info[(long)img * MAX_CAND + k].npts; if (n <= QCAP) n = 0; }   // short borders sit in their quick slots
+    if (k < num) { const Acc a = acc[(long)img * MAX_CAND + k]; n = a.npts > 2 ? a.nstates : 0; }
     sh[k] = n;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
-        const int v = k >= off ? sh[k - off] : 0;
+        const long v = k >= off ? sh[k - off] : 0;
         __syncthreads();
         sh[k] += v;
         __syncthreads();
     }
-    if (k < num && n) info[(long)img * MAX_CAND + k].off = (int)QOFF + sh[k] - n;
-    if (k == 1023 && (long)sh[1023] > d.pool_cap) atomicOr(&flags[img], 4);
-}
-
-__global__ __launch_bounds__(64) void trace_write_kernel(const unsigned *__restrict__ bits, const Cand *__restrict__ cands,
-                                                         const int *__restrict__ totals, const CandInfo *__restrict__ info,
-                                                         unsigned *__restrict__ pool, const int *__restrict__ flags, DbpostDims d) {
-    const int img = blockIdx.y, k = blockIdx.x;
-    const int lane = threadIdx.x;
-    const int num = min(totals[img], MAX_CAND);
-    if (k >= num || (flags[img] & 4)) return;
-    const CandInfo ci = info[(long)img * MAX_CAND + k];
-    if (ci.npts <= QCAP) return;
-    const Cand c = cands[(long)img * MAX_CAND + k];
-    BitWindow im; im.bits = bits + (long)img * d.H * d.WW; im.H = d.H; im.W = d.W; im.WW = d.WW;
-    const int p = __builtin_amdgcn_readfirstlane(c.p), hole = __builtin_amdgcn_readfirstlane(c.is_hole);
-    const int off = __builtin_amdgcn_readfirstlane(ci.off);
-    const int y = p / d.W, x = p - y * d.W;
-    trace_border<true>(im, x - hole, y, hole, pool + (long)img * d.pool_stride + off, 0x7fffffc0, lane);
+    const bool fits = sh[1023] <= d.pool_cap;
+    if (k < num && n && fits) acc[(long)img * MAX_CAND + k].off = (int)(sh[k] - n);
+    if (k == 1023 && !fits) atomicOr(&flags[img], 4);
 }
 
 // ------------------------------------------------------------------------------------------ geometry (one lane)
@@ -577,13 +663,14 @@ __device__ int convex_hull_sorted(const F2 *a, int n, F2 *hull, int *stack) {
     return nout;
 }
 
-// float32 rotating calipers (restates OpenCV rotcalipers.cpp, CALIPERS_MINAREARECT); scratch: 3*n floats
+// float32 rotating calipers (restates OpenCV rotcalipers.cpp, CALIPERS_MINAREARECT); scratch: 3*n floats + 4 ints (the four
+// caliper positions are indexed dynamically: kept beside the tables, not in a private array that would live in scratch memory)
 __device__ void rotating_calipers(const F2 *points, int n, float *scratch, float *out) {
     float minarea = 3.402823466e+38f;
     float *inv_len = scratch;
     F2 *vect = reinterpret_cast<F2 *>(scratch + n);
     int left = 0, bottom = 0, right = 0, top = 0;
-    int seq[4];
+    int *seq = reinterpret_cast<int *>(scratch + 3 * n);
     float orientation = 0, base_a, base_b = 0;
     F2 pt0 = points[0];
     float left_x = pt0.x, right_x = pt0.x, top_y = pt0.y, bottom_y = pt0.y;
@@ -727,9 +814,11 @@ __device__ void get_mini_boxes(const RRect &box, float out[4][2], float *ssid) {
 struct CPt { long long X, Y; };
 __device__ __forceinline__ long long cl_round(double v) { return v < 0 ? (long long)(v - 0.5) : (long long)(v + 0.5); }
 
-__device__ int clipper_offset_round(const CPt *path4, double delta, F2 *out, int cap) {
+// ws: 16 eight-byte words of workspace (LDS): the de-duplicated path and the edge normals are indexed dynamically
+__device__ int clipper_offset_round(const CPt *path4, double delta, F2 *out, int cap, long long *ws) {
     const double pi = 3.141592653589793238, two_pi = pi * 2, def_arc = 0.25, arc_tol = 0.25;
-    CPt src[4]; double nx[4], ny[4];
+    CPt *src = reinterpret_cast<CPt *>(ws);
+    double *nx = reinterpret_cast<double *>(ws + 8), *ny = nx + 4;
     int highI = 3, j = 0, nout = 0;
     while (highI > 0 && path4[0].X == path4[highI].X && path4[0].Y == path4[highI].Y) highI--;
     src[0] = path4[0];
@@ -800,32 +889,37 @@ __device__ int clipper_offset_round(const CPt *path4, double delta, F2 *out, int
 
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return x > hi ? hi : (x < lo ? lo : x); }
 
-// ------------------------------------------------------------------------------------------ per-border workgroup
+
+// ------------------------------------------------------------------------------------------ per-border stages
+// Public statuses 0..5 (ptocr_hip.h); internal ones mark where a border stands in the stage pipeline.
 enum { ST_OK = 0, ST_SKIP_NPTS = 1, ST_SKIP_SSID = 2, ST_SKIP_SCORE = 3, ST_SKIP_UNCLIP = 4, ST_SKIP_SSID2 = 5, ST_NONE = 6,
-       ST_DEFER = 7 };   // ST_DEFER: left by the small-footprint pass for the full-size one (never visible after a call)
+       ST_DEFER = 7,          // left by a small-footprint stage for the full-size pass (never visible after a call)
+       ST_PEND_RECT = 8, ST_PEND_SCORE = 9, ST_PEND_UNCLIP = 10 };
 
 struct Result { int status; int box[8]; float score; float rect[5]; int npix; float distance; };
 
 constexpr int CT_THREADS = 256;
 constexpr int MAXW = 2048;                // widest map the column tables hold
-constexpr int LDS_PLANE_WORDS = 4096;     // mask planes up to 131072 pixels live in LDS; larger ones in a global slot
-constexpr int MAXHULL = 512;              // strict hull vertices of a lattice polygon inside 2048 x 32767 stay far below
+constexpr int LDS_PLANE_WORDS = 4096;     // full-size pass: mask planes up to 131072 pixels live in LDS; larger ones in a global slot
+constexpr int MAXHULL = 512;              // full-size pass: strict hull vertices of a lattice polygon inside 2048 x 32767 stay far below
 constexpr int NSLOTS = 256;               // global mask slots (two full-image bit planes each)
+constexpr int S_MW = 512, S_PLANE = 1984, S_MH = 96;      // small-footprint stages: border width, mask plane words, hull / offset points
 
 __device__ __forceinline__ long long cross3(int ax, int ay, int bx, int by, int px, int py) {
     return (long long)(bx - ax) * (py - ay) - (long long)(by - ay) * (px - ax);
 }
 
+// block sum in a FIXED tree order (lanes by shuffle, then the four waves in order): sh = CT_THREADS / 64 entries
 template <typename T>
 __device__ T block_reduce_sum(T v, T *sh) {
     const int tid = threadIdx.x;
-    sh[tid] = v;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    if ((tid & 63) == 0) sh[tid >> 6] = v;
     __syncthreads();
-    for (int s = CT_THREADS / 2; s > 0; s >>= 1) {
-        if (tid < s) sh[tid] = sh[tid] + sh[tid + s];
-        __syncthreads();
-    }
-    const T r = sh[0];
+    T r = sh[0];
+#pragma unroll
+    for (int w = 1; w < CT_THREADS / 64; w++) r += sh[w];
     __syncthreads();
     return r;
 }
@@ -843,10 +937,14 @@ __device__ __forceinline__ void plane_st(unsigned *p, unsigned v) {
     else *p = v;
 }
 
-// fillPoly(mask, {border polygon}, 1, lineType=1) over the bounding box + cv::mean(pred, mask):
-// returns sum (double, block tree order) and pixel count; leaves the final mask in `border`.
+// fillPoly(mask, {border polygon}, 1, lineType=1) over the bounding box + cv::mean(pred, mask), from the border's STATES: a
+// polygon edge of the CHAIN_APPROX_SIMPLE contour is a run of equal unit steps, and both things fillPoly derives from an edge
+// decompose over its unit steps -- the even-odd crossing of a non-horizontal edge on rows ya <= y < yb (FillEdgeCollection's
+// half-open rule) is one toggle at the upper end of every unit step, and the 4-connected edge line (cv::Line, connectivity 1
+// -> 4, walked from the left end: x step first, then y step) is the step's two end pixels plus, for a diagonal step, the
+// pixel beside its left end.  Returns sum (double, block tree order) and pixel count; leaves the final mask in `border`.
 template <bool GLOBAL>
-__device__ void score_mask(const unsigned *pts, int n, int xmin, int ymin, int bw, int bh, unsigned *border, unsigned *toggle,
+__device__ void score_mask(const unsigned *st, int n, int xmin, int ymin, int bw, int bh, unsigned *border, unsigned *toggle,
                            const float *pimg, int W, double *red_d, int *red_i, double *sum_out, int *cnt_out) {
     const int tid = threadIdx.x;
     const int pw = (bw + 31) >> 5;
@@ -854,37 +952,17 @@ __device__ void score_mask(const unsigned *pts, int n, int xmin, int ymin, int b
     for (long i = tid; i < plane_words; i += CT_THREADS) { plane_st<GLOBAL>(&border[i], 0); plane_st<GLOBAL>(&toggle[i], 0); }
     __syncthreads();
     for (int i = tid; i < n; i += CT_THREADS) {
-        const unsigned p0 = pts[i == 0 ? n - 1 : i - 1], p1 = pts[i];
-        int x0 = (int)(p0 & 0xffff) - xmin, y0 = (int)(p0 >> 16) - ymin;
-        int x1 = (int)(p1 & 0xffff) - xmin, y1 = (int)(p1 >> 16) - ymin;
-        // even-odd crossings of the non-horizontal edge on rows ya <= y < yb (FillEdgeCollection's half-open rule)
-        if (y0 != y1) {
-            int ya, yb, xa, xb;
-            if (y0 < y1) { ya = y0; yb = y1; xa = x0; xb = x1; } else { ya = y1; yb = y0; xa = x1; xb = x0; }
-            const int dxs = (xb - xa) / (yb - ya);              // -1, 0, +1: border edges run in the 8 chain directions
-            for (int y = ya, x = xa; y < yb; y++, x += dxs) atomicXor(&toggle[(long)y * pw + (x >> 5)], 1u << (x & 31));
-        }
-        // the edge itself, 4-connected (cv::Line: connectivity 1 -> 4), walked from its left end point
-        if (x1 < x0) { int t = x0; x0 = x1; x1 = t; t = y0; y0 = y1; y1 = t; }
-        const int dx = x1 - x0, dy = y1 - y0;
-        if (dy == 0) {
-            for (int w = x0 >> 5; w <= (x1 >> 5); w++) {
-                const int lo = max(x0, w * 32) & 31, hi = min(x1, w * 32 + 31) & 31;
-                const unsigned m = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1)) & ~((1u << lo) - 1);
-                atomicOr(&border[(long)y0 * pw + w], m);
-            }
-        } else if (dx == 0) {
-            const int ya = min(y0, y1), yb = max(y0, y1);
-            for (int y = ya; y <= yb; y++) atomicOr(&border[(long)y * pw + (x0 >> 5)], 1u << (x0 & 31));
-        } else {
-            const int sy = dy > 0 ? 1 : -1;
-            int x = x0, y = y0;
-            atomicOr(&border[(long)y * pw + (x >> 5)], 1u << (x & 31));
-            for (int s = 0; s < dx; s++) {                      // x step first, then y step
-                x++;
-                atomicOr(&border[(long)y * pw + (x >> 5)], 1u << (x & 31));
-                y += sy;
-                atomicOr(&border[(long)y * pw + (x >> 5)], 1u << (x & 31));
+        const unsigned s = st[i];
+        const int so = st_out(s);
+        const int x0 = st_x(s) - xmin, y0 = st_y(s) - ymin;
+        const int dx = dir_dx(so), dy = dir_dy(so);
+        atomicOr(&border[(long)y0 * pw + (x0 >> 5)], 1u << (x0 & 31));                     // this end (the other end is the next state's)
+        if (dy != 0) {
+            const int xu = dy > 0 ? x0 : x0 + dx, yu = dy > 0 ? y0 : y0 - 1;               // upper end of the step
+            atomicXor(&toggle[(long)yu * pw + (xu >> 5)], 1u << (xu & 31));
+            if (dx != 0) {                                                               // diagonal: the pixel right of the left end
+                const int xc = dx > 0 ? x0 + 1 : x0, yc = dx > 0 ? y0 : y0 + dy;
+                atomicOr(&border[(long)yc * pw + (xc >> 5)], 1u << (xc & 31));
             }
         }
     }
@@ -930,60 +1008,30 @@ __device__ double score_mask_raster_order(const unsigned *border, int xmin, int 
     return s;
 }
 
-// Two instantiations share this body (contour_kernel / contour_big_kernel below).  SMALL: column tables for borders up to
-// 512 px wide, mask planes up to 30720 px and 80 hull candidates -- 17.5 KB of LDS and <= 80 VGPRs, so a dozen workgroups fit a CU and one fits NEXT TO a Winograd workgroup of
-// the following batch's forward pass (which leaves 18 KB of LDS and 92 VGPRs per SIMD); a border that exceeds any of the
-// limits is marked ST_DEFER.  The full-size instantiation (2048 px, 131072 px, 512 candidates; 53 KB) then handles only those.
-template <int MW, int PLANE, int MH, bool SMALL>
-__device__ void contour_body(int img, int k, const float *__restrict__ maps, const Cand *__restrict__ cands,
-                             const CandInfo *__restrict__ info, const unsigned *__restrict__ pool, unsigned *__restrict__ gslots,
-                             int *__restrict__ slot_locks, Result *__restrict__ results, int *__restrict__ flags,
-                             const int *__restrict__ src_wh, float box_thresh, float unclip_ratio, long slot_words,
-                             int use_padding_resize, const DbpostDims &d) {
+// ---- stage A (a workgroup): hull candidates of a border.  Per-column extremes of the contour points, i.e. of the states at
+// which the chain turns (every strict hull vertex is one, and a text blob has few: 8 of 169 columns is typical) -> compaction of the non-empty columns (a text blob's border touches few columns) -> a column extreme
+// survives only if it is a strict vertex of its chain: for the min-y chain, point i survives iff it lies strictly on the
+// outer side of every chord (j, k), j < i < k; it is enough to test the chord through the steepest predecessor and the
+// steepest successor.  Exact integer arithmetic, O(m^2 / 256).  Survivors come out in (x, y) order, the order
+// cv::convexHull sorts to.  arena: 3 * MW ints of LDS.  Returns the number of survivors (may exceed cap: nothing beyond
+// cap is stored).
+template <int MW>
+__device__ int hull_candidates(const unsigned *st, int n, int xmin, int bw, unsigned *arena, F2 *out, int cap, int *wave_cnt, int *sh_n) {
     const int tid = threadIdx.x;
-    Result *res = &results[(long)img * MAX_CAND + k];
-    const CandInfo ci = info[(long)img * MAX_CAND + k];
-    if (flags[img] & 4) { if (tid == 0) res->status = ST_NONE; return; }
-    if (ci.npts <= 2) { if (tid == 0) res->status = ST_SKIP_NPTS; return; }     // db_postprocess.cpp:255
-    const unsigned *pts = pool + (long)img * d.pool_stride + ci.off;
-    const int n = ci.npts;
-    const int xmin = ci.xmin, xmax = ci.xmax, ymin = ci.ymin, ymax = ci.ymax;
-    const int bw = xmax - xmin + 1, bh = ymax - ymin + 1;
-    // Speckle: both sides of a min-area rectangle are projections of the point set, so neither exceeds its diameter, which is
-    // at most the diagonal of the bounding box; a diagonal <= sqrt(8) means ssid < 3 (db_postprocess.cpp:265) without
-    // computing the rectangle.  Noise maps are made of thousands of such borders.
-    if ((bw - 1) * (bw - 1) + (bh - 1) * (bh - 1) <= 8) { if (tid == 0) res->status = ST_SKIP_SSID; return; }
-    if (SMALL && (bw > MW || (long)((bw + 31) >> 5) * bh > PLANE)) { if (tid == 0) { res->status = ST_DEFER; atomicOr(&flags[img], 8); } return; }
-
-    // LDS arena: column tables (hull phase) and mask planes (score phase) are never live together
-    constexpr int ARENA = 2 * PLANE > 3 * MW ? 2 * PLANE : 3 * MW;
-    __shared__ __attribute__((aligned(16))) unsigned arena[ARENA];
-    int *col_lo = reinterpret_cast<int *>(arena);               // [MW] min y of the border points per column
+    int *col_lo = reinterpret_cast<int *>(arena);               // [MW] min y of the border pixels per column
     int *col_hi = col_lo + MW;                                  // [MW] max y
-    __shared__ F2 cand_pts[MH];
-    __shared__ F2 hull_pts[MH];
-    __shared__ int stack[2 * (MH + 2)];
-    __shared__ float cal_scratch[3 * MH];
-    __shared__ double red_d[CT_THREADS];
-    __shared__ int red_i[CT_THREADS];
-    __shared__ int wave_cnt[CT_THREADS / 64];
-    __shared__ int sh_n, sh_status;
-    __shared__ float sh_mini[4][2];
-
-    // ---- 1. per-column extremes of the border points (every strict hull vertex is a column extreme)
+    int *col_x = col_hi + MW;                                   // [MW] x (relative to xmin) of compacted column a
     for (int i = tid; i < bw; i += CT_THREADS) { col_lo[i] = 0x7fffffff; col_hi[i] = -0x7fffffff; }
-    if (tid == 0) sh_n = 0;
+    if (tid == 0) *sh_n = 0;
     __syncthreads();
     for (int i = tid; i < n; i += CT_THREADS) {
-        const unsigned p = pts[i];
-        const int x = (int)(p & 0xffff) - xmin, y = (int)(p >> 16);
+        const unsigned s = st[i];
+        if (st_out(s) == (st_in(s) ^ 4)) continue;             // the chain runs straight through: not a contour point, not a hull vertex
+        const int x = st_x(s) - xmin, y = st_y(s);
         atomicMin(&col_lo[x], y);
         atomicMax(&col_hi[x], y);
     }
     __syncthreads();
-    // ---- 1b. compact the non-empty columns in place (a CHAIN_APPROX_SIMPLE border touches few columns: 8 of 169 is
-    //          typical for a clean text blob), so that the quadratic filter below runs over m columns, not bw
-    int *col_x = col_hi + MW;                                   // [MW] x (relative to xmin) of compacted column a
     const int lane = tid & 63, wave = tid >> 6;
     int m_cols = 0;
     {
@@ -1008,10 +1056,6 @@ __device__ void contour_body(int img, int k, const float *__restrict__ maps, con
             if (v_pos[r] >= 0) { col_lo[v_pos[r]] = v_lo[r]; col_hi[v_pos[r]] = v_hi[r]; col_x[v_pos[r]] = r * CT_THREADS + tid; }
         __syncthreads();
     }
-    // ---- 2. keep a column extreme only if it is a strict vertex of its chain: for the min-y chain, point i survives
-    //         iff it lies strictly on the outer side of every chord (j, k), j < i < k.  It is enough to test the chord
-    //         through the steepest predecessor and the steepest successor.  Exact integer arithmetic, O(m^2 / 256).
-    //         End columns always survive.  Survivors are emitted in (x, y) order: the order cv::convexHull sorts to.
     for (int base = 0; base < m_cols; base += CT_THREADS) {
         const int i = base + tid;
         int keep_lo = 0, keep_hi = 0, ylo = 0, yhi = 0, xi = 0;
@@ -1041,95 +1085,56 @@ __device__ void contour_body(int img, int k, const float *__restrict__ maps, con
         for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
         if (lane == 63) wave_cnt[wave] = incl;
         __syncthreads();
-        int pos = sh_n + incl - mine;
+        int pos = *sh_n + incl - mine;
         for (int w = 0; w < wave; w++) pos += wave_cnt[w];
-        if (keep_lo) { if (pos < MH) { cand_pts[pos].x = (float)(xi + xmin); cand_pts[pos].y = (float)ylo; } pos++; }
-        if (keep_hi) { if (pos < MH) { cand_pts[pos].x = (float)(xi + xmin); cand_pts[pos].y = (float)yhi; } pos++; }
+        if (keep_lo) { if (pos < cap) { out[pos].x = (float)(xi + xmin); out[pos].y = (float)ylo; } pos++; }
+        if (keep_hi) { if (pos < cap) { out[pos].x = (float)(xi + xmin); out[pos].y = (float)yhi; } pos++; }
         __syncthreads();
-        if (tid == CT_THREADS - 1) sh_n = pos;
+        if (tid == CT_THREADS - 1) *sh_n = pos;
         __syncthreads();
     }
-    // ---- 3. min-area rect of the border, mini-box, first size filter (lane 0; a few dozen vertices)
-    if (tid == 0) {
-        int status = ST_OK;
-        if (sh_n > MH) { if (SMALL) { status = ST_DEFER; atomicOr(&flags[img], 8); } else { atomicOr(&flags[img], 4); status = ST_NONE; } }
-        else {
-            const RRect box = min_area_rect_sorted(cand_pts, sh_n, hull_pts, stack, cal_scratch);
-            float ssid;
-            get_mini_boxes(box, sh_mini, &ssid);
-            res->rect[0] = box.cx; res->rect[1] = box.cy; res->rect[2] = box.w; res->rect[3] = box.h; res->rect[4] = box.angle;
-            if (ssid < 3) status = ST_SKIP_SSID;                // min_size, db_postprocess.cpp:265
-        }
-        sh_status = status;
-    }
-    __syncthreads();
-    if (sh_status != ST_OK) { if (tid == 0) res->status = sh_status; return; }
+    return *sh_n;
+}
 
-    // ---- 4. BoxScore (db_postprocess.cpp:194-229)
-    const float *pimg = maps + (long)img * d.HW;
-    const long plane_words = (long)((bw + 31) >> 5) * bh;
-    double total; int npix;
-    float score;
-    if (plane_words <= PLANE) {
-        unsigned *border = arena, *toggle = arena + PLANE;
-        score_mask<false>(pts, n, xmin, ymin, bw, bh, border, toggle, pimg, d.W, red_d, red_i, &total, &npix);
-        score = (float)(npix ? total / npix : 0.0);
-        if (fabs((double)score - (double)box_thresh) <= 1e-6) {
-            if (tid == 0) { red_d[0] = score_mask_raster_order<false>(border, xmin, ymin, bw, bh, pimg, d.W); atomicOr(&flags[img], 2); }
-            __syncthreads();
-            score = (float)(npix ? red_d[0] / npix : 0.0);
-        }
-    } else {
-        const int slot = (int)(((long)img * MAX_CAND + k) % NSLOTS);
-        unsigned *border = gslots + (long)slot * 2 * slot_words, *toggle = border + slot_words;
-        if (tid == 0) { while (atomicCAS(&slot_locks[slot], 0, 1) != 0) __builtin_amdgcn_s_sleep(32); __threadfence(); }
-        __syncthreads();
-        score_mask<true>(pts, n, xmin, ymin, bw, bh, border, toggle, pimg, d.W, red_d, red_i, &total, &npix);
-        score = (float)(npix ? total / npix : 0.0);
-        if (fabs((double)score - (double)box_thresh) <= 1e-6) {
-            if (tid == 0) { red_d[0] = score_mask_raster_order<true>(border, xmin, ymin, bw, bh, pimg, d.W); atomicOr(&flags[img], 2); }
-            __syncthreads();
-            score = (float)(npix ? red_d[0] / npix : 0.0);
-        }
-        __syncthreads();
-        if (tid == 0) { __threadfence(); atomicExch(&slot_locks[slot], 0); }
-    }
-    if (tid != 0) return;
-    res->score = score; res->npix = npix;
-    if (score < box_thresh) { res->status = ST_SKIP_SCORE; return; }           // db_postprocess.cpp:272
+// ---- stage B (one lane): min-area rectangle of the border, mini-box, first size filter (db_postprocess.cpp:259-265)
+__device__ int rect_stage(const F2 *cand, int n, F2 *hull, int *stack, float *scratch, Result *res, float (*mini)[2]) {
+    const RRect box = min_area_rect_sorted(cand, n, hull, stack, scratch);
+    float ssid;
+    get_mini_boxes(box, mini, &ssid);
+    res->rect[0] = box.cx; res->rect[1] = box.cy; res->rect[2] = box.w; res->rect[3] = box.h; res->rect[4] = box.angle;
+    return ssid < 3 ? ST_SKIP_SSID : ST_PEND_SCORE;             // min_size, db_postprocess.cpp:265
+}
 
-    // ---- 5. UnClip (db_postprocess.cpp:16-64) and the final box (:283-311), lane 0
+// ---- stage D, first half (one lane): UnClip's distance and Clipper's round offset of the truncated mini-box
+// (db_postprocess.cpp:16-49).  Returns the number of offset points (<= 0: empty; > cap: does not fit, nothing usable stored).
+__device__ int unclip_offset(const float (*mini)[2], float unclip_ratio, F2 *pts, int cap, Result *res, int *flag_word, long long *ws) {
     float area = 0.0f, dist = 0.0f;
     for (int i = 0; i < 4; i++) {
         const int nn = (i + 1) % 4;
-        area += sh_mini[i][0] * sh_mini[nn][1] - sh_mini[i][1] * sh_mini[nn][0];
-        dist += sqrtf((sh_mini[i][0] - sh_mini[nn][0]) * (sh_mini[i][0] - sh_mini[nn][0]) +
-                      (sh_mini[i][1] - sh_mini[nn][1]) * (sh_mini[i][1] - sh_mini[nn][1]));
+        area += mini[i][0] * mini[nn][1] - mini[i][1] * mini[nn][0];
+        dist += sqrtf((mini[i][0] - mini[nn][0]) * (mini[i][0] - mini[nn][0]) +
+                      (mini[i][1] - mini[nn][1]) * (mini[i][1] - mini[nn][1]));
     }
     area = (float)fabs((double)(float)(area / 2.0));
     const float distance = area * unclip_ratio / dist;
     res->distance = distance;
-    if (distance < 0.75f) atomicOr(&flags[img], 1);            // sub-pixel sliver: Clipper's union clean-up not reproduced
-    CPt path[4];
-    for (int i = 0; i < 4; i++) { path[i].X = (long long)(int)sh_mini[i][0]; path[i].Y = (long long)(int)sh_mini[i][1]; }
-    const int np = clipper_offset_round(path, (double)distance, cand_pts, MH);
+    if (distance < 0.75f) atomicOr(flag_word, 1);              // sub-pixel sliver: Clipper's union clean-up not reproduced
+    CPt *path = reinterpret_cast<CPt *>(ws + 16);
+    for (int i = 0; i < 4; i++) { path[i].X = (long long)(int)mini[i][0]; path[i].Y = (long long)(int)mini[i][1]; }
+    return clipper_offset_round(path, (double)distance, pts, cap, ws);
+}
+
+// ---- stage D, second half (one lane): minAreaRect of the offset polygon (pts sorted by (x, y)), the two filters and the final
+// box (db_postprocess.cpp:57-64, 276-311)
+__device__ int unclip_finish(const F2 *pts, int np, F2 *hull, int *stack, float *scratch, Result *res, int src_w, int src_h,
+                             int use_padding_resize, const DbpostDims &d) {
     RRect ub;
-    if (np > MH) { if (SMALL) { res->status = ST_DEFER; atomicOr(&flags[img], 8); } else { atomicOr(&flags[img], 4); res->status = ST_NONE; } return; }
     if (np <= 0) { ub.cx = 0; ub.cy = 0; ub.w = 1; ub.h = 1; ub.angle = 0; }
-    else {
-        for (int i = 1; i < np; i++) {                          // sort by (x, y) like cv::convexHull
-            const F2 t = cand_pts[i];
-            int j = i;
-            for (; j > 0 && (t.x < cand_pts[j - 1].x || (t.x == cand_pts[j - 1].x && t.y < cand_pts[j - 1].y)); j--) cand_pts[j] = cand_pts[j - 1];
-            cand_pts[j] = t;
-        }
-        ub = min_area_rect_sorted(cand_pts, np, hull_pts, stack, cal_scratch);
-    }
-    if (ub.h < 1.001 && ub.w < 1.001) { res->status = ST_SKIP_UNCLIP; return; }
+    else ub = min_area_rect_sorted(pts, np, hull, stack, scratch);
+    if (ub.h < 1.001 && ub.w < 1.001) return ST_SKIP_UNCLIP;
     float clip[4][2], ssid;
     get_mini_boxes(ub, clip, &ssid);
-    if (ssid < 5) { res->status = ST_SKIP_SSID2; return; }                        // min_size + 2
-    const int src_w = src_wh[2 * img], src_h = src_wh[2 * img + 1];
+    if (ssid < 5) return ST_SKIP_SSID2;                        // min_size + 2
     for (int j = 0; j < 4; j++) {
         if (use_padding_resize) {
             // get_affine_transform(center, max(src_w, src_h), H, inv=1) + transform_preds (db_postprocess.cpp:111-145, 289-301):
@@ -1148,39 +1153,209 @@ __device__ void contour_body(int img, int k, const float *__restrict__ maps, con
             res->box[2 * j + 1] = (int)clampf(roundf(clip[j][1] / (float)d.H * (float)src_h), 0, (float)src_h);
         }
     }
-    res->status = ST_OK;
+    return ST_OK;
 }
 
-// small-footprint pass: one workgroup per border
-__global__ __launch_bounds__(CT_THREADS, 6) void contour_kernel(const float *__restrict__ maps, const Cand *__restrict__ cands,
-                                                                const int *__restrict__ totals, const CandInfo *__restrict__ info,
-                                                                const unsigned *__restrict__ pool, unsigned *__restrict__ gslots,
-                                                                int *__restrict__ slot_locks, Result *__restrict__ results,
-                                                                int *__restrict__ flags, const int *__restrict__ src_wh,
-                                                                float box_thresh, float unclip_ratio, long slot_words, int use_padding_resize,
-                                                                DbpostDims d) {
+// both halves on one lane (full-size pass); ST_DEFER when the offset polygon has more than cap points
+__device__ int unclip_stage(const float (*mini)[2], float unclip_ratio, F2 *pts, int cap, F2 *hull, int *stack, float *scratch,
+                            Result *res, int *flag_word, int src_w, int src_h, int use_padding_resize, const DbpostDims &d, long long *ws) {
+    const int np = unclip_offset(mini, unclip_ratio, pts, cap, res, flag_word, ws);
+    if (np > cap) return ST_DEFER;
+    for (int i = 1; i < np; i++) {                              // sort by (x, y) like cv::convexHull
+        const F2 t = pts[i];
+        int j = i;
+        for (; j > 0 && (t.x < pts[j - 1].x || (t.x == pts[j - 1].x && t.y < pts[j - 1].y)); j--) pts[j] = pts[j - 1];
+        pts[j] = t;
+    }
+    return unclip_finish(pts, np, hull, stack, scratch, res, src_w, src_h, use_padding_resize, d);
+}
+
+struct StageArgs {
+    const float *maps; const Cand *cands; const int *totals; const Acc *acc; const unsigned *pool; unsigned *gslots; int *slot_locks;
+    Result *results; int *flags; const int *src_wh; F2 *hin; int *hn; float *mini;
+    float box_thresh, unclip_ratio; long slot_words; int use_padding_resize;
+};
+
+// ---- stage A kernel: one workgroup per border (6 KB of LDS: fits beside a Winograd workgroup of the next batch's forward)
+__global__ __launch_bounds__(CT_THREADS, 6) void hull_kernel(StageArgs a, DbpostDims d) {
     const int img = blockIdx.y, k = blockIdx.x;
-    if (k >= min(totals[img], MAX_CAND)) return;
-    contour_body<512, 960, 80, true>(img, k, maps, cands, info, pool, gslots, slot_locks, results, flags, src_wh, box_thresh, unclip_ratio,
-                                     slot_words, use_padding_resize, d);
+    if (k >= min(a.totals[img], MAX_CAND)) return;
+    const int tid = threadIdx.x;
+    const long bi = (long)img * MAX_CAND + k;
+    Result *res = &a.results[bi];
+    const Acc ac = a.acc[bi];
+    if (a.flags[img] & 4) { if (tid == 0) res->status = ST_NONE; return; }
+    if (ac.npts <= 2) { if (tid == 0) res->status = ST_SKIP_NPTS; return; }     // db_postprocess.cpp:255
+    const int bw = ac.xmax - ac.xmin + 1, bh = ac.ymax - ac.ymin + 1;
+    // Speckle: both sides of a min-area rectangle are projections of the point set, so neither exceeds its diameter, which is
+    // at most the diagonal of the bounding box; a diagonal <= sqrt(8) means ssid < 3 (db_postprocess.cpp:265) without
+    // computing the rectangle.  Noise maps are made of thousands of such borders.
+    if ((bw - 1) * (bw - 1) + (bh - 1) * (bh - 1) <= 8) { if (tid == 0) res->status = ST_SKIP_SSID; return; }
+    if (bw > S_MW) { if (tid == 0) { res->status = ST_DEFER; atomicOr(&a.flags[img], 8); } return; }
+    __shared__ __attribute__((aligned(16))) unsigned arena[3 * S_MW];
+    __shared__ int wave_cnt[CT_THREADS / 64];
+    __shared__ int sh_n;
+    const int n = hull_candidates<S_MW>(a.pool + (long)img * d.pool_cap + ac.off, ac.nstates, ac.xmin, bw, arena, a.hin + bi * S_MH, S_MH,
+                                        wave_cnt, &sh_n);
+    if (tid == 0) {
+        if (n > S_MH) { res->status = ST_DEFER; atomicOr(&a.flags[img], 8); }
+        else { a.hn[bi] = n; res->status = ST_PEND_RECT; }
+    }
 }
 
-// full-size pass: a few workgroups per image walk the borders the small pass deferred (usually none)
-__global__ __launch_bounds__(CT_THREADS, 1) void contour_big_kernel(const float *__restrict__ maps, const Cand *__restrict__ cands,
-                                                                    const int *__restrict__ totals, const CandInfo *__restrict__ info,
-                                                                    const unsigned *__restrict__ pool, unsigned *__restrict__ gslots,
-                                                                    int *__restrict__ slot_locks, Result *__restrict__ results,
-                                                                    int *__restrict__ flags, const int *__restrict__ src_wh,
-                                                                    float box_thresh, float unclip_ratio, long slot_words,
-                                                                    int use_padding_resize, DbpostDims d) {
+// ---- stage B kernel: one WAVE per border (3.7 KB of LDS, no other resource: thousands are resident at once, so the stage
+// lasts as long as ONE rectangle).  The rectangle is the reference's sequential float32 code, run by lane 0 on LDS arrays.
+__global__ __launch_bounds__(64) void rect_kernel(StageArgs a, DbpostDims d) {
+    const int img = blockIdx.y, k = blockIdx.x;
+    if (k >= min(a.totals[img], MAX_CAND)) return;
+    const long bi = (long)img * MAX_CAND + k;
+    Result *res = &a.results[bi];
+    if (res->status != ST_PEND_RECT) return;                    // uniform over the wave
+    __shared__ F2 cand[S_MH], hull[S_MH];
+    __shared__ int stack[2 * (S_MH + 2)];
+    __shared__ float scratch[3 * S_MH + 4];
+    const int n = a.hn[bi];
+    for (int i = threadIdx.x; i < n; i += 64) cand[i] = a.hin[bi * S_MH + i];
+    __syncthreads();
+    if (threadIdx.x == 0) res->status = rect_stage(cand, n, hull, stack, scratch, res, reinterpret_cast<float (*)[2]>(a.mini + bi * 8));
+}
+
+// ---- stage C kernel: BoxScore (db_postprocess.cpp:194-229), one workgroup per border (15.6 KB of LDS: mask planes up to 63 488 px)
+__global__ __launch_bounds__(CT_THREADS, 6) void score_kernel(StageArgs a, DbpostDims d) {
+    const int img = blockIdx.y, k = blockIdx.x;
+    if (k >= min(a.totals[img], MAX_CAND)) return;
+    const int tid = threadIdx.x;
+    const long bi = (long)img * MAX_CAND + k;
+    Result *res = &a.results[bi];
+    if (res->status != ST_PEND_SCORE) return;                   // uniform over the workgroup (written by an earlier kernel)
+    const Acc ac = a.acc[bi];
+    const int bw = ac.xmax - ac.xmin + 1, bh = ac.ymax - ac.ymin + 1;
+    const long plane_words = (long)((bw + 31) >> 5) * bh;
+    if (plane_words > S_PLANE) { if (tid == 0) { res->status = ST_DEFER; atomicOr(&a.flags[img], 8); } return; }
+    __shared__ __attribute__((aligned(16))) unsigned planes[2 * S_PLANE];
+    __shared__ double red_d[CT_THREADS / 64];
+    __shared__ int red_i[CT_THREADS / 64];
+    const float *pimg = a.maps + (long)img * d.HW;
+    double total; int npix;
+    score_mask<false>(a.pool + (long)img * d.pool_cap + ac.off, ac.nstates, ac.xmin, ac.ymin, bw, bh, planes, planes + S_PLANE, pimg, d.W,
+                      red_d, red_i, &total, &npix);
+    float score = (float)(npix ? total / npix : 0.0);
+    if (fabs((double)score - (double)a.box_thresh) <= 1e-6) {
+        if (tid == 0) { red_d[0] = score_mask_raster_order<false>(planes, ac.xmin, ac.ymin, bw, bh, pimg, d.W); atomicOr(&a.flags[img], 2); }
+        __syncthreads();
+        score = (float)(npix ? red_d[0] / npix : 0.0);
+    }
+    if (tid == 0) {
+        res->score = score; res->npix = npix;
+        res->status = score < a.box_thresh ? ST_SKIP_SCORE : ST_PEND_UNCLIP;              // db_postprocess.cpp:272
+    }
+}
+
+// ---- stage D kernel: one WAVE per border (3.5 KB of LDS): lane 0 offsets the mini-box (double-precision trigonometry), the
+// wave sorts the offset polygon by rank, lane 0 runs the second rectangle and the final box
+__global__ __launch_bounds__(64, 5) void unclip_kernel(StageArgs a, DbpostDims d) {
+    const int img = blockIdx.y, k = blockIdx.x;
+    if (k >= min(a.totals[img], MAX_CAND)) return;
+    const long bi = (long)img * MAX_CAND + k;
+    Result *res = &a.results[bi];
+    if (res->status != ST_PEND_UNCLIP) return;                  // uniform over the wave
+    __shared__ F2 raw[S_MH], pts[S_MH], hull[S_MH];
+    __shared__ int stack[2 * (S_MH + 2)];
+    __shared__ float scratch[3 * S_MH + 4];
+    __shared__ long long cl_ws[24];
+    __shared__ int sh_np;
+    const float (*mini)[2] = reinterpret_cast<const float (*)[2]>(a.mini + bi * 8);
+    if (threadIdx.x == 0) sh_np = unclip_offset(mini, a.unclip_ratio, raw, S_MH, res, &a.flags[img], cl_ws);
+    __syncthreads();
+    const int np = sh_np;
+    if (np > S_MH) { if (threadIdx.x == 0) { res->status = ST_DEFER; atomicOr(&a.flags[img], 8); } return; }
+    // sort by (x, y) like cv::convexHull: every lane ranks its point (equal points keep their order: they are identical anyway)
+    for (int i = threadIdx.x; i < np; i += 64) {
+        const F2 t = raw[i];
+        int rank = 0;
+        for (int j = 0; j < np; j++) {
+            const F2 o = raw[j];
+            rank += (o.x < t.x || (o.x == t.x && (o.y < t.y || (o.y == t.y && j < i)))) ? 1 : 0;
+        }
+        pts[rank] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        res->status = unclip_finish(pts, np, hull, stack, scratch, res, a.src_wh[2 * img], a.src_wh[2 * img + 1], a.use_padding_resize, d);
+}
+
+// ---- full-size pass: a few workgroups per image walk the borders the small-footprint stages deferred (borders wider than
+// 512 px, masks beyond 30720 px, more than 96 hull / offset points: usually none) through all four stages, serial parts on lane 0
+__global__ __launch_bounds__(CT_THREADS, 1) void contour_big_kernel(StageArgs a, DbpostDims d) {
     const int img = blockIdx.y;
-    if (!(flags[img] & 8)) return;                        // internal bit 3: the small pass deferred at least one border of this image
-    const int num = min(totals[img], MAX_CAND);
+    if (!(a.flags[img] & 8)) return;                      // internal bit 3: a small stage deferred at least one border of this image
+    const int tid = threadIdx.x;
+    constexpr int ARENA = 2 * LDS_PLANE_WORDS > 3 * MAXW ? 2 * LDS_PLANE_WORDS : 3 * MAXW;
+    __shared__ __attribute__((aligned(16))) unsigned arena[ARENA];     // column tables (hull stage) / mask planes (score stage)
+    __shared__ F2 cand_pts[MAXHULL];
+    __shared__ F2 hull_pts[MAXHULL];
+    __shared__ int stack[2 * (MAXHULL + 2)];
+    __shared__ float cal_scratch[3 * MAXHULL + 4];
+    __shared__ long long cl_ws[24];
+    __shared__ double red_d[CT_THREADS / 64];
+    __shared__ int red_i[CT_THREADS / 64];
+    __shared__ int wave_cnt[CT_THREADS / 64];
+    __shared__ int sh_n, sh_status;
+    __shared__ float sh_mini[4][2];
+    const int num = min(a.totals[img], MAX_CAND);
     for (int k = blockIdx.x; k < num; k += gridDim.x) {
-        if (results[(long)img * MAX_CAND + k].status != ST_DEFER) continue;       // uniform over the workgroup
-        contour_body<MAXW, LDS_PLANE_WORDS, MAXHULL, false>(img, k, maps, cands, info, pool, gslots, slot_locks, results, flags, src_wh,
-                                                            box_thresh, unclip_ratio, slot_words, use_padding_resize, d);
-        __syncthreads();                                                          // the body's LDS is reused by the next border
+        const long bi = (long)img * MAX_CAND + k;
+        Result *res = &a.results[bi];
+        if (res->status != ST_DEFER) continue;            // uniform over the workgroup
+        __syncthreads();                                  // the LDS below is reused from the previous border
+        const Acc ac = a.acc[bi];
+        const unsigned *st = a.pool + (long)img * d.pool_cap + ac.off;
+        const int bw = ac.xmax - ac.xmin + 1, bh = ac.ymax - ac.ymin + 1;
+        const int n = hull_candidates<MAXW>(st, ac.nstates, ac.xmin, bw, arena, cand_pts, MAXHULL, wave_cnt, &sh_n);
+        if (tid == 0) {
+            if (n > MAXHULL) { atomicOr(&a.flags[img], 4); sh_status = ST_NONE; }
+            else sh_status = rect_stage(cand_pts, n, hull_pts, stack, cal_scratch, res, sh_mini);
+        }
+        __syncthreads();
+        if (sh_status != ST_PEND_SCORE) { if (tid == 0) res->status = sh_status; continue; }
+        const float *pimg = a.maps + (long)img * d.HW;
+        const long plane_words = (long)((bw + 31) >> 5) * bh;
+        double total; int npix;
+        float score;
+        if (plane_words <= LDS_PLANE_WORDS) {
+            unsigned *border = arena, *toggle = arena + LDS_PLANE_WORDS;
+            score_mask<false>(st, ac.nstates, ac.xmin, ac.ymin, bw, bh, border, toggle, pimg, d.W, red_d, red_i, &total, &npix);
+            score = (float)(npix ? total / npix : 0.0);
+            if (fabs((double)score - (double)a.box_thresh) <= 1e-6) {
+                if (tid == 0) { red_d[0] = score_mask_raster_order<false>(border, ac.xmin, ac.ymin, bw, bh, pimg, d.W); atomicOr(&a.flags[img], 2); }
+                __syncthreads();
+                score = (float)(npix ? red_d[0] / npix : 0.0);
+            }
+        } else {
+            const int slot = (int)(bi % NSLOTS);
+            unsigned *border = a.gslots + (long)slot * 2 * a.slot_words, *toggle = border + a.slot_words;
+            if (tid == 0) { while (atomicCAS(&a.slot_locks[slot], 0, 1) != 0) __builtin_amdgcn_s_sleep(32); __threadfence(); }
+            __syncthreads();
+            score_mask<true>(st, ac.nstates, ac.xmin, ac.ymin, bw, bh, border, toggle, pimg, d.W, red_d, red_i, &total, &npix);
+            score = (float)(npix ? total / npix : 0.0);
+            if (fabs((double)score - (double)a.box_thresh) <= 1e-6) {
+                if (tid == 0) { red_d[0] = score_mask_raster_order<true>(border, ac.xmin, ac.ymin, bw, bh, pimg, d.W); atomicOr(&a.flags[img], 2); }
+                __syncthreads();
+                score = (float)(npix ? red_d[0] / npix : 0.0);
+            }
+            __syncthreads();
+            if (tid == 0) { __threadfence(); atomicExch(&a.slot_locks[slot], 0); }
+        }
+        if (tid == 0) {
+            res->score = score; res->npix = npix;
+            if (score < a.box_thresh) res->status = ST_SKIP_SCORE;                       // db_postprocess.cpp:272
+            else {
+                int s = unclip_stage(sh_mini, a.unclip_ratio, cand_pts, MAXHULL, hull_pts, stack, cal_scratch, res, &a.flags[img],
+                                     a.src_wh[2 * img], a.src_wh[2 * img + 1], a.use_padding_resize, d, cl_ws);
+                if (s == ST_DEFER) { atomicOr(&a.flags[img], 4); s = ST_NONE; }
+                res->status = s;
+            }
+        }
     }
 }
 
@@ -1213,7 +1388,8 @@ using namespace ptocr;
 
 struct ptocr_dbpost {
     int max_n, max_h, max_w;
-    unsigned *bits; unsigned *bits2; int *labels; int *chunk_cnt; int *totals; int *strip_totals; Cand *cands; CandInfo *info; unsigned *pool;
+    unsigned *bits; unsigned *bits2; int *labels; int *word_lab; int *chunk_cnt; int *totals; int *strip_totals; Cand *cands; Acc *acc;
+    unsigned *pool; F2 *hin; int *hn; float *mini;
     unsigned *gslots; int *slot_locks; long slot_words; Result *results; int *flags; int *src_wh; short *boxes; int *counts;
     int boxes_cap;
     long pool_cap;
@@ -1223,23 +1399,27 @@ struct ptocr_dbpost {
 
 extern "C" int ptocr_dbpost_create(ptocr_dbpost_t *out, int max_n, int max_h, int max_w) {
     PT_CHECK(out && max_n > 0 && max_h > 0 && max_w > 0, "ptocr_dbpost_create: bad arguments");
-    PT_CHECK(max_w <= MAXW && max_h < 32768 && (long)max_h * max_w < (1L << 31), "ptocr_dbpost_create: map larger than %d wide / 32767 high", MAXW);
+    PT_CHECK(max_w <= MAXW && max_h < 32768 && (long)max_h * max_w < (1L << 29), "ptocr_dbpost_create: map larger than %d wide / 32767 high / 2^29 pixels", MAXW);
     ptocr_dbpost *h = new ptocr_dbpost();
     memset(h, 0, sizeof *h);
     h->max_n = max_n; h->max_h = max_h; h->max_w = max_w;
     const long hw = (long)max_h * max_w, ww = cdiv(max_w, 32);
-    h->pool_cap = 2 * hw;
+    h->pool_cap = 4 * hw + 64;                  // a pixel has at most 4 gaps: no map can overflow this
     h->boxes_cap = MAX_CAND;
     const long nch = (hw + CHUNK - 1) / CHUNK;
     PT_HIP(hipMalloc(&h->bits, sizeof(unsigned) * max_n * max_h * ww));
     PT_HIP(hipMalloc(&h->bits2, sizeof(unsigned) * max_n * max_h * ww));
     PT_HIP(hipMalloc(&h->labels, sizeof(int) * max_n * hw));
+    PT_HIP(hipMalloc(&h->word_lab, sizeof(int) * max_n * max_h * ww));
     PT_HIP(hipMalloc(&h->chunk_cnt, sizeof(int) * max_n * nch));
     PT_HIP(hipMalloc(&h->totals, sizeof(int) * max_n));
     PT_HIP(hipMalloc(&h->strip_totals, sizeof(int) * max_n));
     PT_HIP(hipMalloc(&h->cands, sizeof(Cand) * max_n * MAX_CAND));
-    PT_HIP(hipMalloc(&h->info, sizeof(CandInfo) * max_n * MAX_CAND));
-    PT_HIP(hipMalloc(&h->pool, sizeof(unsigned) * max_n * (QOFF + h->pool_cap)));
+    PT_HIP(hipMalloc(&h->acc, sizeof(Acc) * max_n * MAX_CAND));
+    PT_HIP(hipMalloc(&h->pool, sizeof(unsigned) * max_n * h->pool_cap));
+    PT_HIP(hipMalloc(&h->hin, sizeof(F2) * (size_t)max_n * MAX_CAND * S_MH));
+    PT_HIP(hipMalloc(&h->hn, sizeof(int) * max_n * MAX_CAND));
+    PT_HIP(hipMalloc(&h->mini, sizeof(float) * 8 * max_n * MAX_CAND));
     h->slot_words = (long)max_h * ww + 64;
     PT_HIP(hipMalloc(&h->gslots, sizeof(unsigned) * NSLOTS * 2 * h->slot_words));
     PT_HIP(hipMalloc(&h->slot_locks, sizeof(int) * NSLOTS));
@@ -1257,8 +1437,8 @@ extern "C" int ptocr_dbpost_create(ptocr_dbpost_t *out, int max_n, int max_h, in
 
 extern "C" int ptocr_dbpost_destroy(ptocr_dbpost_t h) {
     if (!h) return 0;
-    void *bufs[] = {h->bits, h->bits2, h->labels, h->chunk_cnt, h->totals, h->strip_totals, h->cands, h->info, h->pool, h->gslots, h->slot_locks,
-                    h->results, h->flags, h->src_wh, h->boxes, h->counts};
+    void *bufs[] = {h->bits, h->bits2, h->labels, h->word_lab, h->chunk_cnt, h->totals, h->strip_totals, h->cands, h->acc, h->pool, h->hin,
+                    h->hn, h->mini, h->gslots, h->slot_locks, h->results, h->flags, h->src_wh, h->boxes, h->counts};
     for (void *b : bufs) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1267,6 +1447,7 @@ extern "C" int ptocr_dbpost_destroy(ptocr_dbpost_t h) {
 }
 
 // debug/inspection hook used by the parity tests: copies the per-candidate records of the last call
+struct CandInfoOut { int npts, off; short xmin, xmax, ymin, ymax; };
 extern "C" int ptocr_dbpost_debug_results(ptocr_dbpost_t h, int img, int32_t *h_total, void *h_results /* MAX_CAND x Result */,
                                           void *h_cands /* MAX_CAND x Cand */, void *h_info /* MAX_CAND x CandInfo */) {
     PT_CHECK(h && img >= 0 && img < h->max_n, "ptocr_dbpost_debug_results: bad arguments");
@@ -1274,7 +1455,35 @@ extern "C" int ptocr_dbpost_debug_results(ptocr_dbpost_t h, int img, int32_t *h_
     PT_HIP(hipMemcpy(h_total, h->totals + img, sizeof(int), hipMemcpyDeviceToHost));
     PT_HIP(hipMemcpy(h_results, h->results + (long)img * MAX_CAND, sizeof(Result) * MAX_CAND, hipMemcpyDeviceToHost));
     PT_HIP(hipMemcpy(h_cands, h->cands + (long)img * MAX_CAND, sizeof(Cand) * MAX_CAND, hipMemcpyDeviceToHost));
-    PT_HIP(hipMemcpy(h_info, h->info + (long)img * MAX_CAND, sizeof(CandInfo) * MAX_CAND, hipMemcpyDeviceToHost));
+    static thread_local Acc accs[MAX_CAND];
+    PT_HIP(hipMemcpy(accs, h->acc + (long)img * MAX_CAND, sizeof(Acc) * MAX_CAND, hipMemcpyDeviceToHost));
+    CandInfoOut *o = static_cast<CandInfoOut *>(h_info);
+    for (int k = 0; k < MAX_CAND; k++) {
+        o[k].npts = accs[k].npts; o[k].off = accs[k].off;
+        o[k].xmin = (short)accs[k].xmin; o[k].xmax = (short)accs[k].xmax; o[k].ymin = (short)accs[k].ymin; o[k].ymax = (short)accs[k].ymax;
+    }
+    return 0;
+}
+
+// second inspection hook: the border states of candidate k of image img (x | y << 11 | s_out << 26 | s_in << 29); returns the
+// number of states through h_n (0 for a border that got no pool space: <= 2 contour points)
+extern "C" int ptocr_dbpost_debug_states(ptocr_dbpost_t h, int img, int k, uint32_t *h_states, int cap, int32_t *h_n) {
+    PT_CHECK(h && img >= 0 && img < h->max_n && k >= 0 && k < MAX_CAND && h_states && h_n, "ptocr_dbpost_debug_states: bad arguments");
+    PT_HIP(hipDeviceSynchronize());
+    Acc a;
+    PT_HIP(hipMemcpy(&a, h->acc + (long)img * MAX_CAND + k, sizeof a, hipMemcpyDeviceToHost));
+    *h_n = a.off >= 0 ? a.nstates : 0;
+    const int n = *h_n < cap ? *h_n : cap;
+    if (n > 0) PT_HIP(hipMemcpy(h_states, h->pool + (long)img * h->pool_cap + a.off, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// third inspection hook: the label image (valid at run starts) and the per-word labels of image img of the last H x W call
+extern "C" int ptocr_dbpost_debug_labels(ptocr_dbpost_t h, int img, int H, int W, int32_t *h_labels, int32_t *h_word_labels) {
+    PT_CHECK(h && img >= 0 && img < h->max_n && h_labels && h_word_labels, "ptocr_dbpost_debug_labels: bad arguments");
+    PT_HIP(hipDeviceSynchronize());
+    PT_HIP(hipMemcpy(h_labels, h->labels + (long)img * H * W, sizeof(int) * (size_t)H * W, hipMemcpyDeviceToHost));
+    PT_HIP(hipMemcpy(h_word_labels, h->word_lab + (long)img * H * cdiv(W, 32), sizeof(int) * (size_t)H * cdiv(W, 32), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -1307,7 +1516,6 @@ extern "C" int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, co
     d.N = N; d.H = H; d.W = W; d.WW = cdiv(W, 32); d.HW = (long)H * W;
     d.nchunks = (int)((d.HW + CHUNK - 1) / CHUNK);
     d.pool_cap = h->pool_cap;
-    d.pool_stride = QOFF + h->pool_cap;
     PT_HIP(hipMemcpyAsync(h->src_wh, h_src_wh, sizeof(int) * 2 * N, hipMemcpyHostToDevice, s));
     PT_HIP(hipEventRecord(h->ev0, s));
     PT_HIP(hipMemsetAsync(h->flags, 0, sizeof(int) * N, s));
@@ -1321,6 +1529,8 @@ extern "C" int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, co
     }
     PT_HIP(hipMemsetAsync(h->chunk_cnt, 0, sizeof(int) * (size_t)N * d.nchunks, s));
     const int strip_y = H > 2 * STRIP_ROWS ? H - STRIP_ROWS : 0;      // small maps: one pass over everything
+    d.strip_y = strip_y;
+    if (!strip_y) PT_HIP(hipMemsetAsync(h->strip_totals, 0, sizeof(int) * N, s));
     for (int pass = strip_y ? 0 : 1; pass < 2; pass++) {
         CclPass ps;
         ps.y_first = pass == 0 ? strip_y : 0;
@@ -1329,18 +1539,25 @@ extern "C" int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, co
         const dim3 word_grid(cdiv(words > d.nchunks ? words : d.nchunks, 256), N);
         hipLaunchKernelGGL(ccl_init_kernel, word_grid, dim3(256), 0, s, bits, h->labels, h->chunk_cnt, d, ps);
         hipLaunchKernelGGL(ccl_merge_kernel, dim3(cdiv(4 * words, 256), N), dim3(256), 0, s, bits, h->labels, d, ps);
-        hipLaunchKernelGGL(ccl_flatten_kernel, word_grid, dim3(256), 0, s, bits, h->labels, h->chunk_cnt, d, ps);
+        hipLaunchKernelGGL(ccl_flatten_kernel, word_grid, dim3(256), 0, s, bits, h->labels, h->word_lab, h->chunk_cnt, d, ps);
         hipLaunchKernelGGL(chunk_suffix_kernel, dim3(N), dim3(1024), 0, s, h->chunk_cnt, h->totals, d, ps, h->strip_totals);
     }
-    hipLaunchKernelGGL(gather_starts_kernel, dim3(d.nchunks, N), dim3(256), 0, s, bits, h->labels, h->chunk_cnt, h->cands, d);
-    hipLaunchKernelGGL(trace_count_kernel, dim3(MAX_CAND, N), dim3(64), 0, s, bits, h->cands, h->totals, h->info, h->pool, d);
-    hipLaunchKernelGGL(pool_offsets_kernel, dim3(N), dim3(1024), 0, s, h->info, h->totals, h->flags, d);
-    hipLaunchKernelGGL(trace_write_kernel, dim3(MAX_CAND, N), dim3(64), 0, s, bits, h->cands, h->totals, h->info,
-                       h->pool, h->flags, d);
-    hipLaunchKernelGGL(contour_kernel, dim3(MAX_CAND, N), dim3(CT_THREADS), 0, s, d_maps, h->cands, h->totals, h->info, h->pool, h->gslots,
-                       h->slot_locks, h->results, h->flags, h->src_wh, box_thresh, unclip_ratio, h->slot_words, use_padding_resize, d);
-    hipLaunchKernelGGL(contour_big_kernel, dim3(64, N), dim3(CT_THREADS), 0, s, d_maps, h->cands, h->totals, h->info, h->pool, h->gslots,
-                       h->slot_locks, h->results, h->flags, h->src_wh, box_thresh, unclip_ratio, h->slot_words, use_padding_resize, d);
+    hipLaunchKernelGGL(select_starts_kernel, dim3(d.nchunks, N), dim3(256), 0, s, bits, h->labels, h->chunk_cnt, h->totals, h->cands, h->acc, d);
+    const dim3 all_words(cdiv(H * d.WW, 256), N);
+    hipLaunchKernelGGL(border_states_kernel<false>, all_words, dim3(256), 0, s, bits, h->labels, h->word_lab, h->strip_totals, h->acc, h->pool,
+                       h->flags, d);
+    hipLaunchKernelGGL(pool_offsets_kernel, dim3(N), dim3(1024), 0, s, h->acc, h->totals, h->flags, d);
+    hipLaunchKernelGGL(border_states_kernel<true>, all_words, dim3(256), 0, s, bits, h->labels, h->word_lab, h->strip_totals, h->acc, h->pool,
+                       h->flags, d);
+    StageArgs a;
+    a.maps = d_maps; a.cands = h->cands; a.totals = h->totals; a.acc = h->acc; a.pool = h->pool; a.gslots = h->gslots; a.slot_locks = h->slot_locks;
+    a.results = h->results; a.flags = h->flags; a.src_wh = h->src_wh; a.hin = h->hin; a.hn = h->hn; a.mini = h->mini;
+    a.box_thresh = box_thresh; a.unclip_ratio = unclip_ratio; a.slot_words = h->slot_words; a.use_padding_resize = use_padding_resize;
+    hipLaunchKernelGGL(hull_kernel, dim3(MAX_CAND, N), dim3(CT_THREADS), 0, s, a, d);
+    hipLaunchKernelGGL(rect_kernel, dim3(MAX_CAND, N), dim3(64), 0, s, a, d);
+    hipLaunchKernelGGL(score_kernel, dim3(MAX_CAND, N), dim3(CT_THREADS), 0, s, a, d);
+    hipLaunchKernelGGL(unclip_kernel, dim3(MAX_CAND, N), dim3(64), 0, s, a, d);
+    hipLaunchKernelGGL(contour_big_kernel, dim3(64, N), dim3(CT_THREADS), 0, s, a, d);
     hipLaunchKernelGGL(compact_kernel, dim3(N), dim3(1024), 0, s, h->results, h->totals, h->boxes, h->counts, max_boxes);
     if (int e = launch_ok("dbpost kernels")) return e;
     PT_HIP(hipEventRecord(h->ev1, s));
@@ -1351,7 +1568,7 @@ extern "C" int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, co
     PT_HIP(hipStreamSynchronize(s));
     for (int i = 0; i < N; i++) h_flags[i] &= 7;           // bit 3 is internal (deferred borders)
     for (int i = 0; i < N; i++)
-        if (h_flags[i] & 4) return fail("ptocr_db_postprocess: internal capacity exceeded on image %d (point pool %ld points or hull "
+        if (h_flags[i] & 4) return fail("ptocr_db_postprocess: internal capacity exceeded on image %d (state pool %ld entries or hull "
                                         "candidates %d)", i, h->pool_cap, MAXHULL);
     return 0;
 }
