@@ -425,14 +425,17 @@ __global__ __launch_bounds__(256) void border_states_kernel(const unsigned *__re
                                                             const int *__restrict__ flags, DbpostDims d) {
     const int img = blockIdx.y;
     const int y_first = (d.strip_y && strip_totals[img] >= MAX_CAND) ? d.strip_y : 0;     // rows above carry no labels (and no candidate)
-    const int idx0 = blockIdx.x * 256 + threadIdx.x;
-    const bool in_range = idx0 < (d.H - y_first) * d.WW && !(WRITE && (flags[img] & 4));
-    const int idx = in_range ? idx0 : 0;                        // out-of-range lanes idle along (the wave reduction below wants all lanes)
-    const int y = y_first + idx / d.WW, wi = idx % d.WW;
+    // a wave owns a TILE of 8 rows x 8 words (256 x 8 pixels), not 64 consecutive words of a row: a border's words then fall into
+    // few waves, and the per-wave combination at the end leaves few atomics per border
+    const int tiles_x = cdiv(d.WW, 8);
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane_t = threadIdx.x & 63;
+    const int ty0 = (tile / tiles_x) * 8 + (lane_t >> 3), tx0 = (tile % tiles_x) * 8 + (lane_t & 7);
+    const bool in_range = ty0 < d.H - y_first && tx0 < d.WW && !(WRITE && (flags[img] & 4));
+    const int y = in_range ? y_first + ty0 : y_first, wi = in_range ? tx0 : 0;   // out-of-range lanes idle along (the wave reduction wants all lanes)
     const unsigned *bimg = bits + (long)img * d.H * d.WW;
     const unsigned w = in_range ? bimg[(long)y * d.WW + wi] : 0u;
-    auto ld = [&](int yy, int ww) -> unsigned {
-        return ((unsigned)yy < (unsigned)d.H && (unsigned)ww < (unsigned)d.WW) ? bimg[(long)yy * d.WW + ww] : 0u;
+    auto ld = [&](int yy, int ww) -> unsigned {                  // (an all-background word has no border point: no neighbour loads)
+        return (w && (unsigned)yy < (unsigned)d.H && (unsigned)ww < (unsigned)d.WW) ? bimg[(long)yy * d.WW + ww] : 0u;
     };
     const unsigned cl = ld(y, wi - 1), cr = ld(y, wi + 1);
     const unsigned up = ld(y - 1, wi), ul = ld(y - 1, wi - 1), ur = ld(y - 1, wi + 1);
@@ -441,14 +444,13 @@ __global__ __launch_bounds__(256) void border_states_kernel(const unsigned *__re
     const unsigned pE = (w >> 1) | (cr << 31), pW = (w << 1) | (cl >> 31);
     const unsigned pNE = (up >> 1) | (ur << 31), pNW = (up << 1) | (ul >> 31);
     const unsigned pSE = (dn >> 1) | (dr << 31), pSW = (dn << 1) | (dl >> 31);
-    unsigned border = w & ~(up & dn & pE & pW);                 // border points: a background pixel among the 4-neighbours
     const int *lab = labels + (long)img * d.HW;
     const int *wl = word_lab + (long)img * d.H * d.WW;
     Acc *ac = acc + (long)img * MAX_CAND;
     unsigned *pl = pool + (long)img * d.pool_cap;
-    int f_key = -2, F = FRAME, S = -3;                          // cached: run of the current pixel -> its component, its surround
-    int n_key = -2, BN = FRAME, s_key = -2, BS = FRAME;         // cached: background run above / below the current pixel -> its component
-    int ak = -1, an = 0, ap = 0, ax0 = 0, ax1 = 0;              // count mode: pending totals of candidate ak
+    int f_key = -2, F = FRAME, S = -3, kF = -1;                 // cached: run of the current pixel -> its component, its surround, its candidate
+    int n_key = -2, BN = FRAME, kN = -1, s_key = -2, BS = FRAME, kS = -1;   // cached: background run above / below -> component, candidate
+    int ak = -1, an = 0, ap = 0, ax0 = 0x7fffffff, ax1 = -1;    // count mode: pending totals of candidate ak
     unsigned buf[8]; int bn = 0, bk = -1;                       // write mode: pending states of candidate bk (one slot reservation per 8)
     auto wflush = [&]() {
         if (bn) {
@@ -468,27 +470,86 @@ __global__ __launch_bounds__(256) void border_states_kernel(const unsigned *__re
             atomicMin(&ac[ak].ymin, y); atomicMax(&ac[ak].ymax, y);
         }
     };
-    while (border) {
-        const int i = __ffs(border) - 1;
-        border &= border - 1;
+    // component of pixel i of this word (cached per run), the background component that surrounds it, its candidate
+    auto look_f = [&](int i) {
+        const unsigned m = ~w & ((1u << i) - 1u);
+        const int key = m ? 32 - __clz(m) : -1;
+        if (key != f_key) {
+            f_key = key;
+            if (m) { const int rs = y * d.W + wi * 32 + key; F = canon_root(lab[rs], rs); }
+            else F = wl[(long)y * d.WW + wi];
+            if (F < 0) { S = -3; kF = -1; }                      // (strip mode) component reaches above the strip: never a candidate
+            else {
+                const int fy = F / d.W, fx = F - fy * d.W;
+                S = fx == 0 ? FRAME : root_of_pixel(bimg, lab, wl, d, fx - 1, fy);
+                kF = cand_of_root(lab, F);
+            }
+        }
+    };
+    // the background run straight above (g4 == 2) / below (g4 == 6) pixel i: found in the row word this thread already holds,
+    // cached per run (the states along the top or the bottom edge of a text line share it)
+    auto look_ns = [&](int i, int g4, int &B, int &kB) {
+        const int zy = g4 == 2 ? y - 1 : y + 1;
+        if (!((unsigned)zy < (unsigned)d.H && zy >= y_first)) { B = FRAME; kB = -1; return; }
+        const unsigned rw = g4 == 2 ? up : dn;
+        const unsigned m = rw & ((1u << i) - 1u);
+        const int key = m ? 32 - __clz(m) : -1;
+        int &ck = g4 == 2 ? n_key : s_key;
+        int &cb = g4 == 2 ? BN : BS;
+        int &cc = g4 == 2 ? kN : kS;
+        if (key != ck) {
+            ck = key;
+            if (m) { const int rs = zy * d.W + wi * 32 + key; cb = canon_root(lab[rs], rs); }
+            else cb = wl[(long)zy * d.WW + wi];
+            cc = cand_of_root(lab, cb);
+        }
+        B = cb; kB = cc;
+    };
+    // ---- bulk: the straight horizontal states.  Along the top edge of a blob the walk runs west through pixels whose gap is
+    // exactly {NE, N, NW} (s_in = E, s_out = W), along the bottom edge east through {SW, S, SE}; such states are most of a text
+    // line's border, they never turn, and a contiguous stretch of them shares F, B and the candidate: one look-up, one
+    // reservation, then a store per state.
+    const unsigned straight_t = w & pE & pW & ~pNE & ~up & ~pNW;
+    const unsigned straight_b = w & pE & pW & ~pSW & ~dn & ~pSE;
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+        unsigned M = side ? straight_b : straight_t;
+        const int g4 = side ? 6 : 2;
+        const unsigned code = side ? ((0u << 26) | (4u << 29)) : ((4u << 26) | (0u << 29));        // s_out << 26 | s_in << 29
+        while (M) {
+            const int i0 = __ffs(M) - 1;
+            const unsigned rest = ~(M >> i0);
+            const int len = rest ? __ffs(rest) - 1 : 32 - i0;
+            M &= ~((len == 32 ? 0xffffffffu : ((1u << len) - 1u)) << i0);
+            look_f(i0);
+            int B, kB;
+            look_ns(i0, g4, B, kB);
+            const int k = (B == S) ? kF : kB;
+            if (k < 0) continue;
+            const int x0 = wi * 32 + i0;
+            if (WRITE) {
+                const int off = ac[k].off;
+                if (off >= 0) {
+                    const int pos = off + atomicAdd(&ac[k].cursor, len);
+                    const unsigned base = (unsigned)x0 | ((unsigned)y << 11) | code;
+                    for (int j = 0; j < len; j++) pl[pos + j] = base + (unsigned)j;
+                }
+            } else {
+                if (k != ak) { flush(); ak = k; an = 0; ap = 0; ax0 = 0x7fffffff; ax1 = -1; }
+                an += len; ax0 = min(ax0, x0); ax1 = max(ax1, x0 + len - 1);
+            }
+        }
+    }
+    // ---- the other states, pixel by pixel: pixels with a gap that starts after some other neighbour, or isolated pixels
+    unsigned generic = w & (((pE & ~pNE) & ~straight_t) | (pNE & ~up) | (up & ~pNW) | (pNW & ~pW) | ((pW & ~pSW) & ~straight_b) |
+                            (pSW & ~dn) | (dn & ~pSE) | (pSE & ~pE) | ~(pE | pNE | up | pNW | pW | pSW | dn | pSE));
+    while (generic) {
+        const int i = __ffs(generic) - 1;
+        generic &= generic - 1;
         const int x = wi * 32 + i;
         const unsigned nb = ((pE >> i) & 1u) | (((pNE >> i) & 1u) << 1) | (((up >> i) & 1u) << 2) | (((pNW >> i) & 1u) << 3) |
                             (((pW >> i) & 1u) << 4) | (((pSW >> i) & 1u) << 5) | (((dn >> i) & 1u) << 6) | (((pSE >> i) & 1u) << 7);
-        // component of this pixel (cached per run) and the background component that surrounds it
-        {
-            const unsigned m = ~w & ((1u << i) - 1u);
-            const int key = m ? 32 - __clz(m) : -1;
-            if (key != f_key) {
-                f_key = key;
-                if (m) { const int rs = y * d.W + wi * 32 + key; F = canon_root(lab[rs], rs); }
-                else F = wl[(long)y * d.WW + wi];
-                if (F < 0) S = -3;                              // (strip mode) component reaches above the strip: never a candidate
-                else {
-                    const int fy = F / d.W, fx = F - fy * d.W;
-                    S = fx == 0 ? FRAME : root_of_pixel(bimg, lab, wl, d, fx - 1, fy);
-                }
-            }
-        }
+        look_f(i);
         // gaps: for every foreground neighbour s_in whose counter-clockwise successor direction is background
         unsigned starts = nb & ~((nb >> 1) | (nb << 7)) & 0xffu;   // bit s set: neighbour s foreground, neighbour s+1 background
         const bool lone = nb == 0;
@@ -502,30 +563,20 @@ __global__ __launch_bounds__(256) void border_states_kernel(const unsigned *__re
             else {
                 const unsigned rot = ((nb | (nb << 8)) >> (s_in + 1)) & 0xffu;    // bit j = direction s_in + 1 + j
                 const int L = __ffs(rot) - 1;                    // background neighbours in the gap
+                if (L == 3 && (s_in & 3) == 0) continue;          // a straight horizontal state: booked in bulk above
                 s_out = (s_in + 1 + L) & 7;
                 g4 = ((s_in + 1) & 1) ? ((s_in + 2) & 7) : ((s_in + 1) & 7);      // first 4-direction at or after s_in + 1
                 has4 = L >= 2 || (L == 1 && ((s_in + 1) & 1) == 0);
             }
             if (!has4) continue;                                // a lone diagonal background pixel: the walk passes by
-            const int zx = x + dir_dx(g4), zy = y + dir_dy(g4);
-            int B;
-            if (!((unsigned)zx < (unsigned)d.W && (unsigned)zy < (unsigned)d.H && zy >= y_first)) B = FRAME;
-            else if (g4 == 2 || g4 == 6) {
-                // the background run above / below: found in the row word this thread already holds, cached per run (the states
-                // along the top or the bottom edge of a text line share it)
-                const unsigned rw = g4 == 2 ? up : dn;
-                const unsigned m = rw & ((1u << i) - 1u);
-                const int key = m ? 32 - __clz(m) : -1;
-                int &ck = g4 == 2 ? n_key : s_key;
-                int &cb = g4 == 2 ? BN : BS;
-                if (key != ck) {
-                    ck = key;
-                    if (m) { const int rs = zy * d.W + wi * 32 + key; cb = canon_root(lab[rs], rs); }
-                    else cb = wl[(long)zy * d.WW + wi];
-                }
-                B = cb;
-            } else B = root_of_pixel(bimg, lab, wl, d, zx, zy);
-            const int k = (B == S) ? cand_of_root(lab, F) : cand_of_root(lab, B);
+            int B, kB;
+            if (g4 == 2 || g4 == 6) look_ns(i, g4, B, kB);
+            else {
+                const int zx = x + dir_dx(g4);
+                if ((unsigned)zx < (unsigned)d.W) { B = root_of_pixel(bimg, lab, wl, d, zx, y); kB = cand_of_root(lab, B); }
+                else { B = FRAME; kB = -1; }
+            }
+            const int k = (B == S) ? kF : kB;
             if (k < 0) continue;
             const int emit = lone || s_out != (s_in ^ 4);       // the chain turns here: a CHAIN_APPROX_SIMPLE point
             if (WRITE) {
@@ -536,8 +587,8 @@ __global__ __launch_bounds__(256) void border_states_kernel(const unsigned *__re
                 buf[0] = (unsigned)x | ((unsigned)y << 11) | ((unsigned)s_out << 26) | ((unsigned)s_in << 29);
                 bn++;
             } else {
-                if (k != ak) { flush(); ak = k; an = 0; ap = 0; ax0 = x; }
-                an++; ap += emit; ax1 = x;
+                if (k != ak) { flush(); ak = k; an = 0; ap = 0; ax0 = 0x7fffffff; ax1 = -1; }
+                an++; ap += emit; ax0 = min(ax0, x); ax1 = max(ax1, x);
             }
         }
     }
@@ -776,6 +827,155 @@ __device__ RRect min_area_rect_sorted(const F2 *sorted, int n, F2 *hull, int *st
     return box;
 }
 
+// ---- wave-cooperative forms for the one-wave-per-border stages (all 64 lanes call them; blockDim.x == 64).  A lone lane pays
+// 8+ cycles per dependent instruction and ~100 per dependent LDS read, so everything that is independent per hull edge -- the
+// edge vectors and their inverse lengths (a double sqrt and a double division each), the four extreme vertices and the
+// orientation -- runs one edge per lane, with the reference's arithmetic and the reference's tie rules (the FIRST index that
+// attains an extreme; the first non-zero turn).  The caliper loop itself stays the reference's sequential code on lane 0.
+__device__ __forceinline__ void wave_first_extreme(float v, int idx, bool want_max, int *out_idx) {
+    // lane-private (value, index) candidates -> index of the extreme over the wave, lowest index among equals
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float v2 = __shfl_xor(v, o);
+        const int i2 = __shfl_xor(idx, o);
+        const bool better = i2 >= 0 && (idx < 0 || (want_max ? v2 > v : v2 < v) || (v2 == v && i2 < idx));
+        if (better) { v = v2; idx = i2; }
+    }
+    *out_idx = idx;
+}
+
+__device__ void rotating_calipers_wave(const F2 *points, int n, float *scratch, float *out) {
+    const int lane = threadIdx.x;
+    float *inv_len = scratch;
+    F2 *vect = reinterpret_cast<F2 *>(scratch + n);
+    int *seq = reinterpret_cast<int *>(scratch + 3 * n);
+    // per-lane scan of its own vertices in increasing order (strict comparisons keep the first index), then a wave reduction
+    float lx = 0, rx = 0, ty = 0, by = 0;
+    int li = -1, ri = -1, ti = -1, bi = -1;
+    for (int i = lane; i < n; i += 64) {
+        const F2 pt0 = points[i];
+        if (li < 0 || pt0.x < lx) { lx = pt0.x; li = i; }
+        if (ri < 0 || pt0.x > rx) { rx = pt0.x; ri = i; }
+        if (ti < 0 || pt0.y > ty) { ty = pt0.y; ti = i; }
+        if (bi < 0 || pt0.y < by) { by = pt0.y; bi = i; }
+        const F2 pt = points[(i + 1) < n ? (i + 1) : 0];
+        const double dx = pt.x - pt0.x, dy = pt.y - pt0.y;
+        vect[i].x = (float)dx; vect[i].y = (float)dy;
+        inv_len[i] = (float)(1. / sqrt(dx * dx + dy * dy));
+    }
+    int left, right, top, bottom;
+    wave_first_extreme(lx, li, false, &left);
+    wave_first_extreme(rx, ri, true, &right);
+    wave_first_extreme(ty, ti, true, &top);
+    wave_first_extreme(by, bi, false, &bottom);
+    __syncthreads();
+    // orientation: sign of the first non-zero turn (edge i-1 -> edge i), scanning i = 0 .. n-1
+    float orientation = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        double convexity = 0;
+        if (i < n) {
+            const F2 a = vect[i ? i - 1 : n - 1], b = vect[i];
+            convexity = (double)a.x * (double)b.y - (double)a.y * (double)b.x;
+        }
+        const unsigned long long nz = __ballot(convexity != 0);
+        if (nz) {
+            const int src = __ffsll((long long)nz) - 1;
+            orientation = __shfl(convexity > 0 ? 1.f : -1.f, src);
+            break;
+        }
+    }
+    if (lane != 0) return;
+    float minarea = 3.402823466e+38f;
+    float base_a = orientation, base_b = 0;
+    int buf_left = 0, buf_bottom = 0;
+    float buf_a = 0, buf_w = 0, buf_b = 0, buf_h = 0;
+    seq[0] = bottom; seq[1] = right; seq[2] = top; seq[3] = left;
+    for (int k = 0; k < n; k++) {
+        const int s0 = seq[0], s1 = seq[1], s2 = seq[2], s3 = seq[3];
+        const F2 v0 = vect[s0], v1 = vect[s1], v2 = vect[s2], v3 = vect[s3];
+        const float l0 = inv_len[s0], l1 = inv_len[s1], l2 = inv_len[s2], l3 = inv_len[s3];
+        float dp[4];
+        dp[0] = +base_a * v0.x + base_b * v0.y;
+        dp[1] = -base_b * v1.x + base_a * v1.y;
+        dp[2] = -base_a * v2.x - base_b * v2.y;
+        dp[3] = +base_b * v3.x - base_a * v3.y;
+        float maxcos = dp[0] * l0;
+        int main_element = 0;
+        { const float c = dp[1] * l1; if (c > maxcos) { main_element = 1; maxcos = c; } }
+        { const float c = dp[2] * l2; if (c > maxcos) { main_element = 2; maxcos = c; } }
+        { const float c = dp[3] * l3; if (c > maxcos) { main_element = 3; maxcos = c; } }
+        {
+            const F2 vm = main_element == 0 ? v0 : main_element == 1 ? v1 : main_element == 2 ? v2 : v3;
+            const float lm = main_element == 0 ? l0 : main_element == 1 ? l1 : main_element == 2 ? l2 : l3;
+            const float lead_x = vm.x * lm;
+            const float lead_y = vm.y * lm;
+            switch (main_element) {
+            case 0: base_a = lead_x; base_b = lead_y; break;
+            case 1: base_a = lead_y; base_b = -lead_x; break;
+            case 2: base_a = -lead_x; base_b = -lead_y; break;
+            default: base_a = -lead_y; base_b = lead_x; break;
+            }
+        }
+        {
+            int sm = seq[main_element] + 1;
+            sm = (sm == n) ? 0 : sm;
+            seq[main_element] = sm;
+        }
+        {
+            const F2 p0 = points[seq[0]], p1 = points[seq[1]], p2 = points[seq[2]], p3 = points[seq[3]];
+            float dx = p1.x - p3.x;
+            float dy = p1.y - p3.y;
+            const float width = dx * base_a + dy * base_b;
+            dx = p2.x - p0.x;
+            dy = p2.y - p0.y;
+            const float height = -dx * base_b + dy * base_a;
+            const float area = width * height;
+            if (area <= minarea) {
+                minarea = area;
+                buf_left = seq[3]; buf_a = base_a; buf_w = width; buf_b = base_b; buf_h = height; buf_bottom = seq[0];
+            }
+        }
+    }
+    const float A1 = buf_a, B1 = buf_b, A2 = -buf_b, B2 = buf_a;
+    const float C1 = A1 * points[buf_left].x + points[buf_left].y * B1;
+    const float C2 = A2 * points[buf_bottom].x + points[buf_bottom].y * B2;
+    const float idet = 1.f / (A1 * B2 - A2 * B1);
+    out[0] = (C1 * B2 - C2 * B1) * idet;
+    out[1] = (A1 * C2 - A2 * C1) * idet;
+    out[2] = A1 * buf_w; out[3] = B1 * buf_w;
+    out[4] = A2 * buf_h; out[5] = B2 * buf_h;
+}
+
+// minAreaRect on an already x-sorted point list, wave-cooperative; the result is valid on lane 0.  sh_hn: one LDS int.
+__device__ RRect min_area_rect_wave(const F2 *sorted, int n, F2 *hull, int *stack, float *scratch, int *sh_hn) {
+    RRect box; box.cx = box.cy = box.w = box.h = box.angle = 0.f;
+    if (n <= 0) return box;                                     // uniform
+    if (threadIdx.x == 0) *sh_hn = convex_hull_sorted(sorted, n, hull, stack);
+    __syncthreads();
+    const int hn = *sh_hn;
+    if (hn > 2) {
+        float out[6] = {0, 0, 0, 0, 0, 0};
+        rotating_calipers_wave(hull, hn, scratch, out);
+        box.cx = out[0] + (out[2] + out[4]) * 0.5f;
+        box.cy = out[1] + (out[3] + out[5]) * 0.5f;
+        box.w = (float)sqrt((double)out[2] * out[2] + (double)out[3] * out[3]);
+        box.h = (float)sqrt((double)out[4] * out[4] + (double)out[5] * out[5]);
+        box.angle = (float)atan2((double)out[3], (double)out[2]);
+    } else if (hn == 2) {
+        box.cx = (hull[0].x + hull[1].x) * 0.5f;
+        box.cy = (hull[0].y + hull[1].y) * 0.5f;
+        const double dx = hull[1].x - hull[0].x, dy = hull[1].y - hull[0].y;
+        box.w = (float)sqrt(dx * dx + dy * dy);
+        box.h = 0;
+        box.angle = (float)atan2(dy, dx);
+    } else if (hn == 1) {
+        box.cx = hull[0].x; box.cy = hull[0].y;
+    }
+    box.angle = (float)(box.angle * 180 / PT_PI);
+    return box;
+}
+
 __device__ void box_points(const RRect &r, F2 pt[4]) {
     const double ang = r.angle * PT_PI / 180.;
     const float b = (float)cos(ang) * 0.5f;
@@ -903,7 +1103,7 @@ constexpr int MAXW = 2048;                // widest map the column tables hold
 constexpr int LDS_PLANE_WORDS = 4096;     // full-size pass: mask planes up to 131072 pixels live in LDS; larger ones in a global slot
 constexpr int MAXHULL = 512;              // full-size pass: strict hull vertices of a lattice polygon inside 2048 x 32767 stay far below
 constexpr int NSLOTS = 256;               // global mask slots (two full-image bit planes each)
-constexpr int S_MW = 512, S_PLANE = 1984, S_MH = 96;      // small-footprint stages: border width, mask plane words, hull / offset points
+constexpr int S_MW = 1024, S_PLANE = 1984, S_MH = 96;      // small-footprint stages: border width, mask plane words, hull / offset points
 
 __device__ __forceinline__ long long cross3(int ax, int ay, int bx, int by, int px, int py) {
     return (long long)(bx - ax) * (py - ay) - (long long)(by - ay) * (px - ax);
@@ -1097,12 +1297,14 @@ __device__ int hull_candidates(const unsigned *st, int n, int xmin, int bw, unsi
 }
 
 // ---- stage B (one lane): min-area rectangle of the border, mini-box, first size filter (db_postprocess.cpp:259-265)
-__device__ int rect_stage(const F2 *cand, int n, F2 *hull, int *stack, float *scratch, Result *res, float (*mini)[2]) {
-    const RRect box = min_area_rect_sorted(cand, n, hull, stack, scratch);
+__device__ int rect_finish(const RRect &box, Result *res, float (*mini)[2]) {
     float ssid;
     get_mini_boxes(box, mini, &ssid);
     res->rect[0] = box.cx; res->rect[1] = box.cy; res->rect[2] = box.w; res->rect[3] = box.h; res->rect[4] = box.angle;
     return ssid < 3 ? ST_SKIP_SSID : ST_PEND_SCORE;             // min_size, db_postprocess.cpp:265
+}
+__device__ int rect_stage(const F2 *cand, int n, F2 *hull, int *stack, float *scratch, Result *res, float (*mini)[2]) {
+    return rect_finish(min_area_rect_sorted(cand, n, hull, stack, scratch), res, mini);
 }
 
 // ---- stage D, first half (one lane): UnClip's distance and Clipper's round offset of the truncated mini-box
@@ -1126,11 +1328,7 @@ __device__ int unclip_offset(const float (*mini)[2], float unclip_ratio, F2 *pts
 
 // ---- stage D, second half (one lane): minAreaRect of the offset polygon (pts sorted by (x, y)), the two filters and the final
 // box (db_postprocess.cpp:57-64, 276-311)
-__device__ int unclip_finish(const F2 *pts, int np, F2 *hull, int *stack, float *scratch, Result *res, int src_w, int src_h,
-                             int use_padding_resize, const DbpostDims &d) {
-    RRect ub;
-    if (np <= 0) { ub.cx = 0; ub.cy = 0; ub.w = 1; ub.h = 1; ub.angle = 0; }
-    else ub = min_area_rect_sorted(pts, np, hull, stack, scratch);
+__device__ int unclip_box(const RRect &ub, Result *res, int src_w, int src_h, int use_padding_resize, const DbpostDims &d) {
     if (ub.h < 1.001 && ub.w < 1.001) return ST_SKIP_UNCLIP;
     float clip[4][2], ssid;
     get_mini_boxes(ub, clip, &ssid);
@@ -1156,6 +1354,14 @@ __device__ int unclip_finish(const F2 *pts, int np, F2 *hull, int *stack, float 
     return ST_OK;
 }
 
+__device__ int unclip_finish(const F2 *pts, int np, F2 *hull, int *stack, float *scratch, Result *res, int src_w, int src_h,
+                             int use_padding_resize, const DbpostDims &d) {
+    RRect ub;
+    if (np <= 0) { ub.cx = 0; ub.cy = 0; ub.w = 1; ub.h = 1; ub.angle = 0; }
+    else ub = min_area_rect_sorted(pts, np, hull, stack, scratch);
+    return unclip_box(ub, res, src_w, src_h, use_padding_resize, d);
+}
+
 // both halves on one lane (full-size pass); ST_DEFER when the offset polygon has more than cap points
 __device__ int unclip_stage(const float (*mini)[2], float unclip_ratio, F2 *pts, int cap, F2 *hull, int *stack, float *scratch,
                             Result *res, int *flag_word, int src_w, int src_h, int use_padding_resize, const DbpostDims &d, long long *ws) {
@@ -1176,7 +1382,7 @@ struct StageArgs {
     float box_thresh, unclip_ratio; long slot_words; int use_padding_resize;
 };
 
-// ---- stage A kernel: one workgroup per border (6 KB of LDS: fits beside a Winograd workgroup of the next batch's forward)
+// ---- stage A kernel: one workgroup per border (12 KB of LDS: fits beside a Winograd workgroup of the next batch's forward)
 __global__ __launch_bounds__(CT_THREADS, 6) void hull_kernel(StageArgs a, DbpostDims d) {
     const int img = blockIdx.y, k = blockIdx.x;
     if (k >= min(a.totals[img], MAX_CAND)) return;
@@ -1216,8 +1422,10 @@ __global__ __launch_bounds__(64) void rect_kernel(StageArgs a, DbpostDims d) {
     __shared__ float scratch[3 * S_MH + 4];
     const int n = a.hn[bi];
     for (int i = threadIdx.x; i < n; i += 64) cand[i] = a.hin[bi * S_MH + i];
+    __shared__ int sh_hn;
     __syncthreads();
-    if (threadIdx.x == 0) res->status = rect_stage(cand, n, hull, stack, scratch, res, reinterpret_cast<float (*)[2]>(a.mini + bi * 8));
+    const RRect box = min_area_rect_wave(cand, n, hull, stack, scratch, &sh_hn);
+    if (threadIdx.x == 0) res->status = rect_finish(box, res, reinterpret_cast<float (*)[2]>(a.mini + bi * 8));
 }
 
 // ---- stage C kernel: BoxScore (db_postprocess.cpp:194-229), one workgroup per border (15.6 KB of LDS: mask planes up to 63 488 px)
@@ -1231,19 +1439,35 @@ __global__ __launch_bounds__(CT_THREADS, 6) void score_kernel(StageArgs a, Dbpos
     const Acc ac = a.acc[bi];
     const int bw = ac.xmax - ac.xmin + 1, bh = ac.ymax - ac.ymin + 1;
     const long plane_words = (long)((bw + 31) >> 5) * bh;
-    if (plane_words > S_PLANE) { if (tid == 0) { res->status = ST_DEFER; atomicOr(&a.flags[img], 8); } return; }
     __shared__ __attribute__((aligned(16))) unsigned planes[2 * S_PLANE];
     __shared__ double red_d[CT_THREADS / 64];
     __shared__ int red_i[CT_THREADS / 64];
     const float *pimg = a.maps + (long)img * d.HW;
+    const unsigned *st = a.pool + (long)img * d.pool_cap + ac.off;
     double total; int npix;
-    score_mask<false>(a.pool + (long)img * d.pool_cap + ac.off, ac.nstates, ac.xmin, ac.ymin, bw, bh, planes, planes + S_PLANE, pimg, d.W,
-                      red_d, red_i, &total, &npix);
-    float score = (float)(npix ? total / npix : 0.0);
-    if (fabs((double)score - (double)a.box_thresh) <= 1e-6) {
-        if (tid == 0) { red_d[0] = score_mask_raster_order<false>(planes, ac.xmin, ac.ymin, bw, bh, pimg, d.W); atomicOr(&a.flags[img], 2); }
+    float score;
+    if (plane_words <= S_PLANE) {
+        score_mask<false>(st, ac.nstates, ac.xmin, ac.ymin, bw, bh, planes, planes + S_PLANE, pimg, d.W, red_d, red_i, &total, &npix);
+        score = (float)(npix ? total / npix : 0.0);
+        if (fabs((double)score - (double)a.box_thresh) <= 1e-6) {
+            if (tid == 0) { red_d[0] = score_mask_raster_order<false>(planes, ac.xmin, ac.ymin, bw, bh, pimg, d.W); atomicOr(&a.flags[img], 2); }
+            __syncthreads();
+            score = (float)(npix ? red_d[0] / npix : 0.0);
+        }
+    } else {                                                    // a mask too large for the LDS planes: one of the global slots
+        const int slot = (int)(bi % NSLOTS);
+        unsigned *border = a.gslots + (long)slot * 2 * a.slot_words, *toggle = border + a.slot_words;
+        if (tid == 0) { while (atomicCAS(&a.slot_locks[slot], 0, 1) != 0) __builtin_amdgcn_s_sleep(32); __threadfence(); }
         __syncthreads();
-        score = (float)(npix ? red_d[0] / npix : 0.0);
+        score_mask<true>(st, ac.nstates, ac.xmin, ac.ymin, bw, bh, border, toggle, pimg, d.W, red_d, red_i, &total, &npix);
+        score = (float)(npix ? total / npix : 0.0);
+        if (fabs((double)score - (double)a.box_thresh) <= 1e-6) {
+            if (tid == 0) { red_d[0] = score_mask_raster_order<true>(border, ac.xmin, ac.ymin, bw, bh, pimg, d.W); atomicOr(&a.flags[img], 2); }
+            __syncthreads();
+            score = (float)(npix ? red_d[0] / npix : 0.0);
+        }
+        __syncthreads();
+        if (tid == 0) { __threadfence(); atomicExch(&a.slot_locks[slot], 0); }
     }
     if (tid == 0) {
         res->score = score; res->npix = npix;
@@ -1279,13 +1503,16 @@ __global__ __launch_bounds__(64, 5) void unclip_kernel(StageArgs a, DbpostDims d
         }
         pts[rank] = t;
     }
+    __shared__ int sh_hn;
     __syncthreads();
-    if (threadIdx.x == 0)
-        res->status = unclip_finish(pts, np, hull, stack, scratch, res, a.src_wh[2 * img], a.src_wh[2 * img + 1], a.use_padding_resize, d);
+    RRect ub;
+    if (np <= 0) { ub.cx = 0; ub.cy = 0; ub.w = 1; ub.h = 1; ub.angle = 0; }
+    else ub = min_area_rect_wave(pts, np, hull, stack, scratch, &sh_hn);
+    if (threadIdx.x == 0) res->status = unclip_box(ub, res, a.src_wh[2 * img], a.src_wh[2 * img + 1], a.use_padding_resize, d);
 }
 
 // ---- full-size pass: a few workgroups per image walk the borders the small-footprint stages deferred (borders wider than
-// 512 px, masks beyond 30720 px, more than 96 hull / offset points: usually none) through all four stages, serial parts on lane 0
+// 1024 px, more than 96 hull / offset points: usually none) through all four stages, serial parts on lane 0
 __global__ __launch_bounds__(CT_THREADS, 1) void contour_big_kernel(StageArgs a, DbpostDims d) {
     const int img = blockIdx.y;
     if (!(a.flags[img] & 8)) return;                      // internal bit 3: a small stage deferred at least one border of this image
@@ -1543,7 +1770,7 @@ extern "C" int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, co
         hipLaunchKernelGGL(chunk_suffix_kernel, dim3(N), dim3(1024), 0, s, h->chunk_cnt, h->totals, d, ps, h->strip_totals);
     }
     hipLaunchKernelGGL(select_starts_kernel, dim3(d.nchunks, N), dim3(256), 0, s, bits, h->labels, h->chunk_cnt, h->totals, h->cands, h->acc, d);
-    const dim3 all_words(cdiv(H * d.WW, 256), N);
+    const dim3 all_words(cdiv(cdiv(H, 8) * cdiv(d.WW, 8), 4), N);      // 8 x 8-word tiles, four per block
     hipLaunchKernelGGL(border_states_kernel<false>, all_words, dim3(256), 0, s, bits, h->labels, h->word_lab, h->strip_totals, h->acc, h->pool,
                        h->flags, d);
     hipLaunchKernelGGL(pool_offsets_kernel, dim3(N), dim3(1024), 0, s, h->acc, h->totals, h->flags, d);
