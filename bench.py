@@ -239,6 +239,9 @@ def run_det(args, rank, local, world, device):
     B, H, W = args.batch or 32, 736, 1280
     det_cfg, det_contract, gflop_img = DET_VARIANTS[args.det_model]
     model = build_and_sync_weights(det_cfg, det_contract, device, rank, world)
+    bf16 = args.dtype == "bf16"
+    if bf16:
+        model.set_compute_dtype("bf16")                  # BASELINE configs[3]: bf16 activations / weights, fp32 accumulation and maps
     post = build_post_process(DET_POST, dict(use_gpu=True, seed=2022))
     nd = min(args.distinct_images, B)
     base = synth_images(nd, 3, H, W, seed=2022 + rank)               # nd distinct seeded images, tiled to the batch
@@ -256,6 +259,10 @@ def run_det(args, rank, local, world, device):
         ev.record()
         with torch.no_grad():
             out = model(x)
+        if fwd_events is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            fwd_events.append((ev, e1))
         futs = []
         if "model" in tags:                              # the pipeline's own data flow
             futs.append(post.submit({"maps": out["maps"]}, shape_list))
@@ -265,6 +272,7 @@ def run_det(args, rank, local, world, device):
             return [], [f.result() for f in futs], ev
         return futs, [f.result() for f in pending], ev
 
+    fwd_events = None
     pending = []
     for _ in range(args.warmup):
         pending, _, _ = step(pending)
@@ -272,6 +280,15 @@ def run_det(args, rank, local, world, device):
         f.result()
     pending = []
     _sync_all(world)
+    fwd_bytes = None
+    if bf16 and rank == 0:                               # bytes one forward moves, counted by the launch wrappers (one untimed pass)
+        from pytorchocr_amd.modeling import bf16_path
+        bf16_path.TRAFFIC = 0
+        with torch.no_grad():
+            model(x)
+        fwd_bytes, bf16_path.TRAFFIC = bf16_path.TRAFFIC, None
+        torch.cuda.synchronize()
+        fwd_events = []
     ops.PROFILE = [] if rank == 0 else None
     ops.PROFILE_LABELS = [] if rank == 0 else None
     post.device_ms_log = []
@@ -329,19 +346,32 @@ def run_det(args, rank, local, world, device):
             "ms_per_call_overlapped": {t: round(median(v), 4) for t, v in by_tag.items()},
             "per_kernel": (_profile_json("post_traffic.json") or {}).get("per_kernel"),
         }
-    cpu = det_cpu_baseline(args.cpu_images, H, W) if world == 1 and args.cpu_images > 0 else None
-    roof = _wino_roofline(wino_ms, wino_flops, n_wino, args.steps, "every 3x3/s1 layer")
-    roof["all_conv"] = {"launches_per_step": n_launch // max(args.steps, 1), "ms_per_step": round(conv_ms / max(args.steps, 1), 3),
-                        "algorithmic_tflops": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2) if conv_ms > 0 else 0.0,
-                        "kernels": "conv_wino_kernel (3x3 s1) + stem_conv_kernel (7x7 s2) + conv_pw64_kernel (FPN in2) + conv_mfma_v2_kernel (3x3 s2, other 1x1)"}
+    cpu = det_cpu_baseline(args.cpu_images, H, W) if world == 1 and args.cpu_images > 0 and not bf16 else None
+    if bf16:
+        fms = median([a.elapsed_time(b) for a, b in fwd_events])
+        gbps = fwd_bytes / (fms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
+                "traffic": (_profile_json("mbv3s_bf16_traffic.json") or {}).get("hbm_bytes_per_forward"),
+                "kernel": "whole bf16 forward (47 launches: stem, 1x1 MFMA convs, depthwise + SE pool, SE gate, 3x3 MFMA convs, head tail): "
+                          "bytes every launch reads + writes once (activations, weights; %.1f MB per forward of %d images) / median forward time "
+                          "%.3f ms (HIP events on the launch stream, post-process of the previous batch overlapping)" % (fwd_bytes / 1e6, B, fms),
+                "mfma_tflops": round(gflop_img * 1e9 * B / (fms * 1e-3) / 1e12, 2),
+                "mfma_frac_of_bf16_peak": round(gflop_img * 1e9 * B / (fms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}
+    else:
+        roof = _wino_roofline(wino_ms, wino_flops, n_wino, args.steps, "every 3x3/s1 layer")
+    if not bf16:
+        roof["all_conv"] = {"launches_per_step": n_launch // max(args.steps, 1), "ms_per_step": round(conv_ms / max(args.steps, 1), 3),
+                            "algorithmic_tflops": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2) if conv_ms > 0 else 0.0,
+                            "kernels": "conv_wino_kernel (3x3 s1) + stem_conv_kernel (7x7 s2) + conv_pw64_kernel (FPN in2) + conv_mfma_v2_kernel (3x3 s2, other 1x1)"}
     return {
         "metric": "images/sec end-to-end (DBNet-r18 det+post, 736x1280)" if args.det_model == "r18"
                   else "images/sec end-to-end (%s det+post, 736x1280; NOT the BASELINE metric)" % args.det_model,
         "value": round(world * B * args.steps / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "ms_per_step_median": round(median(step_ms), 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "DBNet %s fp32, batch %d synthetic 736x1280 per GPU (%d distinct images tiled), HIP conv + HIP DBPostProcess "
-                               "(BASELINE.json configs[1])" % (args.det_model, B, nd),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+        "config": {"workload": "DBNet %s %s, batch %d synthetic 736x1280 per GPU (%d distinct images tiled), HIP conv + HIP DBPostProcess "
+                               "(BASELINE.json %s)" % (args.det_model, "bf16" if bf16 else "fp32", B, nd,
+                                                       "configs[3]: batch 256 = 32 per GPU x 8" if bf16 else "configs[1]"),
                    "global_batch": world * B, "post_input": args.post_input, "post_overlap": bool(args.overlap),
                    "boxes_per_image": {t: round(v / (B * args.steps), 1) for t, v in nbox.items()},
                    "parallelism": "image-sharded x%d, RCCL weight broadcast only" % world},
@@ -467,6 +497,8 @@ def main():
     ap.add_argument("--det-model", default="r18", choices=sorted(DET_VARIANTS),
                     help="r18 = BASELINE configs[1] (the metric); r18pp (DB++ / ASF) and mbv3s (MobileNetV3-small) are the "
                          "other detectors of the hot path")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="bf16 = BASELINE configs[3] (with --det-model mbv3s): bf16 activations and weights, fp32 accumulation, fp32 maps")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false",
                     help="run the post-process synchronously after each forward instead of overlapping it with the next batch")
     ap.add_argument("--cpu-images", type=int, default=8, help="images in the CPU-baseline sample (0 = skip)")
@@ -499,6 +531,8 @@ def main():
             dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
         else:
             dist.init_process_group(backend=backend, init_method="env://")
+    if args.dtype == "bf16" and (args.workload != "det" or args.det_model != "mbv3s"):
+        raise SystemExit("bench.py: --dtype bf16 is BASELINE configs[3], i.e. --workload det --det-model mbv3s")
     args.crnn_batch = (args.batch or 512) if args.workload == "crnn" else 512
     if args.workload == "det":
         line = run_det(args, rank, local, world, device)

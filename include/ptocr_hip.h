@@ -136,6 +136,35 @@ int ptocr_asf_scale_channel_spatial_f32(const float *d_y, float *d_fuse, const f
                                         int N, int H, int W, void *stream);
 long ptocr_asf_work_floats(int N, int H, int W);
 
+/* ---- bf16 inference path of the MobileNetV3 detector (BASELINE configs[3]) ---------------------------------------------
+ * Activations are bf16 NHWC with the channel count padded to a multiple of 16 (padding channels hold zeros); weights bf16,
+ * K-contiguous rows, BatchNorm folded; accumulation, bias, activation and every non-GEMM kernel in fp32.  Same reference
+ * layers as the fp32 entry points above (det_mobilenet_v3.py:38-151, fpn.py:102-134, det_db_head.py:9-17).  `void *` = bf16. */
+/* 1x1 conv: y[.., coff:coff+cstore] = act(x @ w^T + bias (+ res)) ; w bf16[Cout_pad][Cin] (Cout_pad % 32 == 0, zero rows beyond the
+ * layer's channels), d_scale (optional) f32[N][Cin]: Squeeze-Excitation gate multiplied into the INPUT; res_mode 1: + d_res
+ * (same geometry, channel stride res_ldc) before the activation; 2: + d_res[N,H/2,W/2] nearest-upsampled x2 after it (fpn.py:133). */
+int ptocr_pwconv_bf16(const void *d_x, const void *d_w, const float *d_bias, const void *d_res, const float *d_scale, void *d_y,
+                      int N, int H, int W, int Cin, int Cout_pad, int cstore, int act, int res_mode, int res_ldc, int out_ldc,
+                      int out_coff, void *stream);
+/* 3x3 / s1 / p1 conv with <= 32 outputs: w bf16[32][9 * Cin] (k = (ky*3 + kx) * Cin + ci); the result is stored to an out_up x
+ * out_up block per pixel (nearest upsample) into channels [coff, coff + cstore) of a tensor with channel stride out_ldc. */
+int ptocr_conv3x3_bf16(const void *d_x, const void *d_w, const float *d_bias, void *d_y, int N, int H, int W, int Cin, int cstore,
+                       int act, int out_up, int out_ldc, int out_coff, void *stream);
+/* depthwise k x k conv + bias + activation; d_partial (optional) f32[N][nblk][C], nblk = ptocr_dwconv_bf16_nblk(...): per-chunk
+ * channel sums of the activated output for the Squeeze-Excitation pool (fixed summation order: deterministic). */
+int ptocr_dwconv_bf16(const void *d_x, const float *d_w, const float *d_bias, void *d_y, float *d_partial, int N, int H, int W,
+                      int C, int k, int stride, int act, void *stream);
+int ptocr_dwconv_bf16_nblk(int N, int H, int W, int k, int stride);
+/* SE gate from those sums: d_scale f32[N][C] = hardsigmoid(fc2(relu(fc1(sum / HW)))) (det_mobilenet_v3.py:76-85) */
+int ptocr_se_fc_f32(const float *d_partial, const float *d_w1, const float *d_b1, const float *d_w2, const float *d_b2,
+                    float *d_scale, int N, int HW, int C, int S, int nblk, void *stream);
+/* stem: conv 3x3 / s2 / p1 of the model input f32[N,3,H,W] -> bf16[N,Ho,Wo,16]; d_w f32[27][16] (row (c*3 + ky)*3 + kx), BN folded */
+int ptocr_stem3x3s2_bf16(const float *d_x, const float *d_w, const float *d_bias, void *d_y, int N, int H, int W, int act, void *stream);
+/* DB head tail for C = 24: ConvT(C,C,2,2)+BN+ReLU -> ConvT(C,1,2,2)+bias -> sigmoid; d_x bf16[N,H,W,ldc] -> d_maps f32[N,4H,4W];
+ * d_w1 f32[4][C][C] ((a*2+b), ci, co), d_b1 f32[C], d_w2 f32[4][C] ((a*2+b), co). */
+int ptocr_db_head_tail_bf16(const void *d_x, const float *d_w1, const float *d_b1, const float *d_w2, float b2, float *d_maps,
+                            int N, int H, int W, int C, int ldc, void *stream);
+
 /* ---- DB post-process ------------------------------------------------------------------------------------ */
 typedef struct ptocr_dbpost *ptocr_dbpost_t;
 

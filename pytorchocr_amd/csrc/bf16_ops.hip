@@ -1,0 +1,466 @@
+// bf16 inference path of the MobileNetV3 detector (BASELINE.json configs[3]: DBNet mbv3-small x1.0, bf16): NHWC bf16 activations in
+// HBM, v_mfma_f32_32x32x16_bf16 with fp32 accumulation for every 1x1 / 3x3 GEMM-shaped layer, fp32 arithmetic in the depthwise /
+// squeeze-excitation / head-tail kernels, fp32 probability maps out.
+//
+// Replaces (same layers as the fp32 kernels, reference file:line): ConvBNActivation / InvertedResidual / SqueezeExcitation of
+// pytocr/modeling/backbones/det_mobilenet_v3.py:38-151,154-279, FPN of necks/fpn.py:102-134, DBHead of heads/det_db_head.py:9-17,47-50.
+//
+// Why it looks unlike the fp32 conv kernels: this network is HBM-bound (8.4 GFLOP per 736x1280 image against ~60 MB of activations),
+// bf16 MFMA is 16x the fp32 rate, so nothing is staged through LDS -- both MFMA operands are read from global memory in their fragment
+// layout (a lane's 8 consecutive k values are 16 contiguous bytes of an NHWC pixel or of a K-contiguous weight row), weights stay in
+// L2/L1, every activation is read once and written once, and what a layer's neighbours can do on the way (BN, activation, residual,
+// SE scale on the input, SE pooling on the output, nearest upsample + concat, FPN top-down add) is fused into it.
+//
+// MFMA roles: A = weights (row = output channel), B = pixels (column = pixel).  The accumulator of lane (pixel = lane & 31,
+// half = lane >> 5) then holds, per register quad g, four CONSECUTIVE output channels 8g + 4*half + {0..3} of its pixel: one packed
+// 8-byte bf16 store per quad, no shuffle, no LDS.
+#include "common.h"
+#include <cstdlib>
+
+namespace ptocr {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float actf(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.f);
+    if (act == 2) return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);       // Hardswish
+    return v;
+}
+
+__device__ __forceinline__ bf16x8 zero8() { bf16x8 z; for (int j = 0; j < 8; j++) z[j] = (__bf16)0.f; return z; }
+
+// ---------------------------------------------------------------------------------------------- 1x1 convolution
+struct PwArgs {
+    const __bf16 *x, *w, *res;
+    const float *bias, *scale;      // scale: SE gate f32[N][Cin] applied to the INPUT (x * scale, rounded to bf16 once), or null
+    __bf16 *y;
+    long M;                         // pixels
+    int Cin;                        // padded input channels (multiple of 16) == channel stride of x
+    int ntile;                      // 32-wide output channel tiles (weights are zero-padded to ntile * 32 rows)
+    int cstore;                     // channels written (multiple of 4)
+    int act, res_mode;              // res_mode 0 none / 1 add before the activation (same shape) / 2 nearest-x2 upsampled add after it
+    int H, W;                       // output geometry (res_mode 2, and the image index of a pixel: n = m / (H * W))
+    int out_ldc, out_coff, res_ldc;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void pw_bf16_kernel(PwArgs p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const long m = ((long)blockIdx.x * 4 + wave) * 32 + r;
+    const long mc = m < p.M ? m : p.M - 1;
+    const int t0 = blockIdx.y * NT;
+    const __bf16 *xrow = p.x + mc * p.Cin + 8 * h;
+    const long HW = (long)p.H * p.W;
+    const float *srow = p.scale ? p.scale + (mc / HW) * p.Cin + 8 * h : nullptr;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
+    const __bf16 *wrow = p.w + ((long)t0 * 32 + r) * p.Cin + 8 * h;
+    const int nks = p.Cin >> 4;
+    for (int ks = 0; ks < nks; ks++) {
+        bf16x8 b = *reinterpret_cast<const bf16x8 *>(xrow + ks * 16);
+        if (srow) {
+            const f32x4 s0 = *reinterpret_cast<const f32x4 *>(srow + ks * 16), s1 = *reinterpret_cast<const f32x4 *>(srow + ks * 16 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; j++) { b[j] = (__bf16)((float)b[j] * s0[j]); b[4 + j] = (__bf16)((float)b[4 + j] * s1[j]); }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            if (t0 + t < p.ntile) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(wrow + (long)t * 32 * p.Cin + ks * 16);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    if (m >= p.M) return;
+    int n = 0, oy = 0, ox = 0;
+    if (p.res_mode == 2) { n = (int)(m / HW); const int rem = (int)(m - (long)n * HW); oy = rem / p.W; ox = rem - oy * p.W; }
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        if (t0 + t >= p.ntile) continue;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int c = (t0 + t) * 32 + 8 * g + 4 * h;
+            if (c >= p.cstore) continue;
+            const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + c);
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = acc[t][4 * g + j] + bias[j];
+            if (p.res_mode == 1) {
+                const bf16x4 rr = *reinterpret_cast<const bf16x4 *>(p.res + m * p.res_ldc + c);
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[j] += (float)rr[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = actf(v[j], p.act);
+            if (p.res_mode == 2) {
+                const bf16x4 rr = *reinterpret_cast<const bf16x4 *>(p.res + (((long)n * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) * p.res_ldc + c);
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[j] += (float)rr[j];
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; j++) o[j] = (__bf16)v[j];
+            *reinterpret_cast<bf16x4 *>(p.y + m * p.out_ldc + p.out_coff + c) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- 3x3 / stride 1 / pad 1 convolution
+// (the FPN smoothing convs and the head's first conv: Cin = 96 -> Cout <= 32).  Implicit GEMM over K = 9 * Cin, one 32-channel
+// output tile per wave; the nine taps of a pixel are nine 16-byte-piece reads of neighbouring NHWC pixels (L1 / L2 serve the re-use).
+struct C3Args {
+    const __bf16 *x, *w;
+    const float *bias;
+    __bf16 *y;
+    long M;
+    int H, W, Cin, cstore, act, out_up, out_ldc, out_coff;
+};
+
+__global__ __launch_bounds__(256) void conv3x3_bf16_kernel(C3Args p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const long m = ((long)blockIdx.x * 4 + wave) * 32 + r;
+    const long mc = m < p.M ? m : p.M - 1;
+    const long HW = (long)p.H * p.W;
+    const int n = (int)(mc / HW);
+    const int rem = (int)(mc - (long)n * HW);
+    const int oy = rem / p.W, ox = rem - oy * p.W;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.f;
+    const int ncs = p.Cin >> 4;
+    const __bf16 *wrow = p.w + (long)r * 9 * p.Cin + 8 * h;
+    for (int tap = 0; tap < 9; tap++) {
+        const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+        const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const __bf16 *src = p.x + (((long)n * p.H + (ok ? iy : oy)) * p.W + (ok ? ix : ox)) * p.Cin + 8 * h;
+        for (int cs = 0; cs < ncs; cs++) {
+            bf16x8 b = *reinterpret_cast<const bf16x8 *>(src + cs * 16);
+            if (!ok) b = zero8();
+            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(wrow + tap * p.Cin + cs * 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        }
+    }
+    if (m >= p.M) return;
+    const int U = p.out_up;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int c = 8 * g + 4 * h;
+        if (c >= p.cstore) continue;
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + c);
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; j++) o[j] = (__bf16)actf(acc[4 * g + j] + bias[j], p.act);
+        for (int uy = 0; uy < U; uy++)
+            for (int ux = 0; ux < U; ux++)
+                *reinterpret_cast<bf16x4 *>(p.y + (((long)n * p.H * U + oy * U + uy) * ((long)p.W * U) + ox * U + ux) * p.out_ldc + p.out_coff + c) = o;
+    }
+}
+
+// The same layer with the input staged through LDS: a workgroup owns a tile of 8 rows x 32 columns of output pixels, loads the
+// 10 x 34 halo patch once (every input byte leaves HBM / L2 once, 1.33x with the halo, instead of nine times through a thrashing
+// L1), and its four waves (two output rows each) read their B fragments from LDS.  Pixel stride in LDS = 2 Cin + 16 bytes: the 16
+// lanes of a ds_read_b128 group then fall on 16 different 16-byte bank slots (13 r mod 16 is a permutation).
+constexpr int C3_TH = 8, C3_TW = 32, C3_MAXCIN = 96;
+__global__ __launch_bounds__(256) void conv3x3_bf16_lds_kernel(C3Args p) {
+    __shared__ __attribute__((aligned(16))) unsigned char patch[(C3_TH + 2) * (C3_TW + 2) * (2 * C3_MAXCIN + 16)];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int tiles_x = cdiv(p.W, C3_TW);
+    const int n = blockIdx.y;
+    const int ty0 = (blockIdx.x / tiles_x) * C3_TH, tx0 = (blockIdx.x % tiles_x) * C3_TW;
+    const int stride = 2 * p.Cin + 16, nch = p.Cin >> 3;
+    const __bf16 *ximg = p.x + (long)n * p.H * p.W * p.Cin;
+    for (int i = threadIdx.x; i < (C3_TH + 2) * (C3_TW + 2) * nch; i += 256) {
+        const int pix = i / nch, ch = i - pix * nch;
+        const int iy = ty0 - 1 + pix / (C3_TW + 2), ix = tx0 - 1 + pix % (C3_TW + 2);
+        bf16x8 v = zero8();
+        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v = *reinterpret_cast<const bf16x8 *>(ximg + ((long)iy * p.W + ix) * p.Cin + ch * 8);
+        *reinterpret_cast<bf16x8 *>(patch + pix * stride + ch * 16) = v;
+    }
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[j][i] = 0.f;
+    const int ncs = p.Cin >> 4;
+    const __bf16 *wrow = p.w + (long)r * 9 * p.Cin + 8 * h;
+    for (int tap = 0; tap < 9; tap++) {
+        const int dy = tap / 3, dx = tap % 3;                   // patch coordinates of the tap: (row + dy, col + dx)
+        const unsigned char *b0 = patch + ((2 * wave + dy) * (C3_TW + 2) + r + dx) * stride + 16 * h;
+        const unsigned char *b1 = b0 + (C3_TW + 2) * stride;
+        for (int cs = 0; cs < ncs; cs++) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(wrow + tap * p.Cin + cs * 16);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, *reinterpret_cast<const bf16x8 *>(b0 + cs * 32), acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, *reinterpret_cast<const bf16x8 *>(b1 + cs * 32), acc[1], 0, 0, 0);
+        }
+    }
+    const int U = p.out_up, ox = tx0 + r;
+    if (ox >= p.W) return;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int oy = ty0 + 2 * wave + j;
+        if (oy >= p.H) continue;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int c = 8 * g + 4 * h;
+            if (c >= p.cstore) continue;
+            const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + c);
+            bf16x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; q++) o[q] = (__bf16)actf(acc[j][4 * g + q] + bias[q], p.act);
+            for (int uy = 0; uy < U; uy++)
+                for (int ux = 0; ux < U; ux++)
+                    *reinterpret_cast<bf16x4 *>(p.y + (((long)n * p.H * U + oy * U + uy) * ((long)p.W * U) + ox * U + ux) * p.out_ldc + p.out_coff + c) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- depthwise conv (+ SE pooling)
+// block = (C/8 channel groups) x (L = 256 / (C/8) pixel lanes) over a chunk of output pixels of one image; a thread
+// computes 8 channels of its pixels (16-byte loads and stores, fp32 arithmetic).  With `partial` set the kernel also leaves the
+// per-channel sum of its chunk (of the ACTIVATED fp32 values, combined over the pixel lanes in a fixed order) for the
+// Squeeze-Excitation average pool, so that pool never reads the tensor again.
+// pixels per block: about 64 blocks per image whatever the map size (a 23 x 40 map in 1024-pixel chunks would put ONE block per
+// image on a 256-CU chip, each thread walking hundreds of pixels).  A function of the map size only, never of the batch: the
+// chunking fixes the summation order of the SE pool, and an image's result must not depend on the batch it travels in.
+static inline int dw_chunk(int N, int HWo) {
+    (void)N;
+    long c = (HWo + 63) / 64;
+    c = (c + 15) / 16 * 16;
+    return (int)(c < 16 ? 16 : (c > 1024 ? 1024 : c));
+}
+
+struct DwArgs {
+    const __bf16 *x;
+    const float *w, *bias;          // w f32[k*k][C] tap-major
+    __bf16 *y;
+    float *partial;                 // f32[N][nblk][C] or null
+    int H, W, C, k, stride, Ho, Wo, act, nblk, chunk;
+};
+
+__global__ __launch_bounds__(256) void dwconv_bf16_kernel(DwArgs p) {
+    __shared__ float red[256][8];
+    const int n = blockIdx.y, blk = blockIdx.x;
+    const int C8 = p.C >> 3;
+    const int L = 256 / C8;
+    const int q = threadIdx.x % C8, pl = threadIdx.x / C8;
+    const int pad = (p.k - 1) >> 1;
+    const int HWo = p.Ho * p.Wo;
+    const int p0 = blk * p.chunk, p1 = min(p0 + p.chunk, HWo);
+    float sum[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) sum[j] = 0.f;
+    if (pl < L) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(p.bias + q * 8), b1 = *reinterpret_cast<const f32x4 *>(p.bias + q * 8 + 4);
+        for (int pix = p0 + pl; pix < p1; pix += L) {
+            const int oy = pix / p.Wo, ox = pix - oy * p.Wo;
+            float acc[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            for (int a = 0; a < p.k; a++) {
+                const int iy = oy * p.stride - pad + a;
+                if ((unsigned)iy >= (unsigned)p.H) continue;
+                for (int b = 0; b < p.k; b++) {
+                    const int ix = ox * p.stride - pad + b;
+                    if ((unsigned)ix >= (unsigned)p.W) continue;
+                    const bf16x8 v = *reinterpret_cast<const bf16x8 *>(p.x + (((long)n * p.H + iy) * p.W + ix) * p.C + q * 8);
+                    const float *wp = p.w + (long)(a * p.k + b) * p.C + q * 8;
+                    const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wp), w1 = *reinterpret_cast<const f32x4 *>(wp + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { acc[j] += (float)v[j] * w0[j]; acc[4 + j] += (float)v[4 + j] * w1[j]; }
+                }
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const float t = actf(acc[j], p.act); sum[j] += t; o[j] = (__bf16)t; }
+            *reinterpret_cast<bf16x8 *>(p.y + ((long)n * HWo + pix) * p.C + q * 8) = o;
+        }
+    }
+    if (!p.partial) return;
+#pragma unroll
+    for (int j = 0; j < 8; j++) red[threadIdx.x][j] = sum[j];
+    __syncthreads();
+    if (pl == 0) {
+        for (int l = 1; l < L; l++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) sum[j] += red[l * C8 + q][j];
+        float *dst = p.partial + ((long)n * p.nblk + blk) * p.C + q * 8;
+#pragma unroll
+        for (int j = 0; j < 8; j++) dst[j] = sum[j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- stem: 3x3 / stride 2 / pad 1, RGB
+// reads the model's own input f32[N,3,H,W] (no layout pass), writes bf16[N,Ho,Wo,16] (+ folded BN + Hardswish): 27 taps x 16
+// channels per pixel on the VALU, weights (f32[27][16], row (c*3 + ky)*3 + kx) and bias broadcast from LDS.
+__global__ __launch_bounds__(256) void stem3x3s2_bf16_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                                                             __bf16 *__restrict__ y, int H, int W, int Ho, int Wo, int act, long total) {
+    __shared__ float sw[27 * 16 + 16];
+    for (int i = threadIdx.x; i < 27 * 16 + 16; i += 256) sw[i] = i < 27 * 16 ? w[i] : bias[i - 27 * 16];
+    __syncthreads();
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i >= total) return;
+    const int ox = (int)(i % Wo);
+    const long t = i / Wo;
+    const int oy = (int)(t % Ho);
+    const long n = t / Ho;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) acc[j] = sw[27 * 16 + j];
+    for (int c = 0; c < 3; c++)
+        for (int ky = 0; ky < 3; ky++) {
+            const int iy = 2 * oy - 1 + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            for (int kx = 0; kx < 3; kx++) {
+                const int ix = 2 * ox - 1 + kx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const float v = x[((n * 3 + c) * H + iy) * (long)W + ix];
+                const float *wr = sw + ((c * 3 + ky) * 3 + kx) * 16;
+#pragma unroll
+                for (int j = 0; j < 16; j++) acc[j] += v * wr[j];
+            }
+        }
+    bf16x8 o0, o1;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { o0[j] = (__bf16)actf(acc[j], act); o1[j] = (__bf16)actf(acc[8 + j], act); }
+    *reinterpret_cast<bf16x8 *>(y + i * 16) = o0;
+    *reinterpret_cast<bf16x8 *>(y + i * 16 + 8) = o1;
+}
+
+// ---------------------------------------------------------------------------------------------- DB head tail
+// ConvTranspose2d(C, C, 2, 2) + BN + ReLU -> ConvTranspose2d(C, 1, 2, 2) + bias -> sigmoid (det_db_head.py:13-17) for the small head
+// of this detector (C = 24, stored as 32): one thread per input pixel produces its 4 x 4 block of fp32 probabilities.
+// w1 f32[4][C][C] ((a*2+b), ci, co; BN folded), b1 f32[C], w2 f32[4][C] ((a2*2+b2), co), b2.
+constexpr int HT_C = 24;
+__global__ __launch_bounds__(256) void head_tail_bf16_kernel(const __bf16 *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1,
+                                                             const float *__restrict__ w2, float b2, float *__restrict__ maps, int H, int W,
+                                                             int ldc, long total) {
+    __shared__ float sw1[4 * HT_C * HT_C], sb1[HT_C], sw2[4 * HT_C];
+    for (int i = threadIdx.x; i < 4 * HT_C * HT_C; i += 256) sw1[i] = w1[i];
+    for (int i = threadIdx.x; i < HT_C; i += 256) sb1[i] = b1[i];
+    for (int i = threadIdx.x; i < 4 * HT_C; i += 256) sw2[i] = w2[i];
+    __syncthreads();
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i >= total) return;
+    const int ox = (int)(i % W);
+    const long t = i / W;
+    const int oy = (int)(t % H);
+    const long n = t / H;
+    float xin[HT_C];
+#pragma unroll
+    for (int c8 = 0; c8 < HT_C / 8; c8++) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8 *>(x + i * ldc + c8 * 8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) xin[c8 * 8 + j] = (float)v[j];
+    }
+    float *out = maps + ((n * 4 * H + 4 * oy) * (4L * W) + 4 * ox);
+    for (int ab = 0; ab < 4; ab++) {                        // position (a, b) of the first transposed conv
+        float o[4] = {b2, b2, b2, b2};
+        for (int co = 0; co < HT_C; co++) {
+            float mid = sb1[co];
+            const float *wr = sw1 + (ab * HT_C) * HT_C + co;
+#pragma unroll
+            for (int ci = 0; ci < HT_C; ci++) mid += xin[ci] * wr[ci * HT_C];
+            mid = fmaxf(mid, 0.f);
+#pragma unroll
+            for (int q = 0; q < 4; q++) o[q] += mid * sw2[q * HT_C + co];
+        }
+        const int a = ab >> 1, b = ab & 1;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int a2 = q >> 1, bb2 = q & 1;
+            out[(long)(2 * a + a2) * (4L * W) + 2 * b + bb2] = 1.f / (1.f + expf(-o[q]));
+        }
+    }
+}
+
+}  // namespace ptocr
+
+using namespace ptocr;
+
+extern "C" int ptocr_pwconv_bf16(const void *d_x, const void *d_w, const float *d_bias, const void *d_res, const float *d_scale, void *d_y,
+                                 int N, int H, int W, int Cin, int Cout_pad, int cstore, int act, int res_mode, int res_ldc, int out_ldc,
+                                 int out_coff, void *stream) {
+    PT_CHECK(d_x && d_w && d_bias && d_y && N >= 1 && H >= 1 && W >= 1, "ptocr_pwconv_bf16: null / empty argument");
+    PT_CHECK(Cin % 16 == 0 && Cout_pad % 32 == 0 && cstore % 4 == 0 && cstore >= 4 && cstore <= Cout_pad && act >= 0 && act <= 2,
+             "ptocr_pwconv_bf16: need Cin %% 16 == 0, Cout_pad %% 32 == 0 (zero-padded weight rows), cstore %% 4 == 0");
+    PT_CHECK(res_mode >= 0 && res_mode <= 2 && (res_mode == 0 || d_res) && (res_mode != 2 || (H % 2 == 0 && W % 2 == 0)),
+             "ptocr_pwconv_bf16: bad residual mode");
+    PT_CHECK(out_ldc >= out_coff + cstore && out_ldc % 4 == 0 && out_coff % 4 == 0 && (res_mode == 0 || res_ldc % 4 == 0), "ptocr_pwconv_bf16: bad strides");
+    PwArgs p;
+    p.x = (const __bf16 *)d_x; p.w = (const __bf16 *)d_w; p.res = (const __bf16 *)d_res; p.bias = d_bias; p.scale = d_scale; p.y = (__bf16 *)d_y;
+    p.M = (long)N * H * W; p.Cin = Cin; p.ntile = Cout_pad / 32; p.cstore = cstore; p.act = act; p.res_mode = res_mode; p.H = H; p.W = W;
+    p.out_ldc = out_ldc; p.out_coff = out_coff; p.res_ldc = res_ldc;
+    const long blocks = (p.M + 127) / 128;
+    PT_CHECK(blocks < (1L << 31), "ptocr_pwconv_bf16: too many pixels");
+    hipStream_t s = (hipStream_t)stream;
+    if (p.ntile >= 3) hipLaunchKernelGGL(pw_bf16_kernel<3>, dim3((unsigned)blocks, cdiv(p.ntile, 3)), dim3(256), 0, s, p);
+    else if (p.ntile == 2) hipLaunchKernelGGL(pw_bf16_kernel<2>, dim3((unsigned)blocks, 1), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(pw_bf16_kernel<1>, dim3((unsigned)blocks, 1), dim3(256), 0, s, p);
+    return launch_ok("pw_bf16_kernel");
+}
+
+extern "C" int ptocr_conv3x3_bf16(const void *d_x, const void *d_w, const float *d_bias, void *d_y, int N, int H, int W, int Cin, int cstore,
+                                  int act, int out_up, int out_ldc, int out_coff, void *stream) {
+    PT_CHECK(d_x && d_w && d_bias && d_y && N >= 1 && H >= 1 && W >= 1, "ptocr_conv3x3_bf16: null / empty argument");
+    PT_CHECK(Cin % 16 == 0 && cstore % 4 == 0 && cstore >= 4 && cstore <= 32 && act >= 0 && act <= 2 && out_up >= 1 && out_up <= 8,
+             "ptocr_conv3x3_bf16: need Cin %% 16 == 0, cstore <= 32 (one output tile), out_up <= 8");
+    PT_CHECK(out_ldc >= out_coff + cstore && out_ldc % 4 == 0 && out_coff % 4 == 0, "ptocr_conv3x3_bf16: bad strides");
+    C3Args p;
+    p.x = (const __bf16 *)d_x; p.w = (const __bf16 *)d_w; p.bias = d_bias; p.y = (__bf16 *)d_y; p.M = (long)N * H * W; p.H = H; p.W = W; p.Cin = Cin;
+    p.cstore = cstore; p.act = act; p.out_up = out_up; p.out_ldc = out_ldc; p.out_coff = out_coff;
+    const long blocks = (p.M + 127) / 128;
+    PT_CHECK(blocks < (1L << 31), "ptocr_conv3x3_bf16: too many pixels");
+    static const bool use_lds = !(getenv("PTOCR_BF16_C3_LDS") && atoi(getenv("PTOCR_BF16_C3_LDS")) == 0);
+    if (use_lds && Cin <= C3_MAXCIN && N <= 65535) {
+        hipLaunchKernelGGL(conv3x3_bf16_lds_kernel, dim3(cdiv(W, C3_TW) * cdiv(H, C3_TH), N), dim3(256), 0, (hipStream_t)stream, p);
+        return launch_ok("conv3x3_bf16_lds_kernel");
+    }
+    hipLaunchKernelGGL(conv3x3_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    return launch_ok("conv3x3_bf16_kernel");
+}
+
+extern "C" int ptocr_dwconv_bf16(const void *d_x, const float *d_w, const float *d_bias, void *d_y, float *d_partial, int N, int H, int W,
+                                 int C, int k, int stride, int act, void *stream) {
+    PT_CHECK(d_x && d_w && d_bias && d_y && C % 8 == 0 && C <= 2048 && (k == 3 || k == 5) && (stride == 1 || stride == 2) && act >= 0 && act <= 2 && N <= 65535,
+             "ptocr_dwconv_bf16: need C %% 8 == 0, k in {3,5}, stride in {1,2}");
+    const int pad = (k - 1) / 2;
+    DwArgs p;
+    p.x = (const __bf16 *)d_x; p.w = d_w; p.bias = d_bias; p.y = (__bf16 *)d_y; p.partial = d_partial; p.H = H; p.W = W; p.C = C; p.k = k;
+    p.stride = stride; p.Ho = (H + 2 * pad - k) / stride + 1; p.Wo = (W + 2 * pad - k) / stride + 1; p.act = act;
+    p.chunk = dw_chunk(N, p.Ho * p.Wo);
+    p.nblk = cdiv(p.Ho * p.Wo, p.chunk);
+    hipLaunchKernelGGL(dwconv_bf16_kernel, dim3(p.nblk, N), dim3(256), 0, (hipStream_t)stream, p);
+    return launch_ok("dwconv_bf16_kernel");
+}
+
+extern "C" int ptocr_dwconv_bf16_nblk(int N, int H, int W, int k, int stride) {
+    const int pad = (k - 1) / 2;
+    const int HWo = ((H + 2 * pad - k) / stride + 1) * ((W + 2 * pad - k) / stride + 1);
+    return cdiv(HWo, dw_chunk(N, HWo));
+}
+
+extern "C" int ptocr_stem3x3s2_bf16(const float *d_x, const float *d_w, const float *d_bias, void *d_y, int N, int H, int W, int act, void *stream) {
+    PT_CHECK(d_x && d_w && d_bias && d_y && N >= 1 && H >= 2 && W >= 2 && act >= 0 && act <= 2, "ptocr_stem3x3s2_bf16: bad arguments");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long total = (long)N * Ho * Wo;
+    hipLaunchKernelGGL(stem3x3s2_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_x, d_w, d_bias, (__bf16 *)d_y,
+                       H, W, Ho, Wo, act, total);
+    return launch_ok("stem3x3s2_bf16_kernel");
+}
+
+extern "C" int ptocr_db_head_tail_bf16(const void *d_x, const float *d_w1, const float *d_b1, const float *d_w2, float b2, float *d_maps,
+                                       int N, int H, int W, int C, int ldc, void *stream) {
+    PT_CHECK(d_x && d_w1 && d_b1 && d_w2 && d_maps && C == HT_C && ldc >= C && ldc % 8 == 0, "ptocr_db_head_tail_bf16: built for C == %d (got %d)", HT_C, C);
+    const long total = (long)N * H * W;
+    hipLaunchKernelGGL(head_tail_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)d_x, d_w1, d_b1,
+                       d_w2, b2, d_maps, H, W, ldc, total);
+    return launch_ok("head_tail_bf16_kernel");
+}

@@ -137,3 +137,13 @@ extern "C" int ptocr_se_scale_f32(float *d_x, const float *d_w1, const float *d_
     hipLaunchKernelGGL(se_apply_kernel, dim3(grid_cap(total, 256)), dim3(256), 0, s, d_x, scale, HW, C / 4, total);
     return launch_ok("se kernels");
 }
+
+// Squeeze-Excitation gate alone (det_mobilenet_v3.py:76-85 without the pooling pass and without the multiply): d_partial
+// f32[N][nblk][C] per-chunk channel sums (left by ptocr_dwconv_bf16) -> d_scale f32[N][C] = hardsigmoid(fc2(relu(fc1(mean)))).
+extern "C" int ptocr_se_fc_f32(const float *d_partial, const float *d_w1, const float *d_b1, const float *d_w2, const float *d_b2,
+                               float *d_scale, int N, int HW, int C, int S, int nblk, void *stream) {
+    PT_CHECK(d_partial && d_w1 && d_b1 && d_w2 && d_b2 && d_scale && C <= 1024 && S <= 256 && N >= 1 && HW >= 1 && nblk >= 1,
+             "ptocr_se_fc_f32: bad arguments (C <= 1024, S <= 256)");
+    hipLaunchKernelGGL(se_fc_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, d_partial, d_w1, d_b1, d_w2, d_b2, d_scale, HW, C, S, nblk);
+    return launch_ok("se_fc_kernel");
+}

@@ -37,6 +37,33 @@ class BaseModel(nn.Module):
         config["Head"]["in_channels"] = in_channels
         self.head = build_head(config["Head"])
         self.return_all_feats = config.get("return_all_feats", False)
+        self._compute, self._bf16, self._bf16_sig = "f32", None, None
+
+    def set_compute_dtype(self, dtype):
+        """"f32" (default) or "bf16".  bf16 is the reduced-precision inference mode of BASELINE configs[3] (the counterpart of
+        running the reference module under .half() / autocast): bf16 activations and weights, fp32 accumulation, fp32 maps; built
+        for det models with a MobileNetV3 backbone + FPN + DBHead (modeling/bf16_path.py); anything else raises."""
+        if dtype in ("f32", "fp32", "float32", None):
+            self._compute, self._bf16 = "f32", None
+        elif dtype in ("bf16", "bfloat16"):
+            if self.model_type != "det" or not self.use_neck:
+                raise NotImplementedError("pytorchocr_amd: the bf16 path is built for the MobileNetV3 DB detector only")
+            self._compute = "bf16"
+        else:
+            raise ValueError("compute dtype must be 'f32' or 'bf16', got %r" % (dtype,))
+        return self
+
+    def _bf16_runner(self):
+        sig = tuple((t._version, t.data_ptr(), str(t.device)) for t in list(self.parameters()) + list(self.buffers()))
+        if self._bf16 is None or sig != self._bf16_sig:            # (re)pack after load_state_dict / .to(device)
+            from ..bf16_path import Mbv3DbBf16
+            dev = next(self.parameters()).device
+            if dev.type != "cuda":
+                raise RuntimeError("pytorchocr_amd: model is on %s; move it to a cuda (ROCm) device -- no CPU fallback" % dev)
+            if self.training:
+                raise NotImplementedError("pytorchocr_amd implements the inference (eval) hot path only; call .eval()")
+            self._bf16, self._bf16_sig = Mbv3DbBf16(self, dev), sig
+        return self._bf16
 
     def forward_nhwc4(self, x4):
         """det models: f32[N,H,W,4] (the GPU pre-process output: RGB + zero channel, NHWC) -> {"maps": f32[N,1,H,W]}"""
@@ -47,6 +74,10 @@ class BaseModel(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("pytorchocr_amd BaseModel.forward: input is on %s; the HIP path has no CPU fallback" % x.device)
         y = dict()
+        if self._compute == "bf16":
+            if self.return_all_feats:
+                raise NotImplementedError("return_all_feats is an fp32-path option")
+            return self._bf16_runner().forward(x)
         if self.model_type == "det":
             feats = self.backbone.forward_from_nchw(x) if hasattr(self.backbone, "forward_from_nchw") \
                 else self.backbone.forward_nhwc(ops.nchw_to_nhwc(x, 4))
