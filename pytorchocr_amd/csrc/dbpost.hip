@@ -30,6 +30,7 @@
 //    planes + masked mean in double (a workgroup), unclip + second rectangle + final box (one lane per border).
 // Memory: everything is integer/bit work bound by HBM/L2 latency, not by MFMA; the bitmap is 1 bit/pixel.
 #include "common.h"
+#include <cstdlib>
 
 namespace ptocr {
 
@@ -832,6 +833,14 @@ __device__ RRect min_area_rect_sorted(const F2 *sorted, int n, F2 *hull, int *st
 // edge vectors and their inverse lengths (a double sqrt and a double division each), the four extreme vertices and the
 // orientation -- runs one edge per lane, with the reference's arithmetic and the reference's tie rules (the FIRST index that
 // attains an extreme; the first non-zero turn).  The caliper loop itself stays the reference's sequential code on lane 0.
+// LDS hand-off between the lanes of ONE wave (the wave's LDS operations execute in order; the fences keep the compiler from
+// moving accesses across, the barrier is a scheduling no-op for a single wave): usable inside any workgroup by one of its waves
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ void wave_first_extreme(float v, int idx, bool want_max, int *out_idx) {
     // lane-private (value, index) candidates -> index of the extreme over the wave, lowest index among equals
 #pragma unroll
@@ -845,7 +854,7 @@ __device__ __forceinline__ void wave_first_extreme(float v, int idx, bool want_m
 }
 
 __device__ void rotating_calipers_wave(const F2 *points, int n, float *scratch, float *out) {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     float *inv_len = scratch;
     F2 *vect = reinterpret_cast<F2 *>(scratch + n);
     int *seq = reinterpret_cast<int *>(scratch + 3 * n);
@@ -868,7 +877,7 @@ __device__ void rotating_calipers_wave(const F2 *points, int n, float *scratch, 
     wave_first_extreme(rx, ri, true, &right);
     wave_first_extreme(ty, ti, true, &top);
     wave_first_extreme(by, bi, false, &bottom);
-    __syncthreads();
+    wave_sync();
     // orientation: sign of the first non-zero turn (edge i-1 -> edge i), scanning i = 0 .. n-1
     float orientation = 0;
     for (int base = 0; base < n; base += 64) {
@@ -951,8 +960,8 @@ __device__ void rotating_calipers_wave(const F2 *points, int n, float *scratch, 
 __device__ RRect min_area_rect_wave(const F2 *sorted, int n, F2 *hull, int *stack, float *scratch, int *sh_hn) {
     RRect box; box.cx = box.cy = box.w = box.h = box.angle = 0.f;
     if (n <= 0) return box;                                     // uniform
-    if (threadIdx.x == 0) *sh_hn = convex_hull_sorted(sorted, n, hull, stack);
-    __syncthreads();
+    if ((threadIdx.x & 63) == 0) *sh_hn = convex_hull_sorted(sorted, n, hull, stack);
+    wave_sync();
     const int hn = *sh_hn;
     if (hn > 2) {
         float out[6] = {0, 0, 0, 0, 0, 0};
@@ -1100,16 +1109,15 @@ struct Result { int status; int box[8]; float score; float rect[5]; int npix; fl
 
 constexpr int CT_THREADS = 256;
 constexpr int MAXW = 2048;                // widest map the column tables hold
-constexpr int LDS_PLANE_WORDS = 4096;     // full-size pass: mask planes up to 131072 pixels live in LDS; larger ones in a global slot
+constexpr int LDS_PLANE_WORDS = 4096;     // full-size pass: mask planes of 131072 pixels in LDS (larger masks go through them in bands)
 constexpr int MAXHULL = 512;              // full-size pass: strict hull vertices of a lattice polygon inside 2048 x 32767 stay far below
-constexpr int NSLOTS = 256;               // global mask slots (two full-image bit planes each)
 constexpr int S_MW = 1024, S_PLANE = 1984, S_MH = 96;      // small-footprint stages: border width, mask plane words, hull / offset points
 
 __device__ __forceinline__ long long cross3(int ax, int ay, int bx, int by, int px, int py) {
     return (long long)(bx - ax) * (py - ay) - (long long)(by - ay) * (px - ax);
 }
 
-// block sum in a FIXED tree order (lanes by shuffle, then the four waves in order): sh = CT_THREADS / 64 entries
+// block sum in a FIXED tree order (lanes by shuffle, then the waves in order): sh = blockDim.x / 64 entries (<= 16)
 template <typename T>
 __device__ T block_reduce_sum(T v, T *sh) {
     const int tid = threadIdx.x;
@@ -1118,23 +1126,9 @@ __device__ T block_reduce_sum(T v, T *sh) {
     if ((tid & 63) == 0) sh[tid >> 6] = v;
     __syncthreads();
     T r = sh[0];
-#pragma unroll
-    for (int w = 1; w < CT_THREADS / 64; w++) r += sh[w];
+    for (int w = 1; w < (int)(blockDim.x >> 6); w++) r += sh[w];
     __syncthreads();
     return r;
-}
-
-// Plane words may live in LDS or in a global slot.  Global words are written with atomics (performed at L2) by
-// every wave of the workgroup, so they are read back with agent-scope loads that bypass this CU's L1.
-template <bool GLOBAL>
-__device__ __forceinline__ unsigned plane_ld(const unsigned *p) {
-    if (GLOBAL) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return *p;
-}
-template <bool GLOBAL>
-__device__ __forceinline__ void plane_st(unsigned *p, unsigned v) {
-    if (GLOBAL) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
 }
 
 // fillPoly(mask, {border polygon}, 1, lineType=1) over the bounding box + cv::mean(pred, mask), from the border's STATES: a
@@ -1142,70 +1136,115 @@ __device__ __forceinline__ void plane_st(unsigned *p, unsigned v) {
 // decompose over its unit steps -- the even-odd crossing of a non-horizontal edge on rows ya <= y < yb (FillEdgeCollection's
 // half-open rule) is one toggle at the upper end of every unit step, and the 4-connected edge line (cv::Line, connectivity 1
 // -> 4, walked from the left end: x step first, then y step) is the step's two end pixels plus, for a diagonal step, the
-// pixel beside its left end.  Returns sum (double, block tree order) and pixel count; leaves the final mask in `border`.
-template <bool GLOBAL>
-__device__ void score_mask(const unsigned *st, int n, int xmin, int ymin, int bw, int bh, unsigned *border, unsigned *toggle,
-                           const float *pimg, int W, double *red_d, int *red_i, double *sum_out, int *cnt_out) {
-    const int tid = threadIdx.x;
+// pixel beside its left end.  mask row = prefix_xor(crossings) | edge pixels (a span [c1, c2] of the reference = parity bits
+// c1 .. c2-1 plus edge pixel c2).
+// The two bit planes live in LDS (`plane_words` words each); a mask that does not fit is built and summed in BANDS of rows, every
+// band scanning the state list for the steps that touch it (rows are independent: the parity never crosses a row).  The masked
+// sum reads the probability map fully coalesced: a half-wave takes the 32 pixels of one mask word.
+// raster == false: returns sum (double; fixed order: per-thread over its words, then the block tree) and pixel count.
+// raster == true: the sum is taken by ONE lane in raster order, the order of cv::mean (only when the decision is within rounding).
+__device__ void score_mask(const unsigned *st, int n, int xmin, int ymin, int bw, int bh, unsigned *border, unsigned *toggle, int plane_words,
+                           const float *pimg, int W, double *red_d, int *red_i, bool raster, double *sum_out, int *cnt_out) {
+    const int tid = threadIdx.x, nt = blockDim.x;
     const int pw = (bw + 31) >> 5;
-    const long plane_words = (long)pw * bh;
-    for (long i = tid; i < plane_words; i += CT_THREADS) { plane_st<GLOBAL>(&border[i], 0); plane_st<GLOBAL>(&toggle[i], 0); }
-    __syncthreads();
-    for (int i = tid; i < n; i += CT_THREADS) {
-        const unsigned s = st[i];
-        const int so = st_out(s);
-        const int x0 = st_x(s) - xmin, y0 = st_y(s) - ymin;
-        const int dx = dir_dx(so), dy = dir_dy(so);
-        atomicOr(&border[(long)y0 * pw + (x0 >> 5)], 1u << (x0 & 31));                     // this end (the other end is the next state's)
-        if (dy != 0) {
-            const int xu = dy > 0 ? x0 : x0 + dx, yu = dy > 0 ? y0 : y0 - 1;               // upper end of the step
-            atomicXor(&toggle[(long)yu * pw + (xu >> 5)], 1u << (xu & 31));
-            if (dx != 0) {                                                               // diagonal: the pixel right of the left end
-                const int xc = dx > 0 ? x0 + 1 : x0, yc = dx > 0 ? y0 : y0 + dy;
-                atomicOr(&border[(long)yc * pw + (xc >> 5)], 1u << (xc & 31));
+    const int R = plane_words / pw;                             // rows per band (>= 1: callers size the planes for the widest map)
+    double s = 0; int cnt = 0;
+    for (int r0 = 0; r0 < bh; r0 += R) {
+        const int rows = min(R, bh - r0);
+        for (int i = tid; i < rows * pw; i += nt) { border[i] = 0; toggle[i] = 0; }
+        __syncthreads();
+        for (int i = tid; i < n; i += nt) {
+            const unsigned sv = st[i];
+            const int so = st_out(sv);
+            const int x0 = st_x(sv) - xmin, y0 = st_y(sv) - ymin - r0;                 // row relative to the band
+            const int dx = dir_dx(so), dy = dir_dy(so);
+            if ((unsigned)y0 < (unsigned)rows) atomicOr(&border[y0 * pw + (x0 >> 5)], 1u << (x0 & 31));       // this end (the other end is the next state's)
+            if (dy != 0) {
+                const int xu = dy > 0 ? x0 : x0 + dx, yu = dy > 0 ? y0 : y0 - 1;       // upper end of the step
+                if ((unsigned)yu < (unsigned)rows) atomicXor(&toggle[yu * pw + (xu >> 5)], 1u << (xu & 31));
+                if (dx != 0) {                                                       // diagonal: the pixel right of the left end
+                    const int xc = dx > 0 ? x0 + 1 : x0, yc = dx > 0 ? y0 : y0 + dy;
+                    if ((unsigned)yc < (unsigned)rows) atomicOr(&border[yc * pw + (xc >> 5)], 1u << (xc & 31));
+                }
             }
         }
-    }
-    if (GLOBAL) __threadfence();
-    __syncthreads();
-    // mask row = prefix_xor(crossings) | border   (a span [c1, c2] of the reference = parity bits c1..c2-1 plus border pixel c2)
-    for (int y = tid; y < bh; y += CT_THREADS) {
-        unsigned carry = 0;
-        for (int w = 0; w < pw; w++) {
-            unsigned t = plane_ld<GLOBAL>(&toggle[(long)y * pw + w]);
-            t ^= t << 1; t ^= t << 2; t ^= t << 4; t ^= t << 8; t ^= t << 16;
-            t ^= carry;
-            carry = (t >> 31) ? 0xffffffffu : 0u;
-            plane_st<GLOBAL>(&border[(long)y * pw + w], plane_ld<GLOBAL>(&border[(long)y * pw + w]) | t);
+        __syncthreads();
+        for (int y = tid; y < rows; y += nt) {
+            unsigned carry = 0;
+            for (int w = 0; w < pw; w++) {
+                unsigned t = toggle[y * pw + w];
+                t ^= t << 1; t ^= t << 2; t ^= t << 4; t ^= t << 8; t ^= t << 16;
+                t ^= carry;
+                carry = (t >> 31) ? 0xffffffffu : 0u;
+                border[y * pw + w] |= t;
+            }
         }
+        __syncthreads();
+        if (raster) {
+            if (tid == 0)
+                for (int y = 0; y < rows; y++)
+                    for (int w = 0; w < pw; w++) {
+                        unsigned m = border[y * pw + w];
+                        const float *prow = pimg + (long)(y + r0 + ymin) * W + xmin + w * 32;
+                        while (m) { const int b = __ffs(m) - 1; m &= m - 1; s += (double)prow[b]; }
+                    }
+        } else {
+            // eight lanes per mask word, four consecutive pixels (one 16-byte load) per lane: a wave instruction covers eight words,
+            // and four of them are in flight per lane (a lone workgroup summing a full-image mask is bound by bytes in flight)
+            struct __attribute__((packed, aligned(4))) F4 { float v[4]; };
+            const int grp = tid >> 3, q = tid & 7;
+            const int ng = nt >> 3, nw = rows * pw;
+            for (int i0 = grp; i0 < nw; i0 += 4 * ng) {
+                F4 v[4];
+                unsigned mm[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = i0 + u * ng;
+                    mm[u] = 0;
+                    if (i < nw) {
+                        const unsigned m = (border[i] >> (4 * q)) & 15u;
+                        const int y = i / pw, w = i - y * pw;
+                        const int x = w * 32 + 4 * q;
+                        // the last word of a row may reach past the map's right edge: its bits there are clear, and a load that
+                        // would cross the end of the row is not issued
+                        if (m && xmin + x + 3 < W) { v[u] = *reinterpret_cast<const F4 *>(pimg + (long)(y + r0 + ymin) * W + xmin + x); mm[u] = m; }
+                        else if (m) {
+                            for (int e = 0; e < 4; e++) v[u].v[e] = ((m >> e) & 1u) ? pimg[(long)(y + r0 + ymin) * W + xmin + x + e] : 0.f;
+                            mm[u] = m;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if ((mm[u] >> e) & 1u) { s += (double)v[u].v[e]; cnt++; }
+            }
+        }
+        __syncthreads();
     }
-    if (GLOBAL) __threadfence();
-    __syncthreads();
-    double s = 0; int cnt = 0;
-    for (long i = tid; i < plane_words; i += CT_THREADS) {
-        unsigned m = plane_ld<GLOBAL>(&border[i]);
-        if (!m) continue;
-        const int y = (int)(i / pw), w = (int)(i - (long)y * pw);
-        const float *prow = pimg + (long)(y + ymin) * W + xmin + w * 32;
-        cnt += __popc(m);
-        while (m) { const int b = __ffs(m) - 1; m &= m - 1; s += (double)prow[b]; }
-    }
+    if (raster) { *sum_out = s; return; }                        // valid on thread 0
     *sum_out = block_reduce_sum<double>(s, red_d);
     *cnt_out = block_reduce_sum<int>(cnt, red_i);
 }
 
-// same mask, summed by ONE lane in raster order: the order of cv::mean (only when the decision is within rounding)
-template <bool GLOBAL>
-__device__ double score_mask_raster_order(const unsigned *border, int xmin, int ymin, int bw, int bh, const float *pimg, int W) {
-    const int pw = (bw + 31) >> 5;
-    double s = 0;
-    for (int y = 0; y < bh; y++)
-        for (int w = 0; w < pw; w++) {
-            unsigned m = plane_ld<GLOBAL>(&border[(long)y * pw + w]);
-            const float *prow = pimg + (long)(y + ymin) * W + xmin + w * 32;
-            while (m) { const int b = __ffs(m) - 1; m &= m - 1; s += (double)prow[b]; }
-        }
-    return s;
+// score of a border (db_postprocess.cpp:194-229 + the float compare of :272): parallel sum; when the score lands within 1e-6 of
+// box_thresh the mask is rebuilt and summed in cv::mean's raster order, so the decision is the reference's.  sh_tie: one LDS double.
+__device__ float border_score(const unsigned *st, int n, int xmin, int ymin, int bw, int bh, unsigned *border, unsigned *toggle, int plane_words,
+                              const float *pimg, int W, double *red_d, int *red_i, double *sh_tie, float box_thresh, int *flag_word, int *npix_out) {
+    double total; int npix;
+    score_mask(st, n, xmin, ymin, bw, bh, border, toggle, plane_words, pimg, W, red_d, red_i, false, &total, &npix);
+    float score = (float)(npix ? total / npix : 0.0);
+    if (fabs((double)score - (double)box_thresh) <= 1e-6) {      // uniform: every thread holds the same total
+        double t2; int dummy;
+        score_mask(st, n, xmin, ymin, bw, bh, border, toggle, plane_words, pimg, W, red_d, red_i, true, &t2, &dummy);
+        if (threadIdx.x == 0) { *sh_tie = t2; atomicOr(flag_word, 2); }
+        __syncthreads();
+        score = (float)(npix ? *sh_tie / npix : 0.0);
+        __syncthreads();
+    }
+    *npix_out = npix;
+    return score;
 }
 
 // ---- stage A (a workgroup): hull candidates of a border.  Per-column extremes of the contour points, i.e. of the states at
@@ -1215,16 +1254,16 @@ __device__ double score_mask_raster_order(const unsigned *border, int xmin, int 
 // steepest successor.  Exact integer arithmetic, O(m^2 / 256).  Survivors come out in (x, y) order, the order
 // cv::convexHull sorts to.  arena: 3 * MW ints of LDS.  Returns the number of survivors (may exceed cap: nothing beyond
 // cap is stored).
-template <int MW>
+template <int MW, int NT>
 __device__ int hull_candidates(const unsigned *st, int n, int xmin, int bw, unsigned *arena, F2 *out, int cap, int *wave_cnt, int *sh_n) {
     const int tid = threadIdx.x;
     int *col_lo = reinterpret_cast<int *>(arena);               // [MW] min y of the border pixels per column
     int *col_hi = col_lo + MW;                                  // [MW] max y
     int *col_x = col_hi + MW;                                   // [MW] x (relative to xmin) of compacted column a
-    for (int i = tid; i < bw; i += CT_THREADS) { col_lo[i] = 0x7fffffff; col_hi[i] = -0x7fffffff; }
+    for (int i = tid; i < bw; i += NT) { col_lo[i] = 0x7fffffff; col_hi[i] = -0x7fffffff; }
     if (tid == 0) *sh_n = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += CT_THREADS) {
+    for (int i = tid; i < n; i += NT) {
         const unsigned s = st[i];
         if (st_out(s) == (st_in(s) ^ 4)) continue;             // the chain runs straight through: not a contour point, not a hull vertex
         const int x = st_x(s) - xmin, y = st_y(s);
@@ -1235,11 +1274,11 @@ __device__ int hull_candidates(const unsigned *st, int n, int xmin, int bw, unsi
     const int lane = tid & 63, wave = tid >> 6;
     int m_cols = 0;
     {
-        constexpr int ROUNDS = MW / CT_THREADS;                 // bw <= MW
+        constexpr int ROUNDS = MW / NT;                 // bw <= MW
         int v_lo[ROUNDS], v_hi[ROUNDS], v_pos[ROUNDS];
 #pragma unroll
         for (int r = 0; r < ROUNDS; r++) {
-            const int i = r * CT_THREADS + tid;
+            const int i = r * NT + tid;
             const bool has = i < bw && col_lo[i] != 0x7fffffff;
             v_lo[r] = has ? col_lo[i] : 0; v_hi[r] = has ? col_hi[i] : 0;
             const unsigned long long bal = __ballot(has);
@@ -1248,15 +1287,15 @@ __device__ int hull_candidates(const unsigned *st, int n, int xmin, int bw, unsi
             int pos = m_cols + __popcll(bal & ((1ull << lane) - 1));
             for (int w = 0; w < wave; w++) pos += wave_cnt[w];
             v_pos[r] = has ? pos : -1;
-            for (int w = 0; w < CT_THREADS / 64; w++) m_cols += wave_cnt[w];
+            for (int w = 0; w < NT / 64; w++) m_cols += wave_cnt[w];
             __syncthreads();
         }
 #pragma unroll
         for (int r = 0; r < ROUNDS; r++)
-            if (v_pos[r] >= 0) { col_lo[v_pos[r]] = v_lo[r]; col_hi[v_pos[r]] = v_hi[r]; col_x[v_pos[r]] = r * CT_THREADS + tid; }
+            if (v_pos[r] >= 0) { col_lo[v_pos[r]] = v_lo[r]; col_hi[v_pos[r]] = v_hi[r]; col_x[v_pos[r]] = r * NT + tid; }
         __syncthreads();
     }
-    for (int base = 0; base < m_cols; base += CT_THREADS) {
+    for (int base = 0; base < m_cols; base += NT) {
         const int i = base + tid;
         int keep_lo = 0, keep_hi = 0, ylo = 0, yhi = 0, xi = 0;
         if (i < m_cols) {
@@ -1290,7 +1329,7 @@ __device__ int hull_candidates(const unsigned *st, int n, int xmin, int bw, unsi
         if (keep_lo) { if (pos < cap) { out[pos].x = (float)(xi + xmin); out[pos].y = (float)ylo; } pos++; }
         if (keep_hi) { if (pos < cap) { out[pos].x = (float)(xi + xmin); out[pos].y = (float)yhi; } pos++; }
         __syncthreads();
-        if (tid == CT_THREADS - 1) *sh_n = pos;
+        if (tid == NT - 1) *sh_n = pos;
         __syncthreads();
     }
     return *sh_n;
@@ -1377,9 +1416,10 @@ __device__ int unclip_stage(const float (*mini)[2], float unclip_ratio, F2 *pts,
 }
 
 struct StageArgs {
-    const float *maps; const Cand *cands; const int *totals; const Acc *acc; const unsigned *pool; unsigned *gslots; int *slot_locks;
+    const float *maps; const Cand *cands; const int *totals; const Acc *acc; const unsigned *pool;
     Result *results; int *flags; const int *src_wh; F2 *hin; int *hn; float *mini;
-    float box_thresh, unclip_ratio; long slot_words; int use_padding_resize;
+    float box_thresh, unclip_ratio; int use_padding_resize;
+    int dbg_skip;      // timing experiments only (PTOCR_DBPOST_DBG_SKIP): phases of the full-size pass to leave out
 };
 
 // ---- stage A kernel: one workgroup per border (12 KB of LDS: fits beside a Winograd workgroup of the next batch's forward)
@@ -1401,7 +1441,7 @@ __global__ __launch_bounds__(CT_THREADS, 6) void hull_kernel(StageArgs a, Dbpost
     __shared__ __attribute__((aligned(16))) unsigned arena[3 * S_MW];
     __shared__ int wave_cnt[CT_THREADS / 64];
     __shared__ int sh_n;
-    const int n = hull_candidates<S_MW>(a.pool + (long)img * d.pool_cap + ac.off, ac.nstates, ac.xmin, bw, arena, a.hin + bi * S_MH, S_MH,
+    const int n = hull_candidates<S_MW, CT_THREADS>(a.pool + (long)img * d.pool_cap + ac.off, ac.nstates, ac.xmin, bw, arena, a.hin + bi * S_MH, S_MH,
                                         wave_cnt, &sh_n);
     if (tid == 0) {
         if (n > S_MH) { res->status = ST_DEFER; atomicOr(&a.flags[img], 8); }
@@ -1428,7 +1468,8 @@ __global__ __launch_bounds__(64) void rect_kernel(StageArgs a, DbpostDims d) {
     if (threadIdx.x == 0) res->status = rect_finish(box, res, reinterpret_cast<float (*)[2]>(a.mini + bi * 8));
 }
 
-// ---- stage C kernel: BoxScore (db_postprocess.cpp:194-229), one workgroup per border (15.6 KB of LDS: mask planes up to 63 488 px)
+// ---- stage C kernel: BoxScore (db_postprocess.cpp:194-229), one workgroup per border (15.6 KB of LDS: mask planes of 63 488 px;
+// a larger mask goes through them in bands of rows)
 __global__ __launch_bounds__(CT_THREADS, 6) void score_kernel(StageArgs a, DbpostDims d) {
     const int img = blockIdx.y, k = blockIdx.x;
     if (k >= min(a.totals[img], MAX_CAND)) return;
@@ -1438,37 +1479,13 @@ __global__ __launch_bounds__(CT_THREADS, 6) void score_kernel(StageArgs a, Dbpos
     if (res->status != ST_PEND_SCORE) return;                   // uniform over the workgroup (written by an earlier kernel)
     const Acc ac = a.acc[bi];
     const int bw = ac.xmax - ac.xmin + 1, bh = ac.ymax - ac.ymin + 1;
-    const long plane_words = (long)((bw + 31) >> 5) * bh;
     __shared__ __attribute__((aligned(16))) unsigned planes[2 * S_PLANE];
     __shared__ double red_d[CT_THREADS / 64];
     __shared__ int red_i[CT_THREADS / 64];
-    const float *pimg = a.maps + (long)img * d.HW;
-    const unsigned *st = a.pool + (long)img * d.pool_cap + ac.off;
-    double total; int npix;
-    float score;
-    if (plane_words <= S_PLANE) {
-        score_mask<false>(st, ac.nstates, ac.xmin, ac.ymin, bw, bh, planes, planes + S_PLANE, pimg, d.W, red_d, red_i, &total, &npix);
-        score = (float)(npix ? total / npix : 0.0);
-        if (fabs((double)score - (double)a.box_thresh) <= 1e-6) {
-            if (tid == 0) { red_d[0] = score_mask_raster_order<false>(planes, ac.xmin, ac.ymin, bw, bh, pimg, d.W); atomicOr(&a.flags[img], 2); }
-            __syncthreads();
-            score = (float)(npix ? red_d[0] / npix : 0.0);
-        }
-    } else {                                                    // a mask too large for the LDS planes: one of the global slots
-        const int slot = (int)(bi % NSLOTS);
-        unsigned *border = a.gslots + (long)slot * 2 * a.slot_words, *toggle = border + a.slot_words;
-        if (tid == 0) { while (atomicCAS(&a.slot_locks[slot], 0, 1) != 0) __builtin_amdgcn_s_sleep(32); __threadfence(); }
-        __syncthreads();
-        score_mask<true>(st, ac.nstates, ac.xmin, ac.ymin, bw, bh, border, toggle, pimg, d.W, red_d, red_i, &total, &npix);
-        score = (float)(npix ? total / npix : 0.0);
-        if (fabs((double)score - (double)a.box_thresh) <= 1e-6) {
-            if (tid == 0) { red_d[0] = score_mask_raster_order<true>(border, ac.xmin, ac.ymin, bw, bh, pimg, d.W); atomicOr(&a.flags[img], 2); }
-            __syncthreads();
-            score = (float)(npix ? red_d[0] / npix : 0.0);
-        }
-        __syncthreads();
-        if (tid == 0) { __threadfence(); atomicExch(&a.slot_locks[slot], 0); }
-    }
+    __shared__ double sh_tie;
+    int npix;
+    const float score = border_score(a.pool + (long)img * d.pool_cap + ac.off, ac.nstates, ac.xmin, ac.ymin, bw, bh, planes, planes + S_PLANE, S_PLANE,
+                                     a.maps + (long)img * d.HW, d.W, red_d, red_i, &sh_tie, a.box_thresh, &a.flags[img], &npix);
     if (tid == 0) {
         res->score = score; res->npix = npix;
         res->status = score < a.box_thresh ? ST_SKIP_SCORE : ST_PEND_UNCLIP;              // db_postprocess.cpp:272
@@ -1511,9 +1528,11 @@ __global__ __launch_bounds__(64, 5) void unclip_kernel(StageArgs a, DbpostDims d
     if (threadIdx.x == 0) res->status = unclip_box(ub, res, a.src_wh[2 * img], a.src_wh[2 * img + 1], a.use_padding_resize, d);
 }
 
-// ---- full-size pass: a few workgroups per image walk the borders the small-footprint stages deferred (borders wider than
-// 1024 px, more than 96 hull / offset points: usually none) through all four stages, serial parts on lane 0
-__global__ __launch_bounds__(CT_THREADS, 1) void contour_big_kernel(StageArgs a, DbpostDims d) {
+// ---- full-size pass: a few workgroups of 1024 threads per image walk the borders the small-footprint stages deferred (borders wider
+// than 1024 px, more than 96 hull / offset points: usually none; on noise maps the one giant component) through all four stages:
+// the parallel parts on all 16 waves, the rectangles on wave 0 (cooperative forms above)
+constexpr int BIG_THREADS = 1024;
+__global__ __launch_bounds__(BIG_THREADS, 1) void contour_big_kernel(StageArgs a, DbpostDims d) {
     const int img = blockIdx.y;
     if (!(a.flags[img] & 8)) return;                      // internal bit 3: a small stage deferred at least one border of this image
     const int tid = threadIdx.x;
@@ -1521,13 +1540,15 @@ __global__ __launch_bounds__(CT_THREADS, 1) void contour_big_kernel(StageArgs a,
     __shared__ __attribute__((aligned(16))) unsigned arena[ARENA];     // column tables (hull stage) / mask planes (score stage)
     __shared__ F2 cand_pts[MAXHULL];
     __shared__ F2 hull_pts[MAXHULL];
+    __shared__ F2 raw_pts[MAXHULL];
     __shared__ int stack[2 * (MAXHULL + 2)];
     __shared__ float cal_scratch[3 * MAXHULL + 4];
     __shared__ long long cl_ws[24];
-    __shared__ double red_d[CT_THREADS / 64];
-    __shared__ int red_i[CT_THREADS / 64];
-    __shared__ int wave_cnt[CT_THREADS / 64];
-    __shared__ int sh_n, sh_status;
+    __shared__ double red_d[BIG_THREADS / 64];
+    __shared__ int red_i[BIG_THREADS / 64];
+    __shared__ int wave_cnt[BIG_THREADS / 64];
+    __shared__ int sh_n, sh_status, sh_hn, sh_np;
+    __shared__ double sh_tie;
     __shared__ float sh_mini[4][2];
     const int num = min(a.totals[img], MAX_CAND);
     for (int k = blockIdx.x; k < num; k += gridDim.x) {
@@ -1538,50 +1559,46 @@ __global__ __launch_bounds__(CT_THREADS, 1) void contour_big_kernel(StageArgs a,
         const Acc ac = a.acc[bi];
         const unsigned *st = a.pool + (long)img * d.pool_cap + ac.off;
         const int bw = ac.xmax - ac.xmin + 1, bh = ac.ymax - ac.ymin + 1;
-        const int n = hull_candidates<MAXW>(st, ac.nstates, ac.xmin, bw, arena, cand_pts, MAXHULL, wave_cnt, &sh_n);
-        if (tid == 0) {
-            if (n > MAXHULL) { atomicOr(&a.flags[img], 4); sh_status = ST_NONE; }
-            else sh_status = rect_stage(cand_pts, n, hull_pts, stack, cal_scratch, res, sh_mini);
+        if (a.dbg_skip & 1) { if (tid == 0) res->status = ST_NONE; continue; }
+        const int n = hull_candidates<MAXW, BIG_THREADS>(st, ac.nstates, ac.xmin, bw, arena, cand_pts, MAXHULL, wave_cnt, &sh_n);
+        if (a.dbg_skip & 2) { if (tid == 0) res->status = ST_NONE; continue; }
+        if (n > MAXHULL) { if (tid == 0) { atomicOr(&a.flags[img], 4); res->status = ST_NONE; } continue; }
+        if (tid < 64) {
+            const RRect box = min_area_rect_wave(cand_pts, n, hull_pts, stack, cal_scratch, &sh_hn);
+            if (tid == 0) sh_status = rect_finish(box, res, sh_mini);
         }
         __syncthreads();
         if (sh_status != ST_PEND_SCORE) { if (tid == 0) res->status = sh_status; continue; }
-        const float *pimg = a.maps + (long)img * d.HW;
-        const long plane_words = (long)((bw + 31) >> 5) * bh;
-        double total; int npix;
-        float score;
-        if (plane_words <= LDS_PLANE_WORDS) {
-            unsigned *border = arena, *toggle = arena + LDS_PLANE_WORDS;
-            score_mask<false>(st, ac.nstates, ac.xmin, ac.ymin, bw, bh, border, toggle, pimg, d.W, red_d, red_i, &total, &npix);
-            score = (float)(npix ? total / npix : 0.0);
-            if (fabs((double)score - (double)a.box_thresh) <= 1e-6) {
-                if (tid == 0) { red_d[0] = score_mask_raster_order<false>(border, ac.xmin, ac.ymin, bw, bh, pimg, d.W); atomicOr(&a.flags[img], 2); }
-                __syncthreads();
-                score = (float)(npix ? red_d[0] / npix : 0.0);
-            }
-        } else {
-            const int slot = (int)(bi % NSLOTS);
-            unsigned *border = a.gslots + (long)slot * 2 * a.slot_words, *toggle = border + a.slot_words;
-            if (tid == 0) { while (atomicCAS(&a.slot_locks[slot], 0, 1) != 0) __builtin_amdgcn_s_sleep(32); __threadfence(); }
-            __syncthreads();
-            score_mask<true>(st, ac.nstates, ac.xmin, ac.ymin, bw, bh, border, toggle, pimg, d.W, red_d, red_i, &total, &npix);
-            score = (float)(npix ? total / npix : 0.0);
-            if (fabs((double)score - (double)a.box_thresh) <= 1e-6) {
-                if (tid == 0) { red_d[0] = score_mask_raster_order<true>(border, ac.xmin, ac.ymin, bw, bh, pimg, d.W); atomicOr(&a.flags[img], 2); }
-                __syncthreads();
-                score = (float)(npix ? red_d[0] / npix : 0.0);
-            }
-            __syncthreads();
-            if (tid == 0) { __threadfence(); atomicExch(&a.slot_locks[slot], 0); }
-        }
+        if (a.dbg_skip & 4) { if (tid == 0) res->status = ST_NONE; continue; }
+        int npix;
+        const float score = border_score(st, ac.nstates, ac.xmin, ac.ymin, bw, bh, arena, arena + LDS_PLANE_WORDS, LDS_PLANE_WORDS,
+                                         a.maps + (long)img * d.HW, d.W, red_d, red_i, &sh_tie, a.box_thresh, &a.flags[img], &npix);
+        __syncthreads();
+        if (a.dbg_skip & 8) { if (tid == 0) res->status = ST_NONE; continue; }
         if (tid == 0) {
             res->score = score; res->npix = npix;
-            if (score < a.box_thresh) res->status = ST_SKIP_SCORE;                       // db_postprocess.cpp:272
-            else {
-                int s = unclip_stage(sh_mini, a.unclip_ratio, cand_pts, MAXHULL, hull_pts, stack, cal_scratch, res, &a.flags[img],
-                                     a.src_wh[2 * img], a.src_wh[2 * img + 1], a.use_padding_resize, d, cl_ws);
-                if (s == ST_DEFER) { atomicOr(&a.flags[img], 4); s = ST_NONE; }
-                res->status = s;
+            if (score < a.box_thresh) { res->status = ST_SKIP_SCORE; sh_np = -2; }       // db_postprocess.cpp:272
+            else sh_np = max(unclip_offset(sh_mini, a.unclip_ratio, raw_pts, MAXHULL, res, &a.flags[img], cl_ws), 0);
+        }
+        __syncthreads();
+        const int np = sh_np;
+        if (np == -2) continue;
+        if (np > MAXHULL) { if (tid == 0) { atomicOr(&a.flags[img], 4); res->status = ST_NONE; } continue; }
+        for (int i = tid; i < np; i += BIG_THREADS) {           // sort by (x, y) like cv::convexHull: rank every point
+            const F2 t = raw_pts[i];
+            int rank = 0;
+            for (int j = 0; j < np; j++) {
+                const F2 o = raw_pts[j];
+                rank += (o.x < t.x || (o.x == t.x && (o.y < t.y || (o.y == t.y && j < i)))) ? 1 : 0;
             }
+            cand_pts[rank] = t;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            RRect ub;
+            if (np <= 0) { ub.cx = 0; ub.cy = 0; ub.w = 1; ub.h = 1; ub.angle = 0; }
+            else ub = min_area_rect_wave(cand_pts, np, hull_pts, stack, cal_scratch, &sh_hn);
+            if (tid == 0) res->status = unclip_box(ub, res, a.src_wh[2 * img], a.src_wh[2 * img + 1], a.use_padding_resize, d);
         }
     }
 }
@@ -1617,7 +1634,7 @@ struct ptocr_dbpost {
     int max_n, max_h, max_w;
     unsigned *bits; unsigned *bits2; int *labels; int *word_lab; int *chunk_cnt; int *totals; int *strip_totals; Cand *cands; Acc *acc;
     unsigned *pool; F2 *hin; int *hn; float *mini;
-    unsigned *gslots; int *slot_locks; long slot_words; Result *results; int *flags; int *src_wh; short *boxes; int *counts;
+    Result *results; int *flags; int *src_wh; short *boxes; int *counts;
     int boxes_cap;
     long pool_cap;
     hipEvent_t ev0, ev1;          // device time of the last call's kernels (ptocr_dbpost_last_device_ms)
@@ -1647,10 +1664,6 @@ extern "C" int ptocr_dbpost_create(ptocr_dbpost_t *out, int max_n, int max_h, in
     PT_HIP(hipMalloc(&h->hin, sizeof(F2) * (size_t)max_n * MAX_CAND * S_MH));
     PT_HIP(hipMalloc(&h->hn, sizeof(int) * max_n * MAX_CAND));
     PT_HIP(hipMalloc(&h->mini, sizeof(float) * 8 * max_n * MAX_CAND));
-    h->slot_words = (long)max_h * ww + 64;
-    PT_HIP(hipMalloc(&h->gslots, sizeof(unsigned) * NSLOTS * 2 * h->slot_words));
-    PT_HIP(hipMalloc(&h->slot_locks, sizeof(int) * NSLOTS));
-    PT_HIP(hipMemset(h->slot_locks, 0, sizeof(int) * NSLOTS));
     PT_HIP(hipMalloc(&h->results, sizeof(Result) * max_n * MAX_CAND));
     PT_HIP(hipMalloc(&h->flags, sizeof(int) * max_n));
     PT_HIP(hipMalloc(&h->src_wh, sizeof(int) * 2 * max_n));
@@ -1665,7 +1678,7 @@ extern "C" int ptocr_dbpost_create(ptocr_dbpost_t *out, int max_n, int max_h, in
 extern "C" int ptocr_dbpost_destroy(ptocr_dbpost_t h) {
     if (!h) return 0;
     void *bufs[] = {h->bits, h->bits2, h->labels, h->word_lab, h->chunk_cnt, h->totals, h->strip_totals, h->cands, h->acc, h->pool, h->hin,
-                    h->hn, h->mini, h->gslots, h->slot_locks, h->results, h->flags, h->src_wh, h->boxes, h->counts};
+                    h->hn, h->mini, h->results, h->flags, h->src_wh, h->boxes, h->counts};
     for (void *b : bufs) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1777,14 +1790,15 @@ extern "C" int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, co
     hipLaunchKernelGGL(border_states_kernel<true>, all_words, dim3(256), 0, s, bits, h->labels, h->word_lab, h->strip_totals, h->acc, h->pool,
                        h->flags, d);
     StageArgs a;
-    a.maps = d_maps; a.cands = h->cands; a.totals = h->totals; a.acc = h->acc; a.pool = h->pool; a.gslots = h->gslots; a.slot_locks = h->slot_locks;
+    a.maps = d_maps; a.cands = h->cands; a.totals = h->totals; a.acc = h->acc; a.pool = h->pool;
     a.results = h->results; a.flags = h->flags; a.src_wh = h->src_wh; a.hin = h->hin; a.hn = h->hn; a.mini = h->mini;
-    a.box_thresh = box_thresh; a.unclip_ratio = unclip_ratio; a.slot_words = h->slot_words; a.use_padding_resize = use_padding_resize;
+    a.box_thresh = box_thresh; a.unclip_ratio = unclip_ratio; a.use_padding_resize = use_padding_resize;
+    a.dbg_skip = getenv("PTOCR_DBPOST_DBG_SKIP") ? atoi(getenv("PTOCR_DBPOST_DBG_SKIP")) : 0;
     hipLaunchKernelGGL(hull_kernel, dim3(MAX_CAND, N), dim3(CT_THREADS), 0, s, a, d);
     hipLaunchKernelGGL(rect_kernel, dim3(MAX_CAND, N), dim3(64), 0, s, a, d);
     hipLaunchKernelGGL(score_kernel, dim3(MAX_CAND, N), dim3(CT_THREADS), 0, s, a, d);
     hipLaunchKernelGGL(unclip_kernel, dim3(MAX_CAND, N), dim3(64), 0, s, a, d);
-    hipLaunchKernelGGL(contour_big_kernel, dim3(64, N), dim3(CT_THREADS), 0, s, a, d);
+    hipLaunchKernelGGL(contour_big_kernel, dim3(64, N), dim3(BIG_THREADS), 0, s, a, d);
     hipLaunchKernelGGL(compact_kernel, dim3(N), dim3(1024), 0, s, h->results, h->totals, h->boxes, h->counts, max_boxes);
     if (int e = launch_ok("dbpost kernels")) return e;
     PT_HIP(hipEventRecord(h->ev1, s));
