@@ -78,37 +78,60 @@ __global__ __launch_bounds__(256) void pw_bf16_kernel(PwArgs p) {
             }
         }
     }
-    if (m >= p.M) return;
-    int n = 0, oy = 0, ox = 0;
-    if (p.res_mode == 2) { n = (int)(m / HW); const int rem = (int)(m - (long)n * HW); oy = rem / p.W; ox = rem - oy * p.W; }
+    // Epilogue through LDS: a lane's accumulator quads are 8-byte pieces of its pixel's row, 160 bytes apart from the next lane's --
+    // stored directly they reach HBM as partial sectors (measured 2.4x write amplification).  Each wave parks its 32 pixels x
+    // NT*32 channels as bf16 in its own LDS tile and writes it back row-major, 16 bytes per lane, consecutive lanes on consecutive
+    // chunks of a pixel row.  Bias, residual, activation and the FPN top-down add are applied in fp32 on the way in.
+    constexpr int TW = NT * 32 + 8;                             // tile row stride in bf16 (16-byte padded: conflict-free 16-B reads)
+    __shared__ __attribute__((aligned(16))) __bf16 tile[4][32][TW];
 #pragma unroll
-    for (int t = 0; t < NT; t++) {
-        if (t0 + t >= p.ntile) continue;
+    for (int t = 0; t < NT; t++)
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            const int c = (t0 + t) * 32 + 8 * g + 4 * h;
-            if (c >= p.cstore) continue;
-            const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + c);
-            f32x4 v;
+            const int c = (t0 + t) * 32 + 8 * g + 4 * h;             // everything is added in fp32 BEFORE the one rounding to bf16
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (t0 + t < p.ntile && c < p.cstore) {
+                const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + c);
 #pragma unroll
-            for (int j = 0; j < 4; j++) v[j] = acc[t][4 * g + j] + bias[j];
-            if (p.res_mode == 1) {
-                const bf16x4 rr = *reinterpret_cast<const bf16x4 *>(p.res + m * p.res_ldc + c);
+                for (int j = 0; j < 4; j++) v[j] = acc[t][4 * g + j] + bias[j];
+                if (p.res_mode == 1 && m < p.M) {
+                    const bf16x4 rr = *reinterpret_cast<const bf16x4 *>(p.res + m * p.res_ldc + c);
 #pragma unroll
-                for (int j = 0; j < 4; j++) v[j] += (float)rr[j];
-            }
+                    for (int j = 0; j < 4; j++) v[j] += (float)rr[j];
+                }
 #pragma unroll
-            for (int j = 0; j < 4; j++) v[j] = actf(v[j], p.act);
-            if (p.res_mode == 2) {
-                const bf16x4 rr = *reinterpret_cast<const bf16x4 *>(p.res + (((long)n * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) * p.res_ldc + c);
+                for (int j = 0; j < 4; j++) v[j] = actf(v[j], p.act);
+                if (p.res_mode == 2 && m < p.M) {
+                    const int n = (int)(m / HW);
+                    const int rem = (int)(m - (long)n * HW);
+                    const int oy = rem / p.W, ox = rem - oy * p.W;
+                    const bf16x4 rr = *reinterpret_cast<const bf16x4 *>(p.res + (((long)n * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) * p.res_ldc + c);
 #pragma unroll
-                for (int j = 0; j < 4; j++) v[j] += (float)rr[j];
+                    for (int j = 0; j < 4; j++) v[j] += (float)rr[j];
+                }
             }
             bf16x4 o;
 #pragma unroll
             for (int j = 0; j < 4; j++) o[j] = (__bf16)v[j];
-            *reinterpret_cast<bf16x4 *>(p.y + m * p.out_ldc + p.out_coff + c) = o;
+            *reinterpret_cast<bf16x4 *>(&tile[wave][r][t * 32 + 8 * g + 4 * h]) = o;
         }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // write-back: chunks of 8 channels; lane l takes chunk l % CH of pixel l / CH (+ 64 / CH per round)
+    const int cbase = t0 * 32;
+    const int cend = min(p.cstore, (t0 + NT) * 32);              // channels [cbase, cend) belong to this workgroup
+    const int CH = (cend - cbase + 7) >> 3;                      // 16-byte chunks per pixel row (the last may be half: cstore % 8 == 4)
+    if (CH <= 0) return;
+    const long mw0 = ((long)blockIdx.x * 4 + wave) * 32;
+    for (int i = lane; i < 32 * CH; i += 64) {
+        const int pr = i / CH, ch = i - pr * CH;
+        const long mm = mw0 + pr;
+        if (mm >= p.M) continue;
+        const int c = cbase + ch * 8;
+        __bf16 *dst = p.y + mm * p.out_ldc + p.out_coff + c;
+        if (c + 8 <= cend) *reinterpret_cast<bf16x8 *>(dst) = *reinterpret_cast<const bf16x8 *>(&tile[wave][pr][ch * 8]);
+        else *reinterpret_cast<bf16x4 *>(dst) = *reinterpret_cast<const bf16x4 *>(&tile[wave][pr][ch * 8]);
     }
 }
 
@@ -393,7 +416,8 @@ extern "C" int ptocr_pwconv_bf16(const void *d_x, const void *d_w, const float *
              "ptocr_pwconv_bf16: need Cin %% 16 == 0, Cout_pad %% 32 == 0 (zero-padded weight rows), cstore %% 4 == 0");
     PT_CHECK(res_mode >= 0 && res_mode <= 2 && (res_mode == 0 || d_res) && (res_mode != 2 || (H % 2 == 0 && W % 2 == 0)),
              "ptocr_pwconv_bf16: bad residual mode");
-    PT_CHECK(out_ldc >= out_coff + cstore && out_ldc % 4 == 0 && out_coff % 4 == 0 && (res_mode == 0 || res_ldc % 4 == 0), "ptocr_pwconv_bf16: bad strides");
+    PT_CHECK(out_ldc >= out_coff + cstore && out_ldc % 8 == 0 && out_coff % 8 == 0 && (res_mode == 0 || res_ldc % 4 == 0),
+             "ptocr_pwconv_bf16: bad strides (out_ldc, out_coff multiples of 8: 16-byte stores)");
     PwArgs p;
     p.x = (const __bf16 *)d_x; p.w = (const __bf16 *)d_w; p.res = (const __bf16 *)d_res; p.bias = d_bias; p.scale = d_scale; p.y = (__bf16 *)d_y;
     p.M = (long)N * H * W; p.Cin = Cin; p.ntile = Cout_pad / 32; p.cstore = cstore; p.act = act; p.res_mode = res_mode; p.H = H; p.W = W;
