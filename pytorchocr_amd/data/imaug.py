@@ -193,3 +193,30 @@ class RecResizeImg(object):
     def __call__(self, data):
         data["image"] = resize_norm_img(data["image"], self.image_shape, resized_w=None, padding=self.padding)
         return data
+
+
+class RecResizeImgForTest(object):
+    """Variable-width recognition batching (reference rec_img_aug.py:55-106): every crop is resized to height imgH keeping its
+    aspect (width = ceil(w * imgH / h), capped at max_w); a LIST of crops is cut into batches of batch_size in input order, each
+    batch zero-padded on the right to ITS widest crop -> list of tensors f32[b, imgC, imgH, batch_max_w]; a single crop ->
+    f32[1, imgC, imgH, its own width]."""
+
+    def __init__(self, imgC=1, imgH=32, max_w=1200, batch_size=16, padding=True, **kwargs):
+        self.imgC, self.imgH, self.max_w, self.batch_size, self.padding = imgC, imgH, max_w, batch_size, padding
+
+    def width_of(self, img):
+        h, w = img.shape[:2]
+        return min(int(math.ceil(w * (self.imgH / float(h)))), self.max_w)
+
+    def __call__(self, imgs):
+        if not isinstance(imgs, list):
+            w = self.width_of(imgs)
+            return resize_norm_img(imgs, [self.imgC, self.imgH, w], resized_w=w, padding=self.padding).unsqueeze(dim=0)
+        widths = [self.width_of(i) for i in imgs]
+        out = []
+        for b0 in range(0, len(imgs), self.batch_size):
+            ws = widths[b0:b0 + self.batch_size]
+            shape = [self.imgC, self.imgH, max(ws)]
+            out.append(torch.stack([resize_norm_img(i, shape, resized_w=w, padding=self.padding)
+                                    for i, w in zip(imgs[b0:b0 + self.batch_size], ws)], dim=0))
+        return out

@@ -127,3 +127,36 @@ def test_gpu_crops_and_rec_preprocess_match_host(tmp_path, contract, monkeypatch
         monkeypatch.setattr(o.det, "run", lambda im: boxes)
     rh, rg = ocr_h.run(img), ocr_g.run(img)
     assert [r[1] for r in rh] == [r[1] for r in rg] and len(rg) == 3
+
+
+def test_gpu_preprocess_and_crops_against_the_cv2_oracle():
+    """HIP pre-process kernels against oracle/cv2_oracle.py (the literal per-pixel restatement of cv2.resize / cvtColor /
+    warpPerspective with hand-derived known answers, tests/test_oracle_cv2.py) -- not against the product's own host operators."""
+    from oracle import cv2_oracle as cvo
+    from pytorchocr_amd.data.gpu_preprocess import det_preprocess, rec_preprocess, warp_crops
+    dev = torch.device("cuda:0")
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    for (h, w, rh, rw), seed in (((37, 53, 64, 96), 1), ((60, 41, 32, 32), 2), ((40, 64, 40, 64), 3)):
+        img = (uniform01(h * w * 3, seed).reshape(h, w, 3) * 255).astype(np.uint8)
+        x4 = det_preprocess(img, (rh, rw), mean, std, dev, swap_rb=True).cpu().numpy()[0]
+        rs = cvo.resize_linear_u8(np.ascontiguousarray(img[:, :, ::-1]), (rw, rh)).astype(np.float32)            # RGB
+        exp = (torch.from_numpy(rs).div(255) - torch.tensor(mean)) / torch.tensor(std)
+        assert np.array_equal(x4[:, :, :3], exp.numpy()), (h, w)
+    img = (uniform01(48 * 80 * 3, 4).reshape(48, 80, 3) * 255).astype(np.uint8)
+    boxes = [np.array([[4, 5], [60, 8], [58, 30], [3, 27]], np.int16), np.array([[66, 2], [76, 2], [76, 40], [66, 40]], np.int16)]
+    buf, metas = warp_crops(torch.from_numpy(img).to(dev), boxes)
+    crops = []
+    for b, (off, ch, cw) in zip(boxes, metas):
+        c = cvo.get_part_img(img, b)
+        if c.shape[0] >= 1.5 * c.shape[1]:
+            c = np.rot90(c, 1)
+        crops.append(np.ascontiguousarray(c))
+        assert np.array_equal(buf[off:off + ch * cw * 3].cpu().numpy().reshape(ch, cw, 3), c)
+    x4 = rec_preprocess(buf, metas, [1, 32, 320], dev).cpu().numpy()
+    for i, c in enumerate(crops):
+        g = cvo.bgr2gray_u8(c)
+        rw = min(320, int(np.ceil(32 * g.shape[1] / float(g.shape[0]))))
+        r = cvo.resize_linear_u8(g, (rw, 32)).astype(np.float32)
+        exp = np.zeros((32, 320), np.float32)
+        exp[:, :rw] = (r / np.float32(255) - np.float32(0.5)) / np.float32(0.5)
+        assert np.array_equal(x4[i, :, :, 0], exp)

@@ -4,6 +4,8 @@ The detector carries the hand-made brightness checkpoint (utils/synth.py: its ma
 brightness) and the images are text-like scenes, so the boxes are REAL detections (nothing monkeypatched) and the crops, the
 recognition batches and the regrouping all do real work.  The CRNN has random-init weights: its texts are gibberish but
 deterministic, which is all an equality test needs."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -82,3 +84,38 @@ def test_config4_source_size_finds_the_text_lines(ocr):
     assert len(exp) == len(got)
     same = sum(np.array_equal(np.asarray(e), g[0]) for e, g in zip(exp, got))
     assert same >= len(exp) - 2, "boxes differ from the oracle pipeline (%d of %d equal)" % (same, len(exp))
+
+
+def test_eval_loop_on_the_gpu_pipeline(ocr):
+    """pytorchocr_amd.eval (reference tools/program.py:421-473) end to end on the HIP path: detection with the brightness checkpoint
+    scored against its own boxes gives hmean 1, against shifted ground truth less; recognition scored against its own texts gives
+    accuracy 1 (the metric arithmetic itself is pinned in tests/test_metrics.py)."""
+    from pytorchocr_amd.eval import eval as run_eval
+    from pytorchocr_amd.metrics import build_metric
+    dev = torch.device("cuda:0")
+    det, rec = ocr.det, ocr.rec
+    imgs = synth_scene_images(2, 240, 320, seed=21)
+    batches = []
+    for img in imgs:
+        x, shape = det._prep(img)
+        boxes = det.run(img)
+        polys = np.stack(boxes).astype(np.float32)[None]
+        batches.append([x[None], shape[None], polys, np.zeros((1, len(boxes)), bool)])
+    m = run_eval(det.deter, dev, batches, det.det_post_process_class, build_metric(dict(name="DetMetric")), model_type="det")
+    assert m["hmean"] == 1.0 and m["precision"] == 1.0 and m["recall"] == 1.0 and m["fps"] > 0
+    far = [[b[0], b[1], b[2] + 200.0, b[3]] for b in batches]
+    m2 = run_eval(det.deter, dev, far, det.det_post_process_class, build_metric(dict(name="DetMetric")), model_type="det")
+    assert m2["hmean"] < 0.2
+    # recognition: labels = the model's own greedy texts, encoded with CTCLabelEncode and decoded by the post-process
+    from pytorchocr_amd.data.label_ops import CTCLabelEncode
+    from pytorchocr_amd.utils.synth import synth_text_lines
+    x = torch.from_numpy(synth_text_lines(6, 32, 320, seed=5))
+    with torch.no_grad():
+        texts = [t for t, _ in rec.rec_post_process_class(rec.recer(x.cuda()))]
+    enc = CTCLabelEncode(max_text_length=100, character_dict_path=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                               "pytorchocr_amd", "utils", "char_dict_6623.txt"))
+    keep = [i for i, t in enumerate(texts) if 0 < len(t) <= 100]
+    labels = np.stack([enc({"label": texts[i]})["label"] for i in keep])
+    rb = [x[keep], labels]
+    m3 = run_eval(rec.recer, dev, [rb], rec.rec_post_process_class, build_metric(dict(name="RecMetric")), model_type="rec")
+    assert len(keep) >= 3 and m3["acc"] > 0.999 and m3["norm_edit_dis"] > 0.999

@@ -40,8 +40,16 @@ def _import_reference_models():
     tv.models = tvm
     tvm.utils = tvu
     sys.modules.update({"torchvision": tv, "torchvision.models": tvm, "torchvision.models.utils": tvu})
-    sys.path.insert(0, REF)
+    # The repo root holds a REGULAR package named `pytocr` (the alias of pytorchocr_amd); the reference's `pytocr` has no
+    # __init__.py (a namespace package), and a regular package anywhere on sys.path beats a namespace portion.  So the repo
+    # root (and the current directory, when it is the root) leave sys.path while the reference is imported.
+    saved = list(sys.path)
+    sys.path[:] = [REF] + [q for q in sys.path if os.path.abspath(q or os.getcwd()) != ROOT]
+    for name in [k for k in sys.modules if k == "pytocr" or k.startswith("pytocr.")]:
+        del sys.modules[name]
     from pytocr.modeling.architectures import build_model
+    assert os.path.abspath(sys.modules["pytocr.modeling.architectures"].__file__).startswith(os.path.abspath(REF)), "not the reference"
+    sys.path[:] = [REF] + saved
     return build_model
 
 
@@ -208,7 +216,41 @@ def gen_clipper_vectors():
     print("clipper vectors:", len(vecs))
 
 
+def gen_label_vectors():
+    """CTCLabelEncode / ClsLabelEncode results recorded from the reference classes (label_ops.py is loaded BY FILE PATH: its package
+    __init__ needs cv2).  DetLabelEncode is not recorded: the reference's uses np.bool, which numpy 2 no longer has."""
+    _import_reference_models()                       # puts the reference's pytocr (for pytocr.utils.logging) on the path
+    spec = importlib.util.spec_from_file_location("ref_label_ops", os.path.join(REF, "pytocr/data/imaug/label_ops.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    dict_path = os.path.join(REF, "pytocr/utils/char_dict_6623.txt")
+    cases = []
+    for name, kw in (("char_dict_6623", dict(max_text_length=25, character_dict_path=dict_path, use_space_char=False)),
+                     ("default36", dict(max_text_length=10, character_dict_path=None, use_space_char=False)),
+                     ("char_dict_6623_cn2en_space", dict(max_text_length=12, character_dict_path=dict_path, use_space_char=True, cn2en=True))):
+        enc = mod.CTCLabelEncode(**kw)
+        chars = enc.character
+        texts = ["0", "Hello", "hello world", "", "x" * 30, chars[1] + chars[min(100, len(chars) - 1)] + chars[-1], "a（b）：c", "\u2603abc", "\u2603"]
+        for t in texts:
+            r = enc({"label": t})
+            cases.append({"enc": name, "kw": {k: v for k, v in kw.items() if k != "character_dict_path"}, "text": t,
+                          "out": None if r is None else {"label": r["label"].tolist(), "length": int(r["length"]),
+                                                         "ace_nonzero": {str(i): int(v) for i, v in enumerate(r["label_ace"].tolist()) if v}},
+                          "nclass": len(chars)})
+    cls = mod.ClsLabelEncode(label_list=["0", "180"])
+    for lab in ("0", "180", "90"):
+        r = cls({"label": lab})
+        cases.append({"enc": "cls", "text": lab, "out": None if r is None else r["label"]})
+    with open(os.path.join(GOLD, "label_encode.json"), "w", encoding="utf-8") as f:
+        json.dump(cases, f, ensure_ascii=False, indent=0)
+    print("label-encode vectors:", len(cases))
+
+
 if __name__ == "__main__":
+    if "--labels-only" in sys.argv:
+        gen_label_vectors()
+        sys.exit(0)
     if "--clipper-only" not in sys.argv:
         main()
     gen_clipper_vectors()
+    gen_label_vectors()
