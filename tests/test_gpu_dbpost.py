@@ -1,8 +1,9 @@
 """GPU DB post-process against the C oracle on identical probability maps: boxes bit-exact (-m gpu).
 
-Candidates whose unclip distance is < 0.75 px are the documented exception (Clipper's integer union clean-up of
-sub-pixel slivers is not reproduced): the GPU flags them (flags bit 0) and they are compared against the
-restated offset instead of the real Clipper."""
+The oracle's unclip step runs THE REFERENCE'S OWN CLIPPER (oracle/_ref: the reference's clipper.cpp compiled as it lies) for every
+candidate.  Candidates whose unclip distance is < 0.75 px are the documented exception (Clipper's integer union clean-up of
+sub-pixel slivers is not reproduced): the GPU flags them (flags bit 0); where such a sliver differs from the
+real Clipper it must equal the restated offset, and the count is bounded (test_zz_sliver_exception_rate)."""
 import ctypes as C
 
 import numpy as np
@@ -42,40 +43,62 @@ def _debug(img, W):
     return tot.value, res, cands, info
 
 
+SLIVER_STATS = {"borders": 0, "thin": 0, "thin_differs_from_real_clipper": 0}
+
+
 def _compare(maps, src_wh, thresh=0.3, box_thresh=0.5, ratio=1.7, strict=True):
+    """GPU against the oracle WITH THE REFERENCE'S OWN CLIPPER (oracle/_ref, compiled from the reference's clipper.cpp) in its
+    unclip step, border by border.  The one documented exception: a candidate whose unclip distance is
+    below 0.75 px -- Clipper's integer union clean-up of such sub-pixel slivers is not reproduced -- may differ from the real
+    Clipper; it must then equal the oracle with the restated offset, it must be flagged (flags bit 0), and it is counted."""
     n, H, W = maps.shape
     got, flags = _gpu(maps, src_wh, thresh, box_thresh, ratio)
-    dbpost.use_reference_clipper(False)
+    have_ref = dbpost.ref_lib() is not None
     nthin = 0
     for i in range(n):
         bm = dbpost.binarize(maps[i], thresh)
-        exp, dbg, ncont = dbpost.boxes_from_bitmap(maps[i], bm, box_thresh, ratio, src_wh[i][0], src_wh[i][1], True)
+        dbpost.use_reference_clipper(False)
+        exp_r, dbg_r, ncont = dbpost.boxes_from_bitmap(maps[i], bm, box_thresh, ratio, src_wh[i][0], src_wh[i][1], True)
+        if have_ref:
+            assert dbpost.use_reference_clipper(True)
+            exp, dbg, _ = dbpost.boxes_from_bitmap(maps[i], bm, box_thresh, ratio, src_wh[i][0], src_wh[i][1], True)
+            dbpost.use_reference_clipper(False)
+        else:
+            exp, dbg = exp_r, dbg_r
         tot, res, cands, info = _debug(i, W)
         msg = ""
+        sliver_diff = 0
         # the GPU stops counting once the bottom strip alone holds the 1000 borders the reference keeps
         if (tot != ncont) if ncont < 1000 else (tot < 1000 or tot > ncont):
             msg = "image %d: %d borders on the GPU, %d in the oracle" % (i, tot, ncont)
         else:
             for k in range(min(tot, 1000)):
-                d, r = dbg[k], res[k]
+                d, r, dr = dbg[k], res[k], dbg_r[k]
                 trig = d.trig_y * W + d.trig_x
                 if cands[k].p != trig or cands[k].is_hole != d.is_hole or info[k].npts != d.npts:
                     msg = "image %d border %d: start/kind/npts (%d,%d,%d) vs oracle (%d,%d,%d)" % (
                         i, k, cands[k].p, cands[k].is_hole, info[k].npts, trig, d.is_hole, d.npts)
                     break
-                if r.status != d.status:
-                    msg = "image %d border %d: status %d vs oracle %d (score %r vs %r, rect %r vs %r)" % (
-                        i, k, r.status, d.status, r.score, d.score, list(r.rect), list(d.rect))
-                    break
-                if d.status == 0 and list(r.box) != list(d.box):
-                    msg = "image %d border %d: box %r vs oracle %r" % (i, k, list(r.box), list(d.box))
-                    break
-                if d.status in (0, 4, 5) and d.distance < 0.75:
-                    nthin += 1
+                SLIVER_STATS["borders"] += 1
+                thin = dr.status in (0, 4, 5) and dr.distance < 0.75
+                nthin += thin
+                SLIVER_STATS["thin"] += thin
+                same_real = r.status == d.status and (d.status != 0 or list(r.box) == list(d.box))
+                if same_real:
+                    continue
+                same_rest = r.status == dr.status and (dr.status != 0 or list(r.box) == list(dr.box))
+                if thin and same_rest:                      # the documented sliver exception
+                    sliver_diff += 1
+                    SLIVER_STATS["thin_differs_from_real_clipper"] += 1
+                    continue
+                msg = "image %d border %d: status %d box %r vs oracle (real Clipper) %d %r (score %r vs %r, rect %r vs %r, distance %r)" % (
+                    i, k, r.status, list(r.box), d.status, list(d.box), r.score, d.score, list(r.rect), list(d.rect), d.distance)
+                break
         assert not msg, msg
-        assert got[i].dtype == np.int16 and got[i].shape == (len(exp), 4, 2)
-        assert np.array_equal(got[i].astype(np.int32), exp), "image %d: boxes differ" % i
-        assert bool(flags[i] & 1) == any(d.status in (0, 4, 5) and d.distance < 0.75 for d in dbg)
+        want = exp_r if sliver_diff else exp
+        assert got[i].dtype == np.int16 and got[i].shape == (len(want), 4, 2)
+        assert np.array_equal(got[i].astype(np.int32), want), "image %d: boxes differ" % i
+        assert bool(flags[i] & 1) == any(d.status in (0, 4, 5) and d.distance < 0.75 for d in dbg_r)
     return got, flags, nthin
 
 
@@ -219,3 +242,12 @@ def test_random_scenes_bit_exact(seed):
     maps = np.stack([_random_scene(rng, h, w) for _ in range(n)])
     src = [[int(rng.integers(20, 2000)), int(rng.integers(20, 2000))] for _ in range(n)]
     _compare(maps, src, box_thresh=float(rng.choice([0.3, 0.5, 0.7])), ratio=float(rng.choice([1.5, 1.7, 2.0])))
+
+
+def test_zz_sliver_exception_rate():
+    """runs last in this file: over every border compared above, how many sub-0.75-px slivers differed from the real Clipper"""
+    if dbpost.ref_lib() is None:
+        pytest.skip("oracle/_ref not present")
+    print("borders %(borders)d, slivers %(thin)d, slivers differing from the reference's Clipper %(thin_differs_from_real_clipper)d" % SLIVER_STATS)
+    assert SLIVER_STATS["borders"] > 10000
+    assert SLIVER_STATS["thin_differs_from_real_clipper"] <= max(5, 0.03 * SLIVER_STATS["thin"])
