@@ -122,6 +122,13 @@ int ptocr_db_head_tail_f32(const float *d_x, const float *d_w1, const float *d_b
  * d_w f32[k*k][C] (tap-major), pad = (k-1)/2.  (MobileNetV3 InvertedResidual.conv2, det_mobilenet_v3.py:123-126) */
 int ptocr_dwconv_f32(const float *d_x, const float *d_w, const float *d_bias, float *d_y, int N, int H, int W, int C, int k,
                      int stride, int act, void *stream);
+/* the same with separate vertical / horizontal strides (the recognition-style MobileNetV3 of the direction classifier strides its
+ * depthwise convs by (s, 1): pytocr/modeling/backbones/rec_mobilenet_v3.py:128-131) */
+int ptocr_dwconv2_f32(const float *d_x, const float *d_w, const float *d_bias, float *d_y, int N, int H, int W, int C, int k,
+                      int stride_h, int stride_w, int act, void *stream);
+/* Direction-classifier head behind that backbone's AvgPool2d(2, 2) (rec_mobilenet_v3.py:221,266 + heads/cls_head.py:16-29):
+ * mean over the 2x2 blocks that fit, Linear(C -> K), softmax.  d_x f32[N,H,W,C], d_w f32[K][C], d_b f32[K], K <= 64 -> d_y f32[N][K]. */
+int ptocr_cls_head_f32(const float *d_x, const float *d_w, const float *d_b, float *d_y, int N, int H, int W, int C, int K, void *stream);
 /* Squeeze-Excitation (det_mobilenet_v3.py:67-85): x[n,:,:,c] *= hardsigmoid(fc2(relu(fc1(mean_hw(x))))) in place.
  * d_w1 f32[S][C], d_b1 f32[S], d_w2 f32[C][S], d_b2 f32[C]; d_work: N*(ceil(H*W/2048)+1)*C floats. C <= 1024, S <= 256. */
 int ptocr_se_scale_f32(float *d_x, const float *d_w1, const float *d_b1, const float *d_w2, const float *d_b2, float *d_work,
@@ -215,7 +222,9 @@ int ptocr_dbpost_debug_labels(ptocr_dbpost_t h, int img, int H, int W, int32_t *
 
 /* ---- pre-process next to the path --------------------------------------------------------------
  * Item descriptors live in device memory (arrays of the structs below, natural C layout). */
-typedef struct { long src_off; int sh, sw; int rh, rw; long dst_off; int dh, dw; } ptocr_pre_item;
+typedef struct { long src_off; int sh, sw; int rh, rw; long dst_off; int dh, dw; int flip; int pad_; } ptocr_pre_item;
+/* flip = 1 reads the source rotated by 180 degrees (run_ocr.py:209-211: a line the direction classifier calls "180").
+ * The classifier's own input (ClsResizeImg, rec_img_aug.py:29-37) is mode 0 with mean = std = 0.5. */
 /* Batched u8 HxWx3 (BGR) -> cv2.resize(INTER_LINEAR) to rh x rw -> fp32 f32[dh][dw][cpad], zero beyond (rh, rw).
  * mode 0: 3 channels (RGB order if swap_rb) as (x/255 - mean)/std  (DetResizeForTest+ToTensor+Normalize, operators.py:41-112,155-252)
  * mode 1: BGR2GRAY then (x/255 - 0.5)/0.5 in channel 0                (resize_norm_img, rec_img_aug.py:108-134) */

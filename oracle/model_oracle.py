@@ -152,6 +152,39 @@ _MBV3_ACT_STRIDE = {
 }
 
 
+# small-variant rows of the recognition-style table (rec_mobilenet_v3.py:299-312): kernel, SE, activation, stride
+_REC_SMALL = [(3, True, "RE", 2), (3, False, "RE", 2), (3, False, "RE", 1), (5, True, "HS", 1), (5, True, "HS", 1), (5, True, "HS", 1),
+              (5, True, "HS", 1), (5, True, "HS", 1), (5, True, "HS", 2), (5, True, "HS", 1), (5, True, "HS", 1)]
+
+
+def cls_mbv3_small_forward(sd, x, return_feats=False):
+    """Direction classifier: recognition-style MobileNetV3-small (rec_mobilenet_v3.py:106-152 block with the depthwise conv striding
+    (s, 1); :205-222,265-268 features + AvgPool2d(2, 2)) and ClsHead (heads/cls_head.py:16-29).  Channel widths come from the
+    state_dict, activations / strides from the table."""
+    with torch.no_grad():
+        p = "backbone.features."
+        x = _cba_mb(sd, p + "0", x, 2, 1, "HS")
+        for i, (k, _, act, stride) in enumerate(_REC_SMALL, 1):
+            b = p + str(i)
+            cin = x.shape[1]
+            exp = _t(sd, b + ".conv2.0.weight").shape[0]
+            assert _t(sd, b + ".conv2.0.weight").shape[2] == k
+            out = _cba_mb(sd, b + ".conv1", x, 1, 1, act) if (b + ".conv1.0.weight") in sd else x
+            out = _cba_mb(sd, b + ".conv2", out, (stride, 1), exp, act)
+            if (b + ".se.fc1.weight") in sd:
+                sc = F.adaptive_avg_pool2d(out, 1)
+                sc = F.relu(F.conv2d(sc, _t(sd, b + ".se.fc1.weight"), _t(sd, b + ".se.fc1.bias")))
+                sc = F.hardsigmoid(F.conv2d(sc, _t(sd, b + ".se.fc2.weight"), _t(sd, b + ".se.fc2.bias")))
+                out = sc * out
+            out = _cba_mb(sd, b + ".conv3", out, 1, 1, None)
+            x = out + x if (stride == 1 and cin == out.shape[1]) else out
+        x = _cba_mb(sd, p + str(len(_REC_SMALL) + 1), x, 1, 1, "HS")
+        feat = F.avg_pool2d(x, 2, 2)
+        logits = F.linear(torch.flatten(F.adaptive_avg_pool2d(feat, 1), 1), _t(sd, "head.fc.weight"), _t(sd, "head.fc.bias"))
+        probs = F.softmax(logits, dim=1)
+    return {"probs": probs, "backbone_out": feat} if return_feats else probs
+
+
 def dbnet_forward(sd, x, return_feats=False):
     """DBNet with whichever backbone the state_dict holds (ResNet-18 or MobileNetV3-small x1.0)."""
     with torch.no_grad():

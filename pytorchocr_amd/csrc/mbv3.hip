@@ -14,7 +14,7 @@ __device__ __forceinline__ float act1(float v, int act) {
 
 // one thread per (output pixel, 4 channels); consecutive threads walk channels, so loads/stores are 16 B coalesced
 __global__ __launch_bounds__(256) void dwconv_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
-                                                     float *__restrict__ y, int H, int W, int C4, int k, int stride, int Ho, int Wo, int act, long total) {
+                                                     float *__restrict__ y, int H, int W, int C4, int k, int stride, int stride_w, int Ho, int Wo, int act, long total) {
     const int pad = (k - 1) / 2;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4);
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float *__restrict__ x
             const int iy = oy * stride - pad + a;
             if ((unsigned)iy >= (unsigned)H) continue;
             for (int b = 0; b < k; b++) {
-                const int ix = ox * stride - pad + b;
+                const int ix = ox * stride_w - pad + b;
                 if ((unsigned)ix >= (unsigned)W) continue;
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(x + (((n * H + iy) * W + ix) * (long)C4 + c) * 4);
                 const f32x4 ww = *reinterpret_cast<const f32x4 *>(w + ((long)(a * k + b) * C4 + c) * 4);
@@ -113,16 +113,59 @@ static inline int grid_cap(long total, int block) {
 
 using namespace ptocr;
 
-extern "C" int ptocr_dwconv_f32(const float *d_x, const float *d_w, const float *d_bias, float *d_y, int N, int H, int W, int C, int k,
-                                int stride, int act, void *stream) {
-    PT_CHECK(d_x && d_w && d_bias && d_y && C % 4 == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2) && act >= 0 && act <= 2,
-             "ptocr_dwconv_f32: need C %% 4 == 0, k in {3,5}, stride in {1,2}");
+extern "C" int ptocr_dwconv2_f32(const float *d_x, const float *d_w, const float *d_bias, float *d_y, int N, int H, int W, int C, int k,
+                                 int stride_h, int stride_w, int act, void *stream) {
+    PT_CHECK(d_x && d_w && d_bias && d_y && C % 4 == 0 && (k == 3 || k == 5) && (stride_h == 1 || stride_h == 2) && (stride_w == 1 || stride_w == 2) &&
+             act >= 0 && act <= 2, "ptocr_dwconv2_f32: need C %% 4 == 0, k in {3,5}, strides in {1,2}");
     const int pad = (k - 1) / 2;
-    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    const int Ho = (H + 2 * pad - k) / stride_h + 1, Wo = (W + 2 * pad - k) / stride_w + 1;
     const long total = (long)N * Ho * Wo * (C / 4);
     hipLaunchKernelGGL(dwconv_kernel, dim3(grid_cap(total, 256)), dim3(256), 0, (hipStream_t)stream, d_x, d_w, d_bias, d_y, H, W, C / 4, k,
-                       stride, Ho, Wo, act, total);
+                       stride_h, stride_w, Ho, Wo, act, total);
     return launch_ok("dwconv_kernel");
+}
+
+extern "C" int ptocr_dwconv_f32(const float *d_x, const float *d_w, const float *d_bias, float *d_y, int N, int H, int W, int C, int k,
+                                int stride, int act, void *stream) {
+    return ptocr_dwconv2_f32(d_x, d_w, d_bias, d_y, N, H, W, C, k, stride, stride, act, stream);
+}
+
+// ClsHead (pytocr/modeling/heads/cls_head.py:16-29) behind the recognition-style MobileNetV3's AvgPool2d(2, 2)
+// (rec_mobilenet_v3.py:221,266): mean over the 2x2 blocks that fit (a trailing odd row / column is dropped, as the pool's floor
+// does), then over the blocks -- both are equal-weight means, so one mean over the cropped map -- then Linear + softmax.
+// one workgroup per image; x f32[N][H][W][C] (C % 4 == 0), w f32[K][C], b f32[K], K <= 64 -> y f32[N][K]
+__global__ __launch_bounds__(256) void cls_head_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b,
+                                                       float *__restrict__ y, int H, int W, int C, int K) {
+    __shared__ float mean[1024], logit[64];
+    const int n = blockIdx.x;
+    const int Hc = H & ~1, Wc = W & ~1;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int yy = 0; yy < Hc; yy++)
+            for (int xx = 0; xx < Wc; xx++) s += x[(((long)n * H + yy) * W + xx) * C + c];
+        mean[c] = s / (float)(Hc * Wc);
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+        float a = b[threadIdx.x];
+        for (int c = 0; c < C; c++) a += w[(long)threadIdx.x * C + c] * mean[c];
+        logit[threadIdx.x] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+        float m = -INFINITY, s = 0.f;
+        for (int k2 = 0; k2 < K; k2++) m = fmaxf(m, logit[k2]);
+        for (int k2 = 0; k2 < K; k2++) s += expf(logit[k2] - m);
+        y[(long)n * K + threadIdx.x] = expf(logit[threadIdx.x] - m) / s;
+    }
+}
+
+extern "C" int ptocr_cls_head_f32(const float *d_x, const float *d_w, const float *d_b, float *d_y, int N, int H, int W, int C, int K,
+                                  void *stream) {
+    PT_CHECK(d_x && d_w && d_b && d_y && N >= 1 && H >= 2 && W >= 2 && C >= 1 && C <= 1024 && K >= 1 && K <= 64,
+             "ptocr_cls_head_f32: need H, W >= 2, C <= 1024, K <= 64");
+    hipLaunchKernelGGL(cls_head_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, d_x, d_w, d_b, d_y, H, W, C, K);
+    return launch_ok("cls_head_kernel");
 }
 
 extern "C" int ptocr_se_scale_f32(float *d_x, const float *d_w1, const float *d_b1, const float *d_w2, const float *d_b2, float *d_work,

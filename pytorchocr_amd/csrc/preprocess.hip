@@ -14,6 +14,8 @@ struct PreItem {            // one image / crop
     int rh, rw;             // resized size (<= dh, dw); the rest of the destination is zero padding
     long dst_off;           // float offset of the destination f32[dh][dw][cpad] inside d_dst
     int dh, dw;
+    int flip;               // 1: the source is read rotated by 180 degrees (cv2.rotate(ROTATE_180) of run_ocr.py:209-211 before the resize)
+    int pad_;
 };
 
 __device__ __forceinline__ void lin_coef(int d, int sn, double scale, int *s0, int *s1, int *a0, int *a1) {
@@ -45,6 +47,10 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t *__restri
         int x0, x1, ax0, ax1, y0, y1, by0, by1;
         lin_coef(x, it.sw, (double)it.sw / it.rw, &x0, &x1, &ax0, &ax1);
         lin_coef(y, it.sh, (double)it.sh / it.rh, &y0, &y1, &by0, &by1);
+        if (it.flip) {
+            x0 = it.sw - 1 - x0; x1 = it.sw - 1 - x1;
+            y0 = it.sh - 1 - y0; y1 = it.sh - 1 - y1;
+        }
         const uint8_t *p00 = s + ((long)y0 * it.sw + x0) * 3, *p01 = s + ((long)y0 * it.sw + x1) * 3;
         const uint8_t *p10 = s + ((long)y1 * it.sw + x0) * 3, *p11 = s + ((long)y1 * it.sw + x1) * 3;
         const bool same = it.rh == it.sh && it.rw == it.sw;

@@ -1,10 +1,10 @@
 """create_operators / transform: mirror of reference pytocr/data/imaug/__init__.py:19-48 for the inference operators
 (Global keys are merged into every operator's kwargs, hence the **kwargs everywhere)."""
-from .imaug import DecodeImage, DetResizeForTest, KeepKeys, Normalize, RecResizeImg, RecResizeImgForTest, ToTensor  # noqa: F401
+from .imaug import ClsResizeImg, DecodeImage, DetResizeForTest, KeepKeys, Normalize, RecResizeImg, RecResizeImgForTest, ToTensor  # noqa: F401
 from .label_ops import ClsLabelEncode, CTCLabelEncode, DetLabelEncode  # noqa: F401
 
 _OPS = {"DecodeImage": DecodeImage, "DetResizeForTest": DetResizeForTest, "ToTensor": ToTensor, "Normalize": Normalize,
-        "KeepKeys": KeepKeys, "RecResizeImg": RecResizeImg, "RecResizeImgForTest": RecResizeImgForTest,
+        "KeepKeys": KeepKeys, "RecResizeImg": RecResizeImg, "ClsResizeImg": ClsResizeImg, "RecResizeImgForTest": RecResizeImgForTest,
         "DetLabelEncode": DetLabelEncode, "CTCLabelEncode": CTCLabelEncode, "ClsLabelEncode": ClsLabelEncode}
 
 

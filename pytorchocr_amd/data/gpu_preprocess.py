@@ -12,7 +12,7 @@ from .. import _lib
 
 class PreItem(C.Structure):
     _fields_ = [("src_off", C.c_long), ("sh", C.c_int), ("sw", C.c_int), ("rh", C.c_int), ("rw", C.c_int),
-                ("dst_off", C.c_long), ("dh", C.c_int), ("dw", C.c_int)]
+                ("dst_off", C.c_long), ("dh", C.c_int), ("dw", C.c_int), ("flip", C.c_int), ("pad_", C.c_int)]
 
 
 class WarpItem(C.Structure):
@@ -32,7 +32,7 @@ def _u8_dev(img, device):
 
 
 PRE_DT = np.dtype([("src_off", "<i8"), ("sh", "<i4"), ("sw", "<i4"), ("rh", "<i4"), ("rw", "<i4"), ("dst_off", "<i8"),
-                   ("dh", "<i4"), ("dw", "<i4")], align=True)
+                   ("dh", "<i4"), ("dw", "<i4"), ("flip", "<i4"), ("pad_", "<i4")], align=True)
 WARP_DT = np.dtype([("minv", "<f8", (9,)), ("left", "<i4"), ("top", "<i4"), ("cw", "<i4"), ("ch", "<i4"), ("rot90", "<i4"),
                     ("img", "<i4"), ("dst_off", "<i8")], align=True)
 assert PRE_DT.itemsize == C.sizeof(PreItem) and WARP_DT.itemsize == C.sizeof(WarpItem)
@@ -120,10 +120,20 @@ def warp_crops_batch(imgs_dev, boxes_per_image):
     return buf, metas
 
 
-def rec_preprocess(buf, metas, image_shape, device):
-    """packed BGR u8 crops -> f32[n, imgH, imgW, 4] (gray in channel 0, (x/255-0.5)/0.5, right zero padding)."""
+def cls_preprocess(buf, metas, image_shape, device, swap_rb=True):
+    """packed BGR u8 crops -> f32[n, imgH, imgW, 4] direction-classifier input: ClsResizeImg (rec_img_aug.py:29-37,108-134) --
+    aspect-keeping resize to height imgH, 3 channels (RGB when swap_rb), (x/255-0.5)/0.5, right zero padding."""
+    return rec_preprocess(buf, metas, image_shape, device, _mode3=(1 if swap_rb else 0))
+
+
+def rec_preprocess(buf, metas, image_shape, device, flip=None, _mode3=None):
+    """packed BGR u8 crops -> f32[n, imgH, imgW, 4] (gray in channel 0, (x/255-0.5)/0.5, right zero padding).
+    flip: optional bool per valid crop -- read that crop rotated by 180 degrees (the classifier said "180")."""
     imgC, imgH, imgW = image_shape
-    assert imgC == 1, "the GPU recognition pre-process implements the GRAY (1-channel) CRNN input"
+    if _mode3 is None:
+        assert imgC == 1, "the GPU recognition pre-process implements the GRAY (1-channel) CRNN input"
+    else:
+        assert imgC == 3, "the GPU classifier pre-process implements the 3-channel input"
     valid = [m for m in metas if m is not None]
     n = len(valid)
     out = torch.empty((max(n, 1), imgH, imgW, 4), dtype=torch.float32, device=device)
@@ -138,7 +148,14 @@ def rec_preprocess(buf, metas, image_shape, device):
     items["rh"], items["rw"] = imgH, np.maximum(rw, 1)
     items["dst_off"] = np.arange(n, dtype=np.int64) * (imgH * imgW * 4)
     items["dh"], items["dw"] = imgH, imgW
+    if flip is not None:
+        items["flip"] = np.asarray(flip, np.int32)
     d_items = _items_dev(items, device)
-    _lib.check(_lib.lib().ptocr_preprocess_u8_f32(_lib.ptr(buf), _lib.ptr(out), _lib.ptr(d_items), n, imgH * imgW, 1, 0, 4, None, None,
-                                                  _lib.cur_stream()), "ptocr_preprocess_u8_f32")
+    if _mode3 is None:
+        _lib.check(_lib.lib().ptocr_preprocess_u8_f32(_lib.ptr(buf), _lib.ptr(out), _lib.ptr(d_items), n, imgH * imgW, 1, 0, 4, None, None,
+                                                      _lib.cur_stream()), "ptocr_preprocess_u8_f32")
+    else:
+        half = (C.c_float * 3)(0.5, 0.5, 0.5)
+        _lib.check(_lib.lib().ptocr_preprocess_u8_f32(_lib.ptr(buf), _lib.ptr(out), _lib.ptr(d_items), n, imgH * imgW, 0, int(_mode3), 4, half,
+                                                      half, _lib.cur_stream()), "ptocr_preprocess_u8_f32")
     return out

@@ -1,6 +1,6 @@
 """Inference pre-process operators (host side, numpy).  Mirrors of reference pytocr/data/imaug/operators.py
 (`DecodeImage` :14-38, `ToTensor` :41-72, `Normalize` :75-112, `KeepKeys` :115-124, `DetResizeForTest` :155-252) and
-rec_img_aug.py (`RecResizeImg` :40-53, `resize_norm_img` :108-134).
+rec_img_aug.py (`ClsResizeImg` :29-37, `RecResizeImg` :40-53, `resize_norm_img` :108-134).
 
 cv2 is not a dependency here: `resize_bilinear` restates cv2.resize(INTER_LINEAR) for uint8 images in its
 fixed-point form (11-bit coefficients, half-pixel centres).  UNPINNED against OpenCV (absent from the image).
@@ -192,6 +192,17 @@ class RecResizeImg(object):
 
     def __call__(self, data):
         data["image"] = resize_norm_img(data["image"], self.image_shape, resized_w=None, padding=self.padding)
+        return data
+
+
+class ClsResizeImg(object):
+    """reference rec_img_aug.py:29-37: the recognition resize (aspect kept, right zero padding) at the classifier's shape"""
+
+    def __init__(self, image_shape, **kwargs):
+        self.image_shape = image_shape
+
+    def __call__(self, data):
+        data["image"] = resize_norm_img(data["image"], self.image_shape)
         return data
 
 

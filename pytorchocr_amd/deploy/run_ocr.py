@@ -3,7 +3,9 @@ per box perspective crop (`get_part_img`), rotate 90 deg when h >= 1.5 w -> reco
 
 The reference recognises every box with a batch-1 CRNN forward and one device->host sync per box
 (run_ocr.py:187-229); here all crops of an image go through the CRNN as ONE batch.  Per-box results are the same
-(the network is batch-independent).  The optional direction classifier (cls) is not built."""
+(the network is batch-independent).  With a direction classifier (cls_cfg + cls_ckpt, run_ocr.py:130-165,192-211) every crop
+is classified first -- again all crops in one batch -- and the crops it calls "180" are rotated by 180 degrees before recognition
+(on the GPU paths the rotation is a flag of the recognition pre-process, no copy)."""
 import os
 
 import numpy as np
@@ -11,6 +13,7 @@ import torch
 
 from ..utils.warp import get_part_img
 from .common import read_image_bgr
+from .infer_cls import Clser
 from .infer_det import Deter
 from .infer_rec import Recer
 
@@ -19,10 +22,26 @@ class OCRer(object):
     def __init__(self, det_cfg, det_ckpt, rec_cfg, rec_ckpt, cls_cfg=None, cls_ckpt=None, character_dict_path=None, gpu_id=0,
                  gpu_preprocess=False) -> None:
         self.gpu_preprocess = gpu_preprocess
-        if cls_cfg is not None and cls_ckpt is not None:
-            raise NotImplementedError("pytorchocr_amd run_ocr: the optional direction classifier is outside the built hot path")
         self.det = Deter(det_cfg, det_ckpt, gpu_id, gpu_preprocess=gpu_preprocess)
         self.rec = Recer(rec_cfg, rec_ckpt, character_dict_path, gpu_id)
+        # the reference builds the classifier only when BOTH are given (run_ocr.py:131); a dict config stands in for the yml path
+        self.cls = Clser(cls_cfg, cls_ckpt, gpu_id) if cls_cfg is not None and (cls_ckpt is not None or isinstance(cls_cfg, dict)) else None
+
+    def _cls_flips(self, buf, metas, dev):
+        """packed crops -> bool per valid crop: the classifier's label is "180" (one batched forward)"""
+        from ..data.gpu_preprocess import cls_preprocess
+        from ..data.imaug import ClsResizeImg
+        if self.cls.cls_img_mode == "GRAY":
+            raise NotImplementedError("the GPU classifier pre-process implements the 3-channel input")
+        shape = [o for o in self.cls.cls_ops if isinstance(o, ClsResizeImg)][0].image_shape
+        x4 = cls_preprocess(buf, metas, shape, dev, swap_rb=self.cls.cls_img_mode == "RGB")
+        if x4.shape[0] == 0:
+            return np.zeros(0, bool)
+        flips = []
+        for c0 in range(0, int(x4.shape[0]), 1024):
+            res = self.cls.cls_post_process_class(self.cls.clser.forward_nhwc4(x4[c0:c0 + 1024]))
+            flips += [lab == "180" for lab, _ in res]
+        return np.asarray(flips, bool)
 
     @torch.no_grad()
     def run_gpu(self, img_path):
@@ -38,7 +57,8 @@ class OCRer(object):
         shape = [o for o in self.rec.rec_ops if isinstance(o, RecResizeImg)][0].image_shape
         img_dev = torch.from_numpy(np.ascontiguousarray(img)).to(self.rec.rec_device)
         buf, metas = warp_crops(img_dev, boxes)
-        x4 = rec_preprocess(buf, metas, shape, self.rec.rec_device)
+        flip = self._cls_flips(buf, metas, self.rec.rec_device) if self.cls is not None else None
+        x4 = rec_preprocess(buf, metas, shape, self.rec.rec_device, flip=flip)
         keep = [b for b, m in zip(boxes, metas) if m is not None]
         res = self.rec.rec_post_process_class(self.rec.recer.forward_greedy_nhwc4(x4)) if len(keep) else []
         return [[box, t, round(p, 2)] for box, (t, p) in zip(keep, res)]
@@ -79,7 +99,8 @@ class OCRer(object):
             boxes = [sort_boxes(r["points"]) for r in res]
             buf, metas = warp_crops_batch(stack, boxes)
             flat = [m for per in metas for m in per]
-            x_rec = rec_preprocess(buf, flat, shape, dev)
+            flip = self._cls_flips(buf, flat, dev) if self.cls is not None else None
+            x_rec = rec_preprocess(buf, flat, shape, dev, flip=flip)
             texts = []
             pend = None
             for c0 in range(0, int(x_rec.shape[0]), rec_batch):          # decode of chunk i overlaps the forward of chunk i+1
@@ -112,5 +133,7 @@ class OCRer(object):
             if h >= 1.5 * w:
                 part_img = np.rot90(part_img, 1)
             crops.append(np.ascontiguousarray(part_img))
+        if self.cls is not None:
+            crops = [np.ascontiguousarray(c[::-1, ::-1]) if lab == "180" else c for c, (lab, _) in zip(crops, self.cls.run_batch(crops))]
         texts = self.rec.run_batch(crops)
         return [[box, text, prob] for box, (text, prob) in zip(boxes, texts)]

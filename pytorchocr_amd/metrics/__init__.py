@@ -7,7 +7,7 @@ import numpy as np
 
 from .polygon import area, intersection_area, is_valid_simple, union_area
 
-__all__ = ["DetectionIoUEvaluator", "DetMetric", "RecMetric", "build_metric", "levenshtein"]
+__all__ = ["DetectionIoUEvaluator", "ClsMetric", "DetMetric", "RecMetric", "build_metric", "levenshtein"]
 
 
 class DetectionIoUEvaluator(object):
@@ -129,9 +129,33 @@ class RecMetric(object):
         self.correct_num, self.all_num, self.norm_edit_dis = 0, 0, 0
 
 
+class ClsMetric(object):
+    """reference pytocr/metrics/cls_metric.py:1-30: share of lines whose predicted direction equals the label"""
+
+    def __init__(self, main_indicator="acc", **kwargs):
+        self.main_indicator = main_indicator
+        self.reset()
+
+    def __call__(self, pred_label, *args, **kwargs):
+        preds, labels = pred_label
+        hits = sum(1 for (pred, _), (target, _) in zip(preds, labels) if pred == target)
+        n = min(len(preds), len(labels))
+        self.correct_num += hits
+        self.all_num += n
+        return {"acc": hits / n}
+
+    def get_metric(self):
+        acc = self.correct_num / self.all_num
+        self.reset()
+        return {"acc": acc}
+
+    def reset(self):
+        self.correct_num, self.all_num = 0, 0
+
+
 def build_metric(config):
     config = dict(config)
     name = config.pop("name")
-    support = {"DetMetric": DetMetric, "RecMetric": RecMetric}
+    support = {"DetMetric": DetMetric, "RecMetric": RecMetric, "ClsMetric": ClsMetric}
     assert name in support, "metric only support {} (pytorchocr_amd)".format(list(support))
     return support[name](**config)

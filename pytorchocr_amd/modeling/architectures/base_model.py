@@ -1,7 +1,7 @@
 """BaseModel: mirror of reference pytocr/modeling/architectures/base_model.py:12-73.
 
 Same config mutation (`in_channels` threaded through Backbone -> Neck -> Head), same `forward(x, data=None)`
-contract: det eval returns {"maps": f32[N,1,H,W]}, rec eval returns softmax f32[T,B,C];
+contract: det eval returns {"maps": f32[N,1,H,W]}, rec eval returns softmax f32[T,B,C], cls eval softmax f32[N,class_dim];
 `return_all_feats` adds "backbone_out" / "neck_out" (converted to NCHW like the reference's tensors).
 Internally activations stay NHWC on the device between backbone, neck and head.
 """
@@ -66,8 +66,11 @@ class BaseModel(nn.Module):
         return self._bf16
 
     def forward_nhwc4(self, x4):
-        """det models: f32[N,H,W,4] (the GPU pre-process output: RGB + zero channel, NHWC) -> {"maps": f32[N,1,H,W]}"""
+        """det models: f32[N,H,W,4] (the GPU pre-process output: RGB + zero channel, NHWC) -> {"maps": f32[N,1,H,W]};
+        cls models: the same input layout -> softmax f32[N, class_dim]"""
         feats = self.backbone.forward_nhwc(x4)
+        if self.model_type == "cls":
+            return self.head.forward_nhwc(feats)
         return self.head.forward_nhwc(self.neck.forward_nhwc(feats) if self.use_neck else feats)
 
     def forward(self, x, data=None):
@@ -86,6 +89,12 @@ class BaseModel(nn.Module):
             if self.return_all_feats:
                 y["backbone_out"] = [ops.nhwc_to_nchw(f)[:, :c] for f, c in zip(feats, self.backbone.out_channels)]
                 y["neck_out"] = ops.nhwc_to_nchw(neck) if self.use_neck else y["backbone_out"]
+        elif self.model_type == "cls":
+            feats = self.backbone.forward_nhwc(ops.nchw_to_nhwc(x, 4))
+            out = self.head.forward_nhwc(feats)                       # softmax f32[N, class_dim]
+            if self.return_all_feats:
+                y["backbone_out"] = self.backbone.avgpool(ops.nhwc_to_nchw(feats)[:, :self.backbone.out_channels])
+                y["neck_out"] = y["backbone_out"]
         else:
             feats = self.backbone.forward_nhwc(ops.nchw_to_nhwc(x, 4))
             neck = self.neck.forward_seq(feats) if self.use_neck else feats

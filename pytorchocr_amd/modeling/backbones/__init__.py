@@ -5,8 +5,9 @@ __all__ = ["build_backbone"]
 def build_backbone(config, model_type):
     from .det_mobilenet_v3 import MobileNetV3
     from .det_resnet import ResNet
+    from .rec_mobilenet_v3 import MobileNetV3 as RecMobileNetV3
     from .rec_vgg import VGG
-    support = {"det": {"ResNet": ResNet, "MobileNetV3": MobileNetV3}, "rec": {"VGG": VGG}}
+    support = {"det": {"ResNet": ResNet, "MobileNetV3": MobileNetV3}, "rec": {"VGG": VGG}, "cls": {"MobileNetV3": RecMobileNetV3}}
     if model_type not in support:
         raise NotImplementedError("pytorchocr_amd: model_type %r is outside the accelerated hot path" % model_type)
     config = dict(config)

@@ -248,7 +248,7 @@ class PackedDW:
         bp = torch.zeros(cp, dtype=torch.float64)
         bp[:c] = b
         self.w, self.b = wp.float().contiguous().to(device), bp.float().contiguous().to(device)
-        self.k, self.stride, self.act, self.c = k, conv.stride[0], _act_code(act), cp
+        self.k, self.stride, self.stride_w, self.act, self.c = k, conv.stride[0], conv.stride[1], _act_code(act), cp
 
 
 def dwconv(x, pd):
@@ -256,10 +256,21 @@ def dwconv(x, pd):
     N, H, W, Cc = x.shape
     assert Cc == pd.c
     pad = (pd.k - 1) // 2
-    Ho, Wo = (H + 2 * pad - pd.k) // pd.stride + 1, (W + 2 * pad - pd.k) // pd.stride + 1
+    Ho, Wo = (H + 2 * pad - pd.k) // pd.stride + 1, (W + 2 * pad - pd.k) // pd.stride_w + 1
     y = torch.empty((N, Ho, Wo, Cc), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().ptocr_dwconv_f32(_lib.ptr(x), _lib.ptr(pd.w), _lib.ptr(pd.b), _lib.ptr(y), N, H, W, Cc, pd.k, pd.stride,
-                                           pd.act, _lib.cur_stream()), "ptocr_dwconv_f32")
+    _lib.check(_lib.lib().ptocr_dwconv2_f32(_lib.ptr(x), _lib.ptr(pd.w), _lib.ptr(pd.b), _lib.ptr(y), N, H, W, Cc, pd.k, pd.stride, pd.stride_w,
+                                            pd.act, _lib.cur_stream()), "ptocr_dwconv2_f32")
+    return y
+
+
+def cls_head(x, w, b):
+    """x f32[N,H,W,Cp] -> softmax f32[N,K]: AvgPool2d(2,2) + AdaptiveAvgPool2d(1) + Linear + softmax (one kernel)"""
+    _require_cuda(x, "cls_head")
+    N, H, W, Cc = x.shape
+    K = w.shape[0]
+    y = torch.empty((N, K), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().ptocr_cls_head_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), N, H, W, Cc, K, _lib.cur_stream()),
+               "ptocr_cls_head_f32")
     return y
 
 

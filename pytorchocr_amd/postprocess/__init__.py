@@ -6,8 +6,9 @@ __all__ = ["build_post_process"]
 
 def build_post_process(config, global_config=None):
     from .db_postprocess import DBPostProcess
+    from .cls_postprocess import ClsPostProcess
     from .rec_postprocess import CTCLabelDecode
-    support = {"DBPostProcess": DBPostProcess, "CTCLabelDecode": CTCLabelDecode}
+    support = {"DBPostProcess": DBPostProcess, "CTCLabelDecode": CTCLabelDecode, "ClsPostProcess": ClsPostProcess}
     config = copy.deepcopy(config)
     name = config.pop("name")
     if global_config is not None:

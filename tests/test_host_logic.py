@@ -1,5 +1,6 @@
 """Host-side logic that needs no GPU: state_dict contract, BN folding / weight packing, config handling, decode."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -212,3 +213,41 @@ def test_pytocr_alias_package_resolves_the_reference_import_lines():
     assert o1 is o2                                        # an alias, not a second copy of the module state
     with pytest.raises(ModuleNotFoundError):
         import pytocr.losses  # noqa: F401
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cls_postprocess_and_metric_reference_vectors(gold_dir):
+    """ClsPostProcess / ClsMetric known answers recorded from the reference classes (tools/gen_golden.py gen_cls_vectors)"""
+    import json
+    import torch
+    from pytorchocr_amd.metrics import build_metric
+    from pytorchocr_amd.postprocess import build_post_process
+    g = json.load(open(os.path.join(gold_dir, "cls_post.json")))
+    pp = build_post_process({"name": "ClsPostProcess"}, {"label_list": ["0", "180"]})
+    table = np.asarray(g["table"], np.float32)
+    for preds in (table, torch.from_numpy(table)):
+        dec, lab = pp(preds, label=g["label"])
+        assert [[t, float(p)] for t, p in dec] == g["decoded"] and [[t, float(p)] for t, p in lab] == g["label_out"]
+    assert [[t, float(p)] for t, p in pp(table)] == g["decoded"]
+    met = build_metric({"name": "ClsMetric", "main_indicator": "acc"})
+    assert met((dec, lab)) == g["batch_metric"]
+    assert met.get_metric() == g["final_metric"] and met.all_num == 0
+
+
+def test_cls_model_has_the_reference_state_dict(contract):
+    from pytorchocr_amd.modeling.architectures import build_model
+    from pytorchocr_amd.utils.config import load_config
+    cfg = load_config(os.path.join(ROOT, "pytorchocr_amd", "configs", "cls", "cls_mbv3small.yml"))
+    sd = build_model(cfg["Architecture"]).state_dict()
+    assert {k: (tuple(v.shape), str(v.dtype)) for k, v in sd.items()} == contract["cls_mbv3s"]
+    assert list(sd) == list(contract["cls_mbv3s"])
+
+
+def test_cls_resize_img_pads_right():
+    from pytorchocr_amd.data import create_operators, transform
+    ops = create_operators([{"ClsResizeImg": {"image_shape": [3, 48, 192]}}, {"KeepKeys": {"keep_keys": ["image"]}}], {"label_list": ["0", "180"]})
+    img = (np.arange(24 * 50 * 3) % 251).astype(np.uint8).reshape(24, 50, 3)
+    x = transform({"image": img}, ops)[0]
+    assert tuple(x.shape) == (3, 48, 192) and float(x[:, :, 100:].abs().max()) == 0.0 and float(x[:, :, :100].abs().max()) > 0
+    assert float(x.min()) >= -1.0 and float(x.max()) <= 1.0

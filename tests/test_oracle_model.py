@@ -53,3 +53,21 @@ def test_mbv3_small_oracle_matches_reference(gold_dir, contract):
     sd = synth_state_dict(contract["det_mbv3s_db"])
     x = torch.from_numpy(synth_images(1, 3, 64, 96, seed=int(g["seed"])))
     assert np.abs(model_oracle.dbnet_forward(sd, x)["maps"].numpy() - g["maps"]).max() <= 1e-6
+
+
+def cls_state_dict(contract, g):
+    """the generator's weights: synthetic state_dict with the fc scaled and its bias zeroed (tools/gen_golden.py gen_cls_vectors)"""
+    sd = synth_state_dict(contract["cls_mbv3s"])
+    sd["head.fc.weight"] = (sd["head.fc.weight"] * np.float32(g["fc_scale"])).astype(np.float32)
+    sd["head.fc.bias"] = np.zeros_like(sd["head.fc.bias"])
+    return sd
+
+
+def test_cls_oracle_matches_reference(gold_dir, contract):
+    g = np.load(os.path.join(gold_dir, "cls_mbv3s_4x3x48x192.npz"))
+    sd = cls_state_dict(contract, g)
+    x = torch.from_numpy(synth_images(4, 3, 48, 192, seed=int(g["seed"])))
+    y = model_oracle.cls_mbv3_small_forward(sd, x, return_feats=True)
+    assert np.abs(y["backbone_out"].numpy() - g["backbone_out"]).max() <= 1e-5 * max(1.0, np.abs(g["backbone_out"]).max())
+    assert np.abs(y["probs"].numpy() - g["probs"]).max() <= 1e-6
+    assert 0.05 < g["probs"].min() and g["probs"].max() < 0.95            # not a saturated softmax

@@ -17,6 +17,8 @@ import os
 import sys
 import types
 
+import copy
+
 import numpy as np
 import torch
 
@@ -183,6 +185,52 @@ def main():
 
 
 
+CLS_MBV3S = dict(model_type="cls", algorithm="CLS", Transform=None,
+                 Backbone=dict(name="MobileNetV3", model_name="small", width_mult=0.35, use_se=True, pretrained=False, ckpt_path=None),
+                 Neck=None, Head=dict(name="ClsHead", class_dim=2))
+
+
+def gen_cls_vectors():
+    """direction classifier (configs/cls/cls_mbv3small.yml): state_dict contract, softmax and pooled backbone features of the
+    reference model on a seeded batch; ClsPostProcess / ClsMetric known answers from the reference classes"""
+    torch.manual_seed(0)
+    build_model = _import_reference_models()
+    m, shapes = build_with_synth(build_model, copy.deepcopy(CLS_MBV3S))
+    path = os.path.join(GOLD, "state_dict_contract.json")
+    contract = json.load(open(path))
+    contract["cls_mbv3s"] = {k: [list(sh), d] for k, (sh, d) in shapes.items()}
+    with open(path, "w") as f:
+        json.dump(contract, f, indent=0, sort_keys=False)
+    fc_scale = 0.25                                 # synth_state_dict's fc (made for the CTC head: bias[0] = 13) saturates a 2-class
+    with torch.no_grad():                           # softmax; with the bias zeroed and the weights scaled it discriminates
+        m.head.fc.weight.mul_(fc_scale)
+        m.head.fc.bias.zero_()
+    x = torch.from_numpy(synth_images(4, 3, 48, 192, seed=16))
+    m.return_all_feats = True
+    with torch.no_grad():
+        y = m(x)
+    def by_path(name, rel):                         # the packages' __init__ files need cv2 / shapely
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    ClsPostProcess = by_path("ref_cls_postprocess", "pytocr/postprocess/cls_postprocess.py").ClsPostProcess
+    ClsMetric = by_path("ref_cls_metric", "pytocr/metrics/cls_metric.py").ClsMetric
+    probs = y["head_out"].numpy()
+    np.savez_compressed(os.path.join(GOLD, "cls_mbv3s_4x3x48x192.npz"), seed=np.int64(16), probs=probs, fc_scale=np.float32(fc_scale),
+                        backbone_out=y["backbone_out"].numpy())
+    pp = ClsPostProcess(label_list=["0", "180"])
+    table = np.array([[0.9, 0.1], [0.2, 0.8], [0.5, 0.5], [0.49, 0.51]], np.float32)
+    dec, lab = pp(torch.from_numpy(table), label=[0, 1, 1, 0])
+    met = ClsMetric()
+    batch = met((dec, lab))
+    with open(os.path.join(GOLD, "cls_post.json"), "w") as f:
+        json.dump({"table": table.tolist(), "label": [0, 1, 1, 0], "decoded": [[t, float(p)] for t, p in dec],
+                   "label_out": [[t, float(p)] for t, p in lab], "batch_metric": batch, "final_metric": met.get_metric(),
+                   "model_decoded": [[t, float(p)] for t, p in pp(torch.from_numpy(probs))]}, f, indent=0)
+    print("cls vectors written; probs =", probs.tolist())
+
+
 def gen_clipper_vectors():
     """Unclip golden vectors from the reference's vendored Clipper (oracle/_ref): input int path, delta,
     full solution.  The float mini-boxes come from seeded rotated rectangles (reference UnClip,
@@ -247,6 +295,9 @@ def gen_label_vectors():
 
 
 if __name__ == "__main__":
+    if "--cls-only" in sys.argv:
+        gen_cls_vectors()
+        sys.exit(0)
     if "--labels-only" in sys.argv:
         gen_label_vectors()
         sys.exit(0)
