@@ -32,6 +32,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, den
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # same guide, dense bf16 matrix peak
 PEAK_HBM_GBPS = 8000.0             # same guide, HBM3E spec peak (6.3 TB/s measured achievable)
 WINOGRAD_GAIN = 2.25               # F(2x2,3x3): 16 multiplies instead of 36 per 2x2 output tile and channel pair
+WINOGRAD4_GAIN = 4.0               # F(4x4,3x3): 36 multiplies instead of 144 per 4x4 output tile and channel pair
 DET_TAIL_GFLOP_PER_IMG = 2.05      # ConvT 64->64 (1.93) + ConvT 64->1 (0.12) run in db_head_tail_kernel, not in the conv kernels
 CRNN_GFLOP_PER_LINE = 4.980
 POST_BYTES_PER_PIXEL = 18          # SURVEY 8d accounting of the DB post-process
@@ -197,14 +198,20 @@ def _max_over_ranks(dt, world, device):
 def _conv_profile(prof, labels):
     """HIP-event durations of the conv launches of the timed region, split into Winograd launches and the rest."""
     ms = [e0.elapsed_time(e1) for e0, e1 in prof]
-    wino_ms, wino_flops, n_wino = 0.0, 0.0, 0
+    wino_ms, n_wino = 0.0, 0
+    wino_flops = {"alg": 0.0, "exec": 0.0, "n4": 0, "ms4": 0.0}      # direct-convolution FLOPs and the FLOPs the MFMAs executed
     for lab, t in zip(labels, ms):
-        if lab.startswith("wino3x3"):
+        if lab.startswith("wino3x3") or lab.startswith("wino43x3"):
             n_, h_, w_, ci = [int(v) for v in lab.split()[1].split("->")[0].split("x")]
             co = int(lab.split("->")[1].split()[0])
+            four = lab.startswith("wino43x3")
             wino_ms += t
             n_wino += 1
-            wino_flops += 2.0 * n_ * h_ * w_ * ci * co * 9
+            f = 2.0 * n_ * h_ * w_ * ci * co * 9
+            wino_flops["alg"] += f
+            wino_flops["exec"] += f / (WINOGRAD4_GAIN if four else WINOGRAD_GAIN)
+            wino_flops["n4"] += int(four)
+            wino_flops["ms4"] += t if four else 0.0
     return sum(ms), len(ms), wino_ms, wino_flops, n_wino
 
 
@@ -217,16 +224,20 @@ def _profile_json(name):
 
 
 def _wino_roofline(wino_ms, wino_flops, n_wino, steps, what):
-    """`achieved` / `frac` = what the matrix pipe EXECUTED (Winograd F(2x2,3x3) runs 1/2.25 of the direct-convolution
-    multiplies): a utilisation, <= 1.  The algorithmic (direct-convolution) rate of the same launches is reported
-    beside it as `algorithmic_tflops` -- it can exceed the peak because of the algorithmic gain, and is not a fraction."""
-    alg = wino_flops / (wino_ms * 1e-3) / 1e12 if wino_ms > 0 else 0.0
+    """`achieved` / `frac` = what the matrix pipe EXECUTED (Winograd F(4x4,3x3) runs 1/4, F(2x2,3x3) 1/2.25 of the
+    direct-convolution multiplies): a utilisation, <= 1.  The algorithmic (direct-convolution) rate of the same
+    launches is reported beside it as `algorithmic_tflops` -- it can exceed the peak because of the algorithmic gain, and is
+    not a fraction."""
+    sec = wino_ms * 1e-3
+    alg = wino_flops["alg"] / sec / 1e12 if wino_ms > 0 else 0.0
+    ex = wino_flops["exec"] / sec / 1e12 if wino_ms > 0 else 0.0
     traffic = (_profile_json("conv_traffic.json") or {}).get("hbm_bytes_per_launch")
-    return {"bound": "mfma", "achieved": round(alg / WINOGRAD_GAIN, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(alg / WINOGRAD_GAIN / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-            "kernel": "conv_wino_kernel (%s; %d launches per step, %.3f ms avg launch, HIP events on the launch stream); achieved = "
-                      "executed MFMA FLOPs (direct-convolution FLOPs / 2.25) of those launches / their time"
-                      % (what, n_wino // max(steps, 1), wino_ms / max(n_wino, 1)),
+    n4 = wino_flops["n4"]
+    return {"bound": "mfma", "achieved": round(ex, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ex / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "kernel": "conv_wino4_kernel F(4x4,3x3) + conv_wino_kernel F(2x2,3x3) (%s; %d + %d launches per step, %.3f ms avg launch, HIP "
+                      "events on the launch stream); achieved = executed MFMA FLOPs (direct-convolution FLOPs / 4 resp. / 2.25) of "
+                      "those launches / their time" % (what, n4 // max(steps, 1), (n_wino - n4) // max(steps, 1), wino_ms / max(n_wino, 1)),
             "algorithmic_tflops": round(alg, 2), "algorithmic_over_peak": round(alg / PEAK_F32_MFMA_TFLOPS, 4)}
 
 
@@ -362,7 +373,7 @@ def run_det(args, rank, local, world, device):
     if not bf16:
         roof["all_conv"] = {"launches_per_step": n_launch // max(args.steps, 1), "ms_per_step": round(conv_ms / max(args.steps, 1), 3),
                             "algorithmic_tflops": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2) if conv_ms > 0 else 0.0,
-                            "kernels": "conv_wino_kernel (3x3 s1) + stem_conv_kernel (7x7 s2) + conv_pw64_kernel (FPN in2) + conv_mfma_v2_kernel (3x3 s2, other 1x1)"}
+                            "kernels": "conv_wino4_kernel / conv_wino_kernel (3x3 s1) + stem_conv_kernel (7x7 s2) + conv_pw64_kernel (FPN in2) + conv_mfma_v2_kernel (3x3 s2, other 1x1)"}
     return {
         "metric": "images/sec end-to-end (DBNet-r18 det+post, 736x1280)" if args.det_model == "r18"
                   else "images/sec end-to-end (%s det+post, 736x1280; NOT the BASELINE metric)" % args.det_model,

@@ -77,6 +77,16 @@ int ptocr_conv2d_f32(const ptocr_conv_desc *d, const float *d_x, const float *d_
 int ptocr_conv3x3_wino_f32(const float *d_x, const float *d_u, const float *d_bias, const float *d_res, float *d_y,
                            int N, int H, int W, int Cin, int Cout, int cout_store, int relu, int res_mode, int res_ldc,
                            int out_ldc, int out_coff, int up, void *stream);
+/* The same layers by Winograd F(4x4,3x3) (4x fewer multiplies than direct, 1.78x fewer than F(2x2); maps move by ~1e-6): same
+ * arguments and epilogue; d_u: U = G6 g G6^T (6x6 per weight pair, fp64 on the host), packed
+ * f32[Cout/64][Cin/4][12][3][64][4]: "wave" w owns the frequencies xi = 3w + e (xi = 6 i + j), lane l = 32 h + n holds
+ * {U[xi][c0+2h][n], U[xi][c0+2h+1][n], U[xi][c0+2h][32+n], U[xi][c0+2h+1][32+n]} with c0 = 4 * chunk and n relative to the 64
+ * output channels of the block.  ptocr_conv3x3_wino4_patches: workgroups per 64 output channels the kernel needs for
+ * N x H x W (to choose between the two forms per layer). */
+int ptocr_conv3x3_wino4_f32(const float *d_x, const float *d_u, const float *d_bias, const float *d_res, float *d_y,
+                            int N, int H, int W, int Cin, int Cout, int cout_store, int relu, int res_mode, int res_ldc,
+                            int out_ldc, int out_coff, int up, void *stream);
+long ptocr_conv3x3_wino4_patches(int N, int H, int W);
 /* ResNet stem: conv 7x7 / stride 2 / pad 3 of an RGB image stored as f32[N,H,W,4] (4th channel ignored) -> f32[N,Ho,Wo,64],
  * Ho = (H-1)/2+1, Wo = (W-1)/2+1, + bias (folded BN) + optional ReLU (det_resnet.py:193-196).  d_w: f32[7][22][64],
  * w[ky][kx*3 + c][cout], row [ky][21] all zero (K runs over 7 x 22 = 154 instead of the generic kernel's 7*7*4 = 196). */
@@ -101,6 +111,7 @@ int ptocr_conv3x3_small_relu_pool_f32(const float *d_x, const float *d_w, const 
 /* Measurement hook (no reference counterpart): d_buf = device u64[4 * workgroups] receives s_memtime samples (start, main
  * loop start, main loop end, end) from every Winograd workgroup launched afterwards; NULL switches the probe off. */
 void ptocr_wino_set_timing_buffer(void *d_buf);
+void ptocr_wino4_set_timing_buffer(void *d_buf);   /* the same for ptocr_conv3x3_wino4_f32 */
 
 /* f32[N,C,H,W] -> f32[N,H,W,Cpad] (channels >= C zero-filled; Cpad % 4 == 0) */
 int ptocr_nchw_to_nhwc_f32(const float *d_x, float *d_y, int N, int C, int H, int W, int Cpad, void *stream);

@@ -15,6 +15,8 @@ PROFILE_LABELS = None                          # optional list: one text label p
 # 3x3 / stride 1 layers run as Winograd F(2x2,3x3) unless PTOCR_WINOGRAD=0 (then the direct implicit GEMM runs them)
 import os as _os
 USE_WINOGRAD = _os.environ.get("PTOCR_WINOGRAD", "1") != "0"
+WINO4_MODE = _os.environ.get("PTOCR_WINO4", "auto")        # "0": F(2x2) only, "1": F(4x4) wherever it applies, else by cost
+WINO_COST = [2560, 14000, 3100, 18000]                     # cycles: F(2x2) per chunk / fixed, F(4x4) per chunk / fixed
 # the 7x7 / stride 2 RGB stem runs in its own kernel unless PTOCR_STEM_KERNEL=0 (then the generic implicit GEMM runs it)
 USE_STEM_KERNEL = _os.environ.get("PTOCR_STEM_KERNEL", "1") != "0"
 # 1x1 convolutions with 64 input channels run in the LDS-resident-weights kernel unless PTOCR_PW64_KERNEL=0
@@ -112,7 +114,7 @@ class PackedConv:
             self.stem_w = sw.float().contiguous().to(device)
             self.stem_b = b.float().contiguous().to(device)
         # Winograd F(2x2,3x3) form of the same weights for 3x3 / s1 / p1 layers: U = G g G^T, packed [Cout/64][Cin/4][16][64][4]
-        self.wino_u = None
+        self.wino_u = self.wino4_u = None
         if (kh, kw) == (3, 3) and self.stride == 1 and (self.pad_h, self.pad_w) == (1, 1) and cin % 16 == 0 and cout % 4 == 0 \
                 and cin_pad == cin and self.relu in (ACT_NONE, ACT_RELU):
             G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64)
@@ -125,6 +127,15 @@ class PackedConv:
             bw[:cout] = b
             self.wino_b = bw.float().contiguous().to(device)
             self.wino_cout = cw
+            # F(4x4,3x3) form for the large maps (conv_wino4.hip): U = G6 g G6^T, packed [Cout/64][Cin/4][12 waves][3 xi][64 lanes][4]:
+            # wave w owns xi = 3w + e; lane (n = lane & 31, h = lane >> 5) holds {nb, t} -> U[xi][4 chunk + 2h + t][64 ct + 32 nb + n]
+            G6 = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+                               [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float64)
+            U6 = torch.zeros(cw, cin, 36, dtype=torch.float64)
+            U6[:cout] = torch.einsum("ar,ocrs,bs->ocab", G6, w, G6).reshape(cout, cin, 36)
+            U6 = U6.reshape(cw // 64, 2, 32, cin // 4, 2, 2, 12, 3)               # [ct, nb, n, chunk, h, t, w, e]
+            U6 = U6.permute(0, 3, 6, 7, 4, 2, 1, 5)                                # [ct, chunk, w, e, h, n, nb, t]
+            self.wino4_u = U6.contiguous().float().to(device)
 
 
 class PackedConvT2x2:
@@ -150,6 +161,20 @@ class PackedConvT2x2:
         self.convt = True
         self.co = cp
         self.cout_real, self.c_tensor = co, cp
+
+
+def _wino4_wins(H, W, Cin):
+    """F(4x4,3x3) or F(2x2,3x3) for this layer: patches per image of the best geometry of each kernel x cycles per patch (main
+    loop per 4-channel chunk + fixed part, measured with the s_memtime probes).  Depends on the map size and the channels only,
+    never on the batch (results are compared bit-exactly across batch sizes); PTOCR_WINO4=0/1 forces one."""
+    if WINO4_MODE in ("0", "1"):
+        return WINO4_MODE == "1"
+    cd = lambda a, b: (a + b - 1) // b
+    n = 8                                                  # nominal batch: every multi-image geometry divides it
+    p2 = min(100 * n * cd(H, 16) * cd(W, 16), 100 * n * cd(H, 32) * cd(W, 8), 106 * cd(n, 2) * cd(H, 8) * cd(W, 16),
+             112 * cd(n, 4) * cd(H, 4) * cd(W, 16), 112 * cd(n, 4) * cd(H, 8) * cd(W, 8)) / 100.0
+    p4 = _lib.lib().ptocr_conv3x3_wino4_patches(n, H, W)
+    return p4 * (WINO_COST[2] * (Cin // 4) + WINO_COST[3]) < p2 * (WINO_COST[0] * (Cin // 4) + WINO_COST[1])
 
 
 def conv2d(x, pc, res=None, res_mode=RES_NONE, out=None, out_up=1, out_coff=0, store=None):
@@ -196,19 +221,22 @@ def conv2d(x, pc, res=None, res_mode=RES_NONE, out=None, out_up=1, out_coff=0, s
             and out_up <= 8 and (store if store is not None else pc.c_tensor) % 4 == 0 and N * H * W * Cin * 4 < 2 ** 31 \
             and (store if store is not None else pc.c_tensor) <= pc.wino_cout:
         cs = store if store is not None else pc.c_tensor      # columns written: zero weights / bias beyond the real channels
+        four = pc.wino4_u is not None and _wino4_wins(H, W, Cin) and out.numel() * 4 < 2 ** 31 and (res is None or res.numel() * 4 < 2 ** 31)
         if PROFILE is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        _lib.check(_lib.lib().ptocr_conv3x3_wino_f32(_lib.ptr(x), _lib.ptr(pc.wino_u), _lib.ptr(pc.wino_b),
-                                                     _lib.ptr(res) if res is not None else C.c_void_p(0), _lib.ptr(out),
-                                                     N, H, W, Cin, pc.wino_cout, cs, int(pc.relu), res_mode,
-                                                     res.shape[3] if res is not None else 0, out.shape[3], out_coff,
-                                                     out_up, _lib.cur_stream()), "ptocr_conv3x3_wino_f32")
+        fn = _lib.lib().ptocr_conv3x3_wino4_f32 if four else _lib.lib().ptocr_conv3x3_wino_f32
+        _lib.check(fn(_lib.ptr(x), _lib.ptr(pc.wino4_u if four else pc.wino_u), _lib.ptr(pc.wino_b),
+                      _lib.ptr(res) if res is not None else C.c_void_p(0), _lib.ptr(out),
+                      N, H, W, Cin, pc.wino_cout, cs, int(pc.relu), res_mode,
+                      res.shape[3] if res is not None else 0, out.shape[3], out_coff,
+                      out_up, _lib.cur_stream()), "ptocr_conv3x3_wino4_f32" if four else "ptocr_conv3x3_wino_f32")
         if PROFILE is not None:
             e1.record()
             PROFILE.append((e0, e1))
             if PROFILE_LABELS is not None:
-                PROFILE_LABELS.append("wino3x3 %dx%dx%dx%d->%d%s" % (N, H, W, Cin, pc.cout_real, " up%d" % out_up if out_up > 1 else ""))
+                PROFILE_LABELS.append("wino%s3x3 %dx%dx%dx%d->%d%s" % ("4" if four else "", N, H, W, Cin, pc.cout_real,
+                                                                      " up%d" % out_up if out_up > 1 else ""))
         return out
     if pc.convt:
         cout_k, cstore = 4 * pc.co, 0
