@@ -26,7 +26,8 @@
 #include "common.h"
 
 #ifndef W4_DBG
-#define W4_DBG 0            // timing experiments only (PTOCR_EXTRA_HIPCC_FLAGS=-DW4_DBG=n): 1 no global stores, 2 no consumer, 4 no exchange writes
+#define W4_DBG 0            // timing experiments only (PTOCR_EXTRA_HIPCC_FLAGS=-DW4_DBG=n): 1 no global stores, 2 no consumer, 4 no exchange writes,
+                            // 8 no input transform, 16 no weight-fragment loads, 32 no raw refill, 64 no transform math (LDS traffic kept)
 #endif
 
 namespace ptocr {
@@ -140,15 +141,18 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args p) {
     float tq[6];
     auto tr_col = [&](int off, int b) {                                             // row pass of patch column b
         const int o = off + b * W4_PX;
+        if (W4_DBG & 64) { tq[b] = __builtin_bit_cast(float, __builtin_bit_cast(int, tb0[o]) | __builtin_bit_cast(int, tb1[o]) | __builtin_bit_cast(int, tb2[o]) | __builtin_bit_cast(int, tb3[o])); return; }
         tq[b] = __builtin_fmaf(tc0, tb0[o], __builtin_fmaf(tc1, tb1[o], __builtin_fmaf(tc2, tb2[o], tc3 * tb3[o])));
     };
     auto tr_out_lo = [&](float *vp) {                                               // column pass (the same B^T), outputs b' = 0, 1, 2
+        if (W4_DBG & 64) { vp[0] = tq[0]; vp[2 * W4_VH] = tq[1]; vp[4 * W4_VH] = tq[2]; return; }
         const float m = __builtin_fmaf(-4.f, tq[2], tq[4]), n = __builtin_fmaf(-4.f, tq[1], tq[3]);
         vp[0 * 2 * W4_VH] = __builtin_fmaf(4.f, tq[0], __builtin_fmaf(-5.f, tq[2], tq[4]));
         vp[1 * 2 * W4_VH] = m + n;
         vp[2 * 2 * W4_VH] = m - n;
     };
     auto tr_out_hi = [&](float *vp) {                                               // outputs b' = 3, 4, 5
+        if (W4_DBG & 64) { vp[6 * W4_VH] = tq[3]; vp[8 * W4_VH] = tq[4]; vp[10 * W4_VH] = tq[5]; return; }
         const float m = tq[4] - tq[2], n = tq[3] - tq[1];
         vp[3 * 2 * W4_VH] = __builtin_fmaf(2.f, n, m);
         vp[4 * 2 * W4_VH] = __builtin_fmaf(-2.f, n, m);
@@ -207,16 +211,18 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args p) {
 #pragma unroll
             for (int g = 0; g < 9; g++) {
                 mfma_g(g);
-                if (g == 3) u_gload(0, chunk + 1);
-                if (g == 7) u_gload(1, chunk + 1);
-                if (g < 2) {
+                if (g == 3 && !(W4_DBG & 16)) u_gload(0, chunk + 1);
+                if (g == 7 && !(W4_DBG & 16)) u_gload(1, chunk + 1);
+                if (g < 2 && !(W4_DBG & 32)) {
                     if (q == 0) raw_gload1(S + 1, g);
                     if (q == 1) { raw_lstore1(sp ^ 1, g); if (g + 2 < NPIECE) raw_gload1(S + 1, g + 2); }
                     if (q == 2 && g + 2 < NPIECE) raw_lstore1(sp ^ 1, g + 2);
                 }
-                if (g >= 1 && g < 7) tr_col(roff, g - 1);
-                if (g == 7) tr_out_lo(vp);
-                if (g == 8) tr_out_hi(vp);
+                if (!(W4_DBG & 8)) {
+                    if (g >= 1 && g < 7) tr_col(roff, g - 1);
+                    if (g == 7) tr_out_lo(vp);
+                    if (g == 8) tr_out_hi(vp);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args p) {
 #pragma unroll
             for (int g = 9; g < 12; g++) mfma_g(g);
             frag_load(2, nxt);
-            u_gload(2, chunk + 1);
+            if (!(W4_DBG & 16)) u_gload(2, chunk + 1);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -350,22 +356,21 @@ static unsigned long long *g_wino4_dbg = nullptr;
 // debug: device buffer of 4 clock samples per workgroup (start, main loop start, main loop end, end); null switches it off
 extern "C" void ptocr_wino4_set_timing_buffer(void *d_buf) { g_wino4_dbg = (unsigned long long *)d_buf; }
 
-// cost (arbitrary units per patch) of covering N x H x W with geometry g; used by the host to choose between the kernels
+// patch geometries {TXN, TYN, TN}: tiles along x, along y, images per patch (TXN * TYN * TN <= 32 tile slots)
+static const int W4_GEO[][3] = {{8, 4, 1}, {4, 8, 1}, {5, 6, 1}, {4, 4, 2}, {8, 2, 2}, {4, 2, 4}, {7, 1, 4}};
+constexpr int W4_NGEO = 7;
 static long wino4_patches(int g, int N, int H, int W) {
-    switch (g) {
-        case 0: return (long)N * cdiv(H, 16) * cdiv(W, 32);          // 4 x 8 tiles
-        case 1: return (long)N * cdiv(H, 32) * cdiv(W, 16);          // 8 x 4 tiles
-        case 2: return (long)N * cdiv(H, 24) * cdiv(W, 20);          // 6 x 5 tiles (30 of 32 slots)
-        default: return (long)cdiv(N, 2) * cdiv(H, 16) * cdiv(W, 16);   // 4 x 4 tiles of two images
-    }
+    return (long)cdiv(N, W4_GEO[g][2]) * cdiv(H, 4 * W4_GEO[g][1]) * cdiv(W, 4 * W4_GEO[g][0]);
+}
+static int wino4_best_geo(int N, int H, int W) {
+    int geo = 0;
+    for (int g = 1; g < W4_NGEO; g++)
+        if (wino4_patches(g, N, H, W) < wino4_patches(geo, N, H, W)) geo = g;
+    return geo;
 }
 
 // number of patches the best geometry needs (x Cout / 64 workgroups): lets the host compare with the F(2x2) kernel's count
-extern "C" long ptocr_conv3x3_wino4_patches(int N, int H, int W) {
-    long best = wino4_patches(0, N, H, W);
-    for (int g = 1; g < 4; g++) best = wino4_patches(g, N, H, W) < best ? wino4_patches(g, N, H, W) : best;
-    return best;
-}
+extern "C" long ptocr_conv3x3_wino4_patches(int N, int H, int W) { return wino4_patches(wino4_best_geo(N, H, W), N, H, W); }
 
 // d_u: weights transformed on the host (U = G g G^T per (cout, cin) in fp64, BN folded), packed
 // f32[Cout/64][Cin/4][12][3][64][4]: wave w, xi = 3w + e, lane (n = lane & 31, h = lane >> 5) holds
@@ -395,13 +400,13 @@ extern "C" int ptocr_conv3x3_wino4_f32(const float *d_x, const float *d_u, const
     a.res_bytes = res_mode ? (long)N * H * W * a.res_ldc * 4 : 0;
     PT_CHECK(a.x_bytes < (1L << 31) && a.u_bytes < (1L << 31) && a.y_bytes < (1L << 31) && a.res_bytes < (1L << 31),
              "ptocr_conv3x3_wino4_f32: tensor larger than 2 GiB");
-    int geo = 0;
-    for (int g = 1; g < 4; g++)
-        if (wino4_patches(g, N, H, W) < wino4_patches(geo, N, H, W)) geo = g;
-    switch (geo) {
+    switch (wino4_best_geo(N, H, W)) {
         case 1: return launch_wino4<4, 8, 1>(a, (hipStream_t)stream);
         case 2: return launch_wino4<5, 6, 1>(a, (hipStream_t)stream);
         case 3: return launch_wino4<4, 4, 2>(a, (hipStream_t)stream);
+        case 4: return launch_wino4<8, 2, 2>(a, (hipStream_t)stream);
+        case 5: return launch_wino4<4, 2, 4>(a, (hipStream_t)stream);
+        case 6: return launch_wino4<7, 1, 4>(a, (hipStream_t)stream);
         default: return launch_wino4<8, 4, 1>(a, (hipStream_t)stream);
     }
 }

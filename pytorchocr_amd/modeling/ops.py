@@ -170,7 +170,7 @@ def _wino4_wins(H, W, Cin):
     if WINO4_MODE in ("0", "1"):
         return WINO4_MODE == "1"
     cd = lambda a, b: (a + b - 1) // b
-    n = 8                                                  # nominal batch: every multi-image geometry divides it
+    n = 16                                                 # nominal batch: every multi-image geometry divides it
     p2 = min(100 * n * cd(H, 16) * cd(W, 16), 100 * n * cd(H, 32) * cd(W, 8), 106 * cd(n, 2) * cd(H, 8) * cd(W, 16),
              112 * cd(n, 4) * cd(H, 4) * cd(W, 16), 112 * cd(n, 4) * cd(H, 8) * cd(W, 8)) / 100.0
     p4 = _lib.lib().ptocr_conv3x3_wino4_patches(n, H, W)
