@@ -36,12 +36,26 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// packed fp32 VALU ops (two lanes of math per instruction); the compiler scalarises <2 x float> arithmetic whose halves come from
+// separate LDS reads, so these are spelled out.  c: wave-uniform coefficient pair in SGPRs.
+__device__ __forceinline__ f32x2 pk_mul_s(f32x2 c, f32x2 x) { f32x2 d; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "s"(c), "v"(x)); return d; }
+__device__ __forceinline__ f32x2 pk_fma_s(f32x2 c, f32x2 x, f32x2 y) { f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "s"(c), "v"(x), "v"(y)); return d; }
+__device__ __forceinline__ f32x2 pk_sub(f32x2 x, f32x2 y) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(y)); return d; }
+// (p.hi + p.lo, p.hi - p.lo)
+__device__ __forceinline__ f32x2 pk_hi_pm_lo(f32x2 p) { f32x2 d; asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(p)); return d; }
+// (p.hi + c p.lo, p.hi - c p.lo)
+__device__ __forceinline__ f32x2 pk_hi_pm_clo(f32x2 c, f32x2 p) {
+    f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1] neg_hi:[0,1,0]" : "=v"(d) : "s"(c), "v"(p)); return d;
+}
+
 constexpr int W4_VH = 80;                      // floats per (xi, k pair) block of V: 32 tiles x 2 channels + 16 (second pair 16 banks off)
 constexpr int W4_V = 36 * 2 * W4_VH;           // floats per V buffer
 constexpr int W4_PX = 17;                      // LDS pixel stride (floats) of the raw patch: 16 channels + 1
 constexpr int W4_EL = 68;                      // exchange tile row stride
 constexpr int W4_THREADS = 768;
-constexpr int w4_raw_floats(int txn, int tyn, int tn) { return (tn * (4 * txn + 2) * (4 * tyn + 2) + 1) * W4_PX + 3; }   // + one dump pixel
+// raw buffer: room for every 16-byte piece the 768 threads store (pieces past the patch are never read), so that piece r of a
+// thread sits at a compile-time offset (192 pixels) behind its piece 0
+constexpr int w4_raw_floats(int txn, int tyn, int tn) { return ((tn * (4 * txn + 2) * (4 * tyn + 2) * 4 + W4_THREADS - 1) / W4_THREADS) * 192 * W4_PX + 4; }
 
 struct Wino4Args {
     const float *x, *u, *bias, *res;
@@ -67,7 +81,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args p) {
     static_assert(12 * 32 * W4_EL <= 2 * W4_V + 2 * W_RAW, "exchange tiles must fit the LDS allocation");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Vb = smem;                           // [2][36][2][W4_VH]
-    float *Rb = smem + 2 * W4_V;                // [2][NPX + 1][W4_PX]
+    float *Rb = smem + 2 * W4_V;                // [2][NPIECE * 192][W4_PX]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // 0..11: three waves per SIMD
@@ -104,10 +118,9 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args p) {
     auto raw_gload1 = [&](int S, int r) {
         rreg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, r_off[r] + (unsigned)(S * 64), 0, 0));
     };
+    float *const r_l0 = Rb + (tid >> 2) * W4_PX + (tid & 3) * 4;                   // piece r: 192 pixels further
     auto raw_lstore1 = [&](int buf, int r) {
-        const int f = tid + W4_THREADS * r;
-        const int px = f >> 2 < NPX ? f >> 2 : NPX;                                // pieces beyond the patch land in the dump pixel
-        float *d = Rb + buf * W_RAW + px * W4_PX + (f & 3) * 4;
+        float *d = r_l0 + buf * W_RAW + r * 192 * W4_PX;
         d[0] = rreg[r][0]; d[1] = rreg[r][1]; d[2] = rreg[r][2]; d[3] = rreg[r][3];
     };
 
@@ -138,25 +151,28 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args p) {
     const float tc1 = ta == 0 ? -5.f : ta == 1 ? -4.f : ta == 2 ? -4.f : ta == 3 ? -1.f : ta == 4 ? -1.f : -5.f;
     const float tc2 = ta == 0 ? 1.f : ta == 1 ? 1.f : ta == 2 ? -1.f : ta == 3 ? 2.f : ta == 4 ? -2.f : 1.f;
     const float tc3 = (ta == 0 || ta == 5) ? 0.f : 1.f;
-    float tq[6];
-    auto tr_col = [&](int off, int b) {                                             // row pass of patch column b
-        const int o = off + b * W4_PX;
-        if (W4_DBG & 64) { tq[b] = __builtin_bit_cast(float, __builtin_bit_cast(int, tb0[o]) | __builtin_bit_cast(int, tb1[o]) | __builtin_bit_cast(int, tb2[o]) | __builtin_bit_cast(int, tb3[o])); return; }
-        tq[b] = __builtin_fmaf(tc0, tb0[o], __builtin_fmaf(tc1, tb1[o], __builtin_fmaf(tc2, tb2[o], tc3 * tb3[o])));
+    const f32x2 tc0v = {tc0, tc0}, tc1v = {tc1, tc1}, tc2v = {tc2, tc2}, tc3v = {tc3, tc3};
+    const f32x2 k_m4 = {-4.f, -4.f}, k_2 = {2.f, 2.f};
+    f32x2 tq[3];                                                                    // row-pass values of the patch columns (1,2) (3,4) (0,5)
+    auto tr_col2 = [&](int off, int pr) {                                           // row pass of two patch columns, packed
+        const int o0 = off + (pr == 2 ? 0 : 2 * pr + 1) * W4_PX, o1 = off + (pr == 2 ? 5 : 2 * pr + 2) * W4_PX;
+        const f32x2 x0 = {tb0[o0], tb0[o1]}, x1 = {tb1[o0], tb1[o1]}, x2 = {tb2[o0], tb2[o1]}, x3 = {tb3[o0], tb3[o1]};
+        if (W4_DBG & 64) { tq[pr] = x0 + x1 + x2 + x3; return; }
+        tq[pr] = pk_fma_s(tc0v, x0, pk_fma_s(tc1v, x1, pk_fma_s(tc2v, x2, pk_mul_s(tc3v, x3))));
     };
-    auto tr_out_lo = [&](float *vp) {                                               // column pass (the same B^T), outputs b' = 0, 1, 2
-        if (W4_DBG & 64) { vp[0] = tq[0]; vp[2 * W4_VH] = tq[1]; vp[4 * W4_VH] = tq[2]; return; }
-        const float m = __builtin_fmaf(-4.f, tq[2], tq[4]), n = __builtin_fmaf(-4.f, tq[1], tq[3]);
-        vp[0 * 2 * W4_VH] = __builtin_fmaf(4.f, tq[0], __builtin_fmaf(-5.f, tq[2], tq[4]));
-        vp[1 * 2 * W4_VH] = m + n;
-        vp[2 * 2 * W4_VH] = m - n;
-    };
-    auto tr_out_hi = [&](float *vp) {                                               // outputs b' = 3, 4, 5
-        if (W4_DBG & 64) { vp[6 * W4_VH] = tq[3]; vp[8 * W4_VH] = tq[4]; vp[10 * W4_VH] = tq[5]; return; }
-        const float m = tq[4] - tq[2], n = tq[3] - tq[1];
-        vp[3 * 2 * W4_VH] = __builtin_fmaf(2.f, n, m);
-        vp[4 * 2 * W4_VH] = __builtin_fmaf(-2.f, n, m);
-        vp[5 * 2 * W4_VH] = __builtin_fmaf(4.f, tq[1], __builtin_fmaf(-5.f, tq[3], tq[5]));
+    auto tr_out = [&](float *vp) {                                                  // column pass (the same B^T along the columns)
+        const f32x2 q12 = tq[0], q34 = tq[1], q05 = tq[2];
+        if (W4_DBG & 64) { vp[0] = q12[0]; vp[2 * W4_VH] = q12[1]; vp[4 * W4_VH] = q34[0]; vp[6 * W4_VH] = q34[1]; vp[8 * W4_VH] = q05[0]; vp[10 * W4_VH] = q05[1]; return; }
+        const f32x2 nm = pk_fma_s(k_m4, q12, q34);                                  // (q3 - 4 q1, q4 - 4 q2)
+        const f32x2 nm2 = pk_sub(q34, q12);                                         // (q3 - q1, q4 - q2)
+        const f32x2 o12 = pk_hi_pm_lo(nm);                                          // b' = 1 | 2
+        const f32x2 o34 = pk_hi_pm_clo(k_2, nm2);                                   // b' = 3 | 4
+        vp[0 * 2 * W4_VH] = __builtin_fmaf(4.f, q05[0], __builtin_fmaf(-5.f, q12[1], q34[1]));
+        vp[1 * 2 * W4_VH] = o12[0];
+        vp[2 * 2 * W4_VH] = o12[1];
+        vp[3 * 2 * W4_VH] = o34[0];
+        vp[4 * 2 * W4_VH] = o34[1];
+        vp[5 * 2 * W4_VH] = __builtin_fmaf(4.f, q12[0], __builtin_fmaf(-5.f, q34[0], q05[1]));
     };
 
     // ---- MFMA: wave w owns xi = 3w + e; A = V rows (tiles), B = U columns (output channels)
@@ -179,9 +195,8 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args p) {
     for (int r = 0; r < NPIECE; r++) raw_lstore1(0, r);
     __syncthreads();
 #pragma unroll
-    for (int b = 0; b < 6; b++) tr_col(0, b);
-    tr_out_lo(Vb + t_voff);
-    tr_out_hi(Vb + t_voff);
+    for (int pr = 0; pr < 3; pr++) tr_col2(0, pr);
+    tr_out(Vb + t_voff);
 #pragma unroll
     for (int e = 0; e < 3; e++)
 #pragma unroll
@@ -207,7 +222,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args p) {
             // nine slots of one MFMA plus a share of the side work for chunk+1, in program order:
             //   3, 7  weight fragments of xi 0, 1 for chunk+1 (global -> the registers their last MFMA has just read)
             //   0-1   raw patch refill for the next 16 channels: pieces 0, 1 load at q=0 / store at q=1, pieces 2, 3 at q=1 / q=2
-            //   1-6   input transform: LDS reads + row pass of one patch column each;  7-8 column pass + LDS writes
+            //   2,4,6 input transform: LDS reads + packed row pass of two patch columns each;  8 column pass + LDS writes
 #pragma unroll
             for (int g = 0; g < 9; g++) {
                 mfma_g(g);
@@ -219,9 +234,8 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args p) {
                     if (q == 2 && g + 2 < NPIECE) raw_lstore1(sp ^ 1, g + 2);
                 }
                 if (!(W4_DBG & 8)) {
-                    if (g >= 1 && g < 7) tr_col(roff, g - 1);
-                    if (g == 7) tr_out_lo(vp);
-                    if (g == 8) tr_out_hi(vp);
+                    if (g == 2 || g == 4 || g == 6) tr_col2(roff, (g - 2) >> 1);
+                    if (g == 8) tr_out(vp);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }

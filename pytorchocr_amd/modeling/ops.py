@@ -16,7 +16,7 @@ PROFILE_LABELS = None                          # optional list: one text label p
 import os as _os
 USE_WINOGRAD = _os.environ.get("PTOCR_WINOGRAD", "1") != "0"
 WINO4_MODE = _os.environ.get("PTOCR_WINO4", "auto")        # "0": F(2x2) only, "1": F(4x4) wherever it applies, else by cost
-WINO_COST = [2560, 14000, 3100, 18000]                     # cycles: F(2x2) per chunk / fixed, F(4x4) per chunk / fixed
+WINO_COST = [2560, 14000, 2990, 23500]                     # cycles: F(2x2) per chunk / fixed, F(4x4) per chunk / fixed
 # the 7x7 / stride 2 RGB stem runs in its own kernel unless PTOCR_STEM_KERNEL=0 (then the generic implicit GEMM runs it)
 USE_STEM_KERNEL = _os.environ.get("PTOCR_STEM_KERNEL", "1") != "0"
 # 1x1 convolutions with 64 input channels run in the LDS-resident-weights kernel unless PTOCR_PW64_KERNEL=0
