@@ -231,12 +231,16 @@ def test_squeeze_excitation():
 
 
 @pytest.mark.parametrize("case", [(2, 64, 20, 36, 64), (1, 256, 23, 40, 64), (1, 128, 16, 32, 128), (1, 64, 33, 47, 192),
-                                  (5, 32, 150, 170, 64), (6, 64, 8, 48, 64), (7, 32, 4, 40, 64), (3, 32, 6, 21, 128), (8, 32, 23, 40, 64), (5, 32, 9, 24, 64)])
-def test_winograd_3x3_matches_torch(case):
-    """Winograd F(2x2,3x3) path (default for 3x3/s1/p1 layers) against torch fp32, incl. odd sizes, residual, concat slice,
-    all four patch geometries (16x16, 32x8, and the 2- / 4-image patches used for short text-line feature maps)."""
+                                  (5, 32, 150, 170, 64), (6, 64, 8, 48, 64), (7, 32, 4, 40, 64), (3, 32, 6, 21, 128), (8, 32, 23, 40, 64), (5, 32, 9, 24, 64),
+                                  (1, 32, 32, 16, 64), (2, 48, 16, 16, 64), (9, 32, 8, 16, 64), (6, 16, 4, 81, 128), (3, 64, 46, 80, 64)])
+@pytest.mark.parametrize("mode", ["1", "0"])
+def test_winograd_3x3_matches_torch(case, mode, monkeypatch):
+    """Both Winograd kernels -- F(4x4,3x3) (mode "1": what the cost model picks for every layer of the three networks) and
+    F(2x2,3x3) (mode "0": the fallback) -- against torch fp32, incl. odd sizes, residual, concat slice, fused upsample store, and every
+    patch geometry of either kernel (single-image patches, the 30-of-32-slot 6x5 patch, the 2- / 4-image patches of short maps)."""
     from pytorchocr_amd.modeling import ops
     assert ops.USE_WINOGRAD
+    monkeypatch.setattr(ops, "WINO4_MODE", mode)
     N, Cin, H, W, Cout = case
     dev = _dev()
     conv = nn.Conv2d(Cin, Cout, 3, 1, 1, bias=False)
@@ -250,11 +254,14 @@ def test_winograd_3x3_matches_torch(case):
     with torch.no_grad():
         ref = F.relu(bn(conv(x)))
         ref_res = F.relu(bn(conv(x)) + res)
-    pc = ops.PackedConv(conv, bn, dev, relu=True)
-    assert pc.wino_u is not None
+    pc = ops.PackedConv(conv, bn, dev, relu=True, cin_pad=Cin)
+    assert pc.wino_u is not None and pc.wino4_u is not None
     xd = _nhwc(x).to(dev)
     tol = 3e-5 * max(1.0, ref.abs().max().item())
+    monkeypatch.setattr(ops, "PROFILE", [])
+    monkeypatch.setattr(ops, "PROFILE_LABELS", [])
     y = ops.conv2d(xd, pc).cpu().permute(0, 3, 1, 2)
+    assert ops.PROFILE_LABELS[0].startswith("wino43x3" if mode == "1" else "wino3x3 ")      # the kernel under test did run
     assert (y - ref).abs().max().item() <= tol
     y = ops.conv2d(xd, pc, res=_nhwc(res).to(dev), res_mode=ops.RES_ADD_PRE_RELU).cpu().permute(0, 3, 1, 2)
     assert (y - ref_res).abs().max().item() <= tol
