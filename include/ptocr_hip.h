@@ -194,9 +194,8 @@ int ptocr_dbpost_destroy(ptocr_dbpost_t h);
  * If d_bitmap != NULL it is used as the u8[N,H,W] segmentation (caller-made, e.g. dilated); otherwise the
  * segmentation is pred > thresh computed on the device.
  * Output (host): h_boxes int16[N][max_boxes][4][2] in the reference's order, h_counts int32[N] (boxes per
- * image), h_flags int32[N] (bit 0: a candidate's unclip distance was < 0.75 px -- Clipper's union clean-up of
- * sub-pixel slivers is not reproduced; bit 1: score within 1e-7 of box_thresh resolved by the
- * exact raster-order re-summation; bit 2: internal capacity exceeded -> the call fails with an error).
+ * image), h_flags int32[N] (bit 0: unused since round 2 -- ClipperOffset::Execute's union is reproduced for every
+ * candidate; bit 1: score within 1e-6 of box_thresh resolved by the exact raster-order re-summation; bit 2: internal capacity exceeded -> the call fails with an error).
  * Synchronises `stream` before returning (the boxes are host data, like the reference's return value). */
 int ptocr_db_postprocess(ptocr_dbpost_t h, const float *d_maps, const uint8_t *d_bitmap, int N, int H, int W,
                          float thresh, float box_thresh, float unclip_ratio, const int *h_src_wh,

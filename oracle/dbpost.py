@@ -132,6 +132,16 @@ def clipper_offset(path, delta):
     return out[:n].copy()
 
 
+def clipper_unclip(path, delta):
+    """restated offset + restated union: the solution's vertices as far as their hull goes (int64 [n,2]; n = 0: no solution)"""
+    path = np.ascontiguousarray(path, np.int64).reshape(-1, 2)
+    out = np.zeros((1024, 2), np.int64)
+    L = lib()
+    L.dbpost_oracle_clipper_unclip.restype = C.c_int
+    n = L.dbpost_oracle_clipper_unclip(_p(path, C.c_longlong), len(path), C.c_double(delta), _p(out, C.c_longlong), 1024)
+    return out[:max(n, 0)].copy()
+
+
 def clipper_ref_offset(path, delta):
     """Real Clipper: returns list of paths."""
     L = ref_lib()

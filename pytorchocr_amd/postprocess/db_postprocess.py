@@ -92,9 +92,7 @@ def device_boxes(maps, src_wh, thresh, box_thresh, unclip_ratio, bitmap=None, us
     return [boxes[i, :counts[i]].copy() for i in range(n)], flags.copy()
 
 
-_FLAG_TEXT = {1: "a candidate's unclip distance was below 0.75 px (sub-pixel sliver: Clipper's union clean-up is not "
-                  "reproduced for it, DESIGN.md section 4)",
-              2: "a box score within 1e-6 of box_thresh was re-summed in the reference's raster order"}
+_FLAG_TEXT = {2: "a box score within 1e-6 of box_thresh was re-summed in the reference's raster order"}
 
 
 def _warn_flags(flags):
