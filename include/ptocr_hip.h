@@ -95,6 +95,13 @@ int ptocr_conv7x7s2_stem_f32(const float *d_x, const float *d_w, const float *d_
 /* the same layer reading the model's input tensor f32[N,3,H,W] directly (saves the NCHW -> NHWC boundary pass) */
 int ptocr_conv7x7s2_stem_nchw_f32(const float *d_x, const float *d_w, const float *d_bias, float *d_y, int N, int H, int W,
                                   int relu, void *stream);
+/* The stem WITH its max pool: conv 7x7 / s2 / p3 + folded BN + ReLU + MaxPool2d(3, 2, 1) (det_resnet.py:193-197,284-287) in one
+ * kernel -> f32[N,Hp,Wp,64], Hp = (Ho-1)/2+1, Wp = (Wo-1)/2+1; the full-resolution stem output is never written.  Bit-identical to
+ * ptocr_conv7x7s2_stem_f32(relu = 1) followed by ptocr_maxpool2d_f32(3, 3, 2, 2, 1, 1).  _nchw: input f32[N,3,H,W]. */
+int ptocr_conv7x7s2_stem_relu_pool_f32(const float *d_x, const float *d_w, const float *d_bias, float *d_y, int N, int H, int W,
+                                       void *stream);
+int ptocr_conv7x7s2_stem_relu_pool_nchw_f32(const float *d_x, const float *d_w, const float *d_bias, float *d_y, int N, int H, int W,
+                                            void *stream);
 /* Pointwise convolution with 64 input channels (the FPN lateral in2, fpn.py:46-51): f32[N,H,W,64] x W[64][Cout] (k-major, BN
  * folded; Cout a multiple of 32, <= 256) + bias + optional ReLU; res_up2 = 1 adds d_res f32[N,H/2,W/2,Cout] nearest-upsampled
  * x2 AFTER the activation (fpn.py:133-134).  Output channels [out_coff, out_coff+Cout) of a tensor with channel stride out_ldc. */

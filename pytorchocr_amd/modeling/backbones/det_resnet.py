@@ -93,8 +93,10 @@ class ResNet(ops.PackedModule):
         """x4: f32[N,H,W,4] (RGB + zero channel) -> [C2, C3, C4, C5] NHWC; or the model's NCHW input as `x_nchw` (x4 None)."""
         self._check_eval()
         p = self.packed()
-        x = ops.conv2d(x4, p["stem"]) if x_nchw is None else ops.stem_from_nchw(x_nchw, p["stem"])
-        x = ops.maxpool2d(x, 3, 2, 1)
+        x = ops.stem_relu_pool(x4, x_nchw, p["stem"])             # stem + ReLU + max pool in one kernel where it applies
+        if x is None:
+            x = ops.conv2d(x4, p["stem"]) if x_nchw is None else ops.stem_from_nchw(x_nchw, p["stem"])
+            x = ops.maxpool2d(x, 3, 2, 1)
         outs = []
         for li in (1, 2, 3, 4):
             for bp in p["layer%d" % li]:

@@ -19,6 +19,8 @@ WINO4_MODE = _os.environ.get("PTOCR_WINO4", "auto")        # "0": F(2x2) only, "
 WINO_COST = [2560, 14000, 2990, 23500]                     # cycles: F(2x2) per chunk / fixed, F(4x4) per chunk / fixed
 # the 7x7 / stride 2 RGB stem runs in its own kernel unless PTOCR_STEM_KERNEL=0 (then the generic implicit GEMM runs it)
 USE_STEM_KERNEL = _os.environ.get("PTOCR_STEM_KERNEL", "1") != "0"
+# ... and takes its 3x3 / stride 2 max pool along (one kernel) unless PTOCR_STEM_POOL=0
+USE_STEM_POOL = _os.environ.get("PTOCR_STEM_POOL", "1") != "0"
 # 1x1 convolutions with 64 input channels run in the LDS-resident-weights kernel unless PTOCR_PW64_KERNEL=0
 USE_PW64_KERNEL = _os.environ.get("PTOCR_PW64_KERNEL", "1") != "0"
 # CRNN's conv0 + ReLU + 2x2 pool run fused on the VALU unless PTOCR_SMALL_CONV_KERNEL=0
@@ -344,6 +346,38 @@ def nhwc_to_nchw(x):
     _lib.check(_lib.lib().ptocr_nhwc_to_nchw_f32(_lib.ptr(x), _lib.ptr(y), N, Cc, H, W, _lib.cur_stream()),
                "ptocr_nhwc_to_nchw_f32")
     return y
+
+
+def stem_relu_pool(x4, x_nchw, pc):
+    """ResNet stem conv 7x7/s2 + BN + ReLU + MaxPool2d(3, 2, 1) in one kernel (the full-resolution stem output never reaches HBM);
+    input either f32[N,H,W,4] (x4) or the model's f32[N,3,H,W] (x_nchw).  None when the fused kernel does not apply."""
+    x = x4 if x_nchw is None else x_nchw
+    _require_cuda(x, "stem_relu_pool")
+    if not (USE_STEM_KERNEL and USE_STEM_POOL and getattr(pc, "stem_w", None) is not None and pc.relu == ACT_RELU and x.dtype == torch.float32):
+        return None
+    if x_nchw is None:
+        N, H, W, Cc = x.shape
+        if Cc != 4 or N * H * W * 16 >= 2 ** 31:
+            return None
+    else:
+        N, Cc, H, W = x.shape
+        if Cc != 3 or N * H * W * 12 >= 2 ** 31:
+            return None
+    x = x.contiguous()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((N, (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1, 64), dtype=torch.float32, device=x.device)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    fn = _lib.lib().ptocr_conv7x7s2_stem_relu_pool_f32 if x_nchw is None else _lib.lib().ptocr_conv7x7s2_stem_relu_pool_nchw_f32
+    _lib.check(fn(_lib.ptr(x), _lib.ptr(pc.stem_w), _lib.ptr(pc.stem_b), _lib.ptr(out), N, H, W, _lib.cur_stream()),
+               "ptocr_conv7x7s2_stem_relu_pool_f32")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((e0, e1))
+        if PROFILE_LABELS is not None:
+            PROFILE_LABELS.append("stem7x7+pool %dx%dx%dx3->64" % (N, H, W))
+    return out
 
 
 def maxpool2d(x, k, s, p):

@@ -96,6 +96,34 @@ def test_stem_7x7_cin3(shape):
     assert torch.equal(y_nchw, ops.conv2d(x4, pc))
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 70, 130), (3, 33, 47), (2, 160, 608), (1, 736, 1280), (5, 9, 250), (1, 129, 61)])
+def test_stem_with_fused_max_pool(shape):
+    """conv 7x7/s2 + BN + ReLU + MaxPool2d(3, 2, 1) in one kernel == the stem kernel followed by the pool kernel, bit for bit (strips
+    of 30 columns with a carried row: sizes that are no multiple of anything, one-strip and many-strip images, 1 and 23 tile rows),
+    from the NHWC4 tensor and from the NCHW input, and within tolerance of torch"""
+    from pytorchocr_amd.modeling import ops
+    dev = _dev()
+    N, H, W = shape
+    conv = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+    bn = nn.BatchNorm2d(64).eval()
+    with torch.no_grad():
+        conv.weight.copy_(_rand(64, 3, 7, 7, seed=1) * 0.15)
+        bn.running_mean.copy_(_rand(64, seed=5) * 0.2); bn.running_var.copy_(_rand(64, seed=6) * 0.5 + 1)
+    x = _rand(N, 3, H, W, seed=11)
+    pc = ops.PackedConv(conv, bn, dev, relu=True, cin_pad=4)
+    xd = x.to(dev)
+    x4 = ops.nchw_to_nhwc(xd, 4)
+    two = ops.maxpool2d(ops.conv2d(x4, pc), 3, 2, 1)
+    one = ops.stem_relu_pool(x4, None, pc)
+    assert one is not None and one.shape == two.shape and torch.equal(one, two)
+    assert torch.equal(ops.stem_relu_pool(None, xd, pc), two)
+    with torch.no_grad():
+        ref = F.max_pool2d(F.relu(bn(conv(x))), 3, 2, 1)
+    got = one.cpu().permute(0, 3, 1, 2)
+    assert got.shape == ref.shape and (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    assert ops.stem_relu_pool(x4, None, ops.PackedConv(conv, bn, dev, relu=False, cin_pad=4)) is None      # needs the ReLU (0 as pool padding)
+
+
 def test_residual_and_upsample_epilogues():
     from pytorchocr_amd.modeling import ops
     dev = _dev()
