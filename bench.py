@@ -500,7 +500,7 @@ def main():
                          "ocr = configs[4] (DB++ r18 -> crops -> CRNN over 64 images of 1280x960)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 32 det / 512 crnn / 64 ocr)")
     ap.add_argument("--crnn-steps", type=int, default=-1, help="steps of the embedded CRNN measurement (default: --steps; 0 = skip it)")
-    ap.add_argument("--distinct-images", type=int, default=8, help="distinct synthetic images / maps tiled to the batch")
+    ap.add_argument("--distinct-images", type=int, default=32, help="distinct synthetic images / maps (tiled to the batch if fewer than it)")
     ap.add_argument("--post-input", default="both", choices=["both", "stress", "model", "none"],
                     help="maps post-processed inside the timed step: the model's own maps (true data flow; random weights "
                          "give noise-like maps), text-like stress maps with ~140 boxes per image, or both (default: "
