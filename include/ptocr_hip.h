@@ -107,7 +107,8 @@ int ptocr_conv7x7s2_stem_relu_pool_nchw_f32(const float *d_x, const float *d_w, 
  * x2 AFTER the activation (fpn.py:133-134).  Output channels [out_coff, out_coff+Cout) of a tensor with channel stride out_ldc. */
 int ptocr_conv1x1_k64_f32(const float *d_x, const float *d_w, const float *d_bias, const float *d_res, float *d_y,
                           int N, int H, int W, int Cout, int relu, int res_up2, int out_ldc, int out_coff, void *stream);
-/* The same kernel for Cin = 32 or 64 and act = 0 none / 1 ReLU / 2 Hardswish (MobileNetV3's 1x1 layers on the large maps,
+/* The same kernel for Cin = 32, 64 or 128 (128: Cout a multiple of 128, half of the output channels per workgroup -- the FPN lateral
+ * in3) and act = 0 none / 1 ReLU / 2 Hardswish (MobileNetV3's 1x1 layers on the large maps,
  * det_mobilenet_v3.py:38-61; pad narrower layers with zero rows / columns). */
 int ptocr_conv1x1_small_k_f32(const float *d_x, const float *d_w, const float *d_bias, const float *d_res, float *d_y,
                               int N, int H, int W, int Cin, int Cout, int act, int res_up2, int out_ldc, int out_coff, void *stream);

@@ -150,6 +150,134 @@ static int launch_pw64(const Pw64Args &a, hipStream_t stream) {
     return launch_ok("conv_pw64_kernel");
 }
 
+
+// ---- the same scheme for 128 input channels (the FPN lateral in3: 128 -> 256 at 1/8 resolution, fpn.py:40-45,113,116): a workgroup
+// owns HALF of the output channels (64 KB of weights in LDS) and the 128-pixel input tile is single-buffered (67 KB) -- the next
+// tile waits in registers while this one computes, one more barrier per tile than the double-buffered form.  The generic kernel
+// runs this layer at 47 % of the MFMA floor (eight short k-steps per workgroup: all prologue and epilogue).
+template <int NMT>                              // output channels of a workgroup / 32
+__global__ __launch_bounds__(256, 1) void conv_pw128_kernel(Pw64Args p, int cout_total) {
+    constexpr int K = 128, RS = K + 4, QPP = K / 4, NPC = PW_TM * QPP / 256;        // 16 pieces per thread
+    constexpr int COUT = NMT * 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Wl = smem;                           // [K][COUT]
+    float *Xb = smem + K * COUT;                // [PW_TM][RS]
+    float *Bl = Xb + PW_TM * RS;                // [COUT]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const int nsplit = cout_total / COUT;
+    const int cbase = ((int)blockIdx.x % nsplit) * COUT;         // this workgroup's output channels: [cbase, cbase + COUT)
+    const int first = (int)blockIdx.x / nsplit, stride = (int)gridDim.x / nsplit;
+
+    for (int i = tid; i < K * COUT / 4; i += 256) {
+        const int k = i / (COUT / 4), c4 = i - k * (COUT / 4);
+        reinterpret_cast<f32x4 *>(Wl)[i] = *reinterpret_cast<const f32x4 *>(p.w + (long)k * cout_total + cbase + c4 * 4);
+    }
+    if (tid < COUT) Bl[tid] = p.bias[cbase + tid];
+
+    f32x4 xreg[NPC];
+    auto gload = [&](int tile) {
+#pragma unroll
+        for (int r = 0; r < NPC; r++) {
+            const int f = tid + 256 * r;
+            const long m = (long)tile * PW_TM + f / QPP;                  // beyond M: out of range -> zeros
+            xreg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (unsigned)(m * (K * 4) + (f % QPP) * 16), 0, 0));
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int r = 0; r < NPC; r++) {
+            const int f = tid + 256 * r;
+            *reinterpret_cast<f32x4 *>(Xb + (f / QPP) * RS + (f % QPP) * 4) = xreg[r];
+        }
+    };
+
+    const int c = lane & 31, kh = lane >> 5;
+    const float *wp = Wl + kh * COUT + c;                        // W[2s + kh][32 mt + c]
+    const float *xp = Xb + (32 * wave + c) * RS + kh;            // X[32w + c][2s + kh]
+
+    int tile = first;                                            // host launches gridDim.x / nsplit <= ntiles
+    gload(tile);
+    lstore();
+    __syncthreads();
+    for (;;) {
+        const int next = tile + stride;
+        const bool has_next = next < p.ntiles;
+        if (has_next) gload(next);                               // in flight during this tile's MFMAs
+
+        const long m = (long)tile * PW_TM + 32 * wave + c;
+        const bool live = m < p.M;
+        f32x4 rres[NMT][4];
+        if (p.res_up2) {                                         // + nearest-upsampled coarser map, after the ReLU
+            const long mm = live ? m : 0;
+            const int hw = p.H * p.W;
+            const int n = (int)(mm / hw), rem = (int)(mm - (long)n * hw);
+            const int oy = rem / p.W, ox = rem - oy * p.W;
+            const float *rp = p.res + (((long)n * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) * cout_total + cbase + 4 * kh;
+#pragma unroll
+            for (int mt = 0; mt < NMT; mt++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) rres[mt][g] = *reinterpret_cast<const f32x4 *>(rp + 32 * mt + 8 * g);
+        }
+        f32x16 acc[NMT];
+#pragma unroll
+        for (int a = 0; a < NMT; a++) acc[a] = (f32x16)(0.f);
+#pragma unroll 4
+        for (int s = 0; s < K / 2; s++) {
+            const float b = xp[2 * s];
+#pragma unroll
+            for (int mt = 0; mt < NMT; mt++)
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp[(2 * s) * COUT + 32 * mt], b, acc[mt], 0, 0, 0);
+        }
+        if (live) {
+            float *yp = p.y + m * p.out_ldc + p.out_coff + cbase;
+#pragma unroll
+            for (int mt = 0; mt < NMT; mt++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int co = 32 * mt + 8 * g + 4 * kh;
+                    f32x4 v = f32x4{acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]} +
+                              *reinterpret_cast<const f32x4 *>(Bl + co);
+                    if (p.relu == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                    if (p.relu == 2) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) v[k] = v[k] * fminf(fmaxf(v[k] + 3.f, 0.f), 6.f) * (1.f / 6.f);
+                    }
+                    if (p.res_up2) v += rres[mt][g];
+                    *reinterpret_cast<f32x4 *>(yp + co) = v;
+                }
+        }
+        if (!has_next) break;
+        __syncthreads();                                         // every wave is done with the tile in LDS
+        lstore();
+        __syncthreads();
+        tile = next;
+    }
+}
+
+static int launch_pw128(const Pw64Args &a, int cout_total, hipStream_t stream) {
+    constexpr int NMT = 4;
+    const size_t lds = sizeof(float) * (128 * NMT * 32 + PW_TM * (128 + 4) + NMT * 32);
+    static bool attr_set = false;
+    if (!attr_set) {
+        PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pw128_kernel<NMT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        PT_HIP(hipGetDevice(&dev));
+        PT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const int nsplit = cout_total / (NMT * 32);
+    int per = n_cu / nsplit;                                     // persistent workgroups per output-channel block
+    if (per > a.ntiles) per = a.ntiles;
+    if (per < 1) per = 1;
+    hipLaunchKernelGGL((conv_pw128_kernel<NMT>), dim3((unsigned)(per * nsplit)), dim3(256), lds, stream, a, cout_total);
+    return launch_ok("conv_pw128_kernel");
+}
+
 }  // namespace ptocr
 
 using namespace ptocr;
@@ -168,7 +296,7 @@ static int dispatch_pw(const Pw64Args &a, hipStream_t s) {
     }
 }
 
-// d_x: f32[N,H,W,Cin], Cin = 32 or 64; d_w: f32[Cin][Cout] (k-major, BN folded, zero rows / columns for padded channels);
+// d_x: f32[N,H,W,Cin], Cin = 32, 64 or 128 (128: Cout a multiple of 128); d_w: f32[Cin][Cout] (k-major, BN folded, zero rows / columns for padded channels);
 // act: 0 none, 1 ReLU, 2 Hardswish; d_res (res_up2 = 1): f32[N,H/2,W/2,Cout], added AFTER the activation (fpn.py:133-134), H and W
 // even; d_y: f32[N,H,W,out_ldc], channels [out_coff, out_coff + Cout).
 extern "C" int ptocr_conv1x1_small_k_f32(const float *d_x, const float *d_w, const float *d_bias, const float *d_res, float *d_y,
@@ -176,8 +304,9 @@ extern "C" int ptocr_conv1x1_small_k_f32(const float *d_x, const float *d_w, con
                                          void *stream) {
     PT_CHECK(d_x && d_w && d_bias && d_y, "ptocr_conv1x1_small_k_f32: null argument");
     PT_CHECK(N > 0 && H > 0 && W > 0, "ptocr_conv1x1_small_k_f32: empty tensor");
-    PT_CHECK(Cin == 32 || Cin == 64, "ptocr_conv1x1_small_k_f32: Cin must be 32 or 64 (got %d)", Cin);
+    PT_CHECK(Cin == 32 || Cin == 64 || Cin == 128, "ptocr_conv1x1_small_k_f32: Cin must be 32, 64 or 128 (got %d)", Cin);
     PT_CHECK(Cout % 32 == 0 && Cout >= 32 && Cout <= PW_MAXC, "ptocr_conv1x1_small_k_f32: Cout must be a multiple of 32 up to %d", PW_MAXC);
+    PT_CHECK(Cin != 128 || Cout % 128 == 0, "ptocr_conv1x1_small_k_f32: with 128 input channels Cout must be a multiple of 128");
     PT_CHECK(act >= 0 && act <= 2, "ptocr_conv1x1_small_k_f32: activation must be none, ReLU or Hardswish");
     PT_CHECK(!res_up2 || (d_res && H % 2 == 0 && W % 2 == 0), "ptocr_conv1x1_small_k_f32: the upsample-add needs d_res and even H, W");
     PT_CHECK(out_ldc % 4 == 0 && out_coff % 4 == 0 && out_ldc >= out_coff + Cout, "ptocr_conv1x1_small_k_f32: channel strides must be multiples of 4");
@@ -187,6 +316,7 @@ extern "C" int ptocr_conv1x1_small_k_f32(const float *d_x, const float *d_w, con
     a.x_bytes = a.M * Cin * 4;
     PT_CHECK(a.x_bytes < (1L << 31), "ptocr_conv1x1_small_k_f32: tensor larger than 2 GiB");
     a.ntiles = (int)((a.M + PW_TM - 1) / PW_TM);
+    if (Cin == 128) return launch_pw128(a, Cout, (hipStream_t)stream);
     return Cin == 32 ? dispatch_pw<32>(a, (hipStream_t)stream) : dispatch_pw<64>(a, (hipStream_t)stream);
 }
 

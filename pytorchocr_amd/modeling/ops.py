@@ -100,7 +100,7 @@ class PackedConv:
         # pointwise layers with <= 64 input channels (the FPN lateral in2, MobileNetV3's wide early layers): W[k][cout], k-major,
         # channels zero-padded to the tensors' widths, for the LDS-resident-weights kernel
         self.pw_w = None
-        if (kh, kw) == (1, 1) and self.stride == 1 and (self.pad_h, self.pad_w) == (0, 0) and cin_pad in (32, 64) and c_tensor <= 256:
+        if (kh, kw) == (1, 1) and self.stride == 1 and (self.pad_h, self.pad_w) == (0, 0) and (cin_pad in (32, 64) or (cin_pad == 128 and c_tensor % 128 == 0)) and c_tensor <= 256:
             pw = torch.zeros(cin_pad, c_tensor, dtype=torch.float64)
             pw[:cin, :cout] = w.reshape(cout, cin).t()
             pb = torch.zeros(c_tensor, dtype=torch.float64)

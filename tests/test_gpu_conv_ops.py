@@ -308,20 +308,23 @@ def test_winograd_3x3_matches_torch(case, mode, monkeypatch):
     assert float((big[..., :64] - 3).abs().max()) == 0
 
 
-@pytest.mark.parametrize("case", [(2, 20, 36, 256), (1, 7, 9, 96), (3, 46, 80, 32), (1, 184, 320, 256)])
+@pytest.mark.parametrize("case", [(2, 20, 36, 256), (1, 7, 9, 96), (3, 46, 80, 32), (1, 184, 320, 256),
+                                  (2, 20, 36, 256, 128), (1, 7, 9, 128, 128), (3, 92, 160, 256, 128), (40, 2, 6, 128, 128)])
 def test_pointwise_k64_kernel(case):
-    """1x1 / Cin=64 kernel (FPN lateral in2): plain, with the nearest-x2 top-down add after the ReLU, into a concat slice;
-    pixel counts that are not multiples of the 128-pixel tile; and the generic kernel on the same layer"""
+    """1x1 kernels with LDS-resident weights, Cin = 64 (FPN lateral in2) and Cin = 128 (in3: half of the output channels per
+    workgroup): plain, with the nearest-x2 top-down add after the ReLU, into a concat slice; pixel counts that are not multiples of
+    the 128-pixel tile, fewer tiles than workgroups; and the generic kernel on the same layer"""
     from pytorchocr_amd.modeling import ops
-    N, H, W, Cout = case
+    N, H, W, Cout = case[:4]
+    Cin = case[4] if len(case) > 4 else 64
     dev = _dev()
-    conv = nn.Conv2d(64, Cout, 1, 1, 0, bias=False)
+    conv = nn.Conv2d(Cin, Cout, 1, 1, 0, bias=False)
     bn = nn.BatchNorm2d(Cout).eval()
     with torch.no_grad():
-        conv.weight.copy_(_rand(Cout, 64, 1, 1, seed=1) * 0.2)
+        conv.weight.copy_(_rand(Cout, Cin, 1, 1, seed=1) * 0.2)
         bn.weight.copy_(_rand(Cout, seed=3) * 0.4 + 1); bn.bias.copy_(_rand(Cout, seed=4) * 0.2)
         bn.running_mean.copy_(_rand(Cout, seed=5) * 0.2); bn.running_var.copy_(_rand(Cout, seed=6) * 0.5 + 1)
-    x = _rand(N, 64, H, W, seed=7)
+    x = _rand(N, Cin, H, W, seed=7)
     with torch.no_grad():
         ref = F.relu(bn(conv(x)))
     pc = ops.PackedConv(conv, bn, dev, relu=True)
