@@ -184,6 +184,9 @@ int ptocr_dwconv_bf16_nblk(int N, int H, int W, int k, int stride);
 /* SE gate from those sums: d_scale f32[N][C] = hardsigmoid(fc2(relu(fc1(sum / HW)))) (det_mobilenet_v3.py:76-85) */
 int ptocr_se_fc_f32(const float *d_partial, const float *d_w1, const float *d_b1, const float *d_w2, const float *d_b2,
                     float *d_scale, int N, int HW, int C, int S, int nblk, void *stream);
+/* the same gate from transposed weights d_w1t f32[C][S], d_w2t f32[S][C] (every load coalesced; what the bf16 path calls) */
+int ptocr_se_fc_t_f32(const float *d_partial, const float *d_w1t, const float *d_b1, const float *d_w2t, const float *d_b2,
+                      float *d_scale, int N, int HW, int C, int S, int nblk, void *stream);
 /* stem: conv 3x3 / s2 / p1 of the model input f32[N,3,H,W] -> bf16[N,Ho,Wo,16]; d_w f32[27][16] (row (c*3 + ky)*3 + kx), BN folded */
 int ptocr_stem3x3s2_bf16(const float *d_x, const float *d_w, const float *d_bias, void *d_y, int N, int H, int W, int act, void *stream);
 /* DB head tail for C = 24: ConvT(C,C,2,2)+BN+ReLU -> ConvT(C,1,2,2)+bias -> sigmoid; d_x bf16[N,H,W,ldc] -> d_maps f32[N,4H,4W];

@@ -191,7 +191,14 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(C3Args p) {
 // 10 x 34 halo patch once (every input byte leaves HBM / L2 once, 1.33x with the halo, instead of nine times through a thrashing
 // L1), and its four waves (two output rows each) read their B fragments from LDS.  Pixel stride in LDS = 2 Cin + 16 bytes: the 16
 // lanes of a ds_read_b128 group then fall on 16 different 16-byte bank slots (13 r mod 16 is a permutation).
+// NCS = Cin / 16 at compile time (0: run-time count): the tap loop is unrolled and the weight fragments of tap t+1 are requested before
+// the MFMAs of tap t -- with a run-time inner loop every MFMA pair waited for its own 16-byte weight load from global memory (54
+// dependent L1 round trips per tile, several times the MFMA time).
+#ifndef C3_DBG
+#define C3_DBG 0             // timing experiments only: 1 no patch loads, 2 no MFMA loop, 4 no stores
+#endif
 constexpr int C3_TH = 8, C3_TW = 32, C3_MAXCIN = 96;
+template <int NCS>
 __global__ __launch_bounds__(256) void conv3x3_bf16_lds_kernel(C3Args p) {
     __shared__ __attribute__((aligned(16))) unsigned char patch[(C3_TH + 2) * (C3_TW + 2) * (2 * C3_MAXCIN + 16)];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -199,14 +206,27 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_lds_kernel(C3Args p) {
     const int tiles_x = cdiv(p.W, C3_TW);
     const int n = blockIdx.y;
     const int ty0 = (blockIdx.x / tiles_x) * C3_TH, tx0 = (blockIdx.x % tiles_x) * C3_TW;
-    const int stride = 2 * p.Cin + 16, nch = p.Cin >> 3;
+    const int nch = NCS > 0 ? 2 * NCS : p.Cin >> 3;             // compile-time where it can be: the piece -> (pixel, chunk) divisions
+    const int stride = 16 * nch + 16;
     const __bf16 *ximg = p.x + (long)n * p.H * p.W * p.Cin;
-    for (int i = threadIdx.x; i < (C3_TH + 2) * (C3_TW + 2) * nch; i += 256) {
+    // all loads of a thread first (16 in flight for Cin = 96), then the LDS stores: load -> store per iteration is 16 serial round trips
+    constexpr int C3_NLD = ((C3_TH + 2) * (C3_TW + 2) * (C3_MAXCIN / 8) + 255) / 256;
+    const int npiece = (C3_TH + 2) * (C3_TW + 2) * nch;
+    bf16x8 pv[C3_NLD];
+#pragma unroll
+    for (int k = 0; k < C3_NLD; k++) {
+        const int i = threadIdx.x + 256 * k;
         const int pix = i / nch, ch = i - pix * nch;
         const int iy = ty0 - 1 + pix / (C3_TW + 2), ix = tx0 - 1 + pix % (C3_TW + 2);
-        bf16x8 v = zero8();
-        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v = *reinterpret_cast<const bf16x8 *>(ximg + ((long)iy * p.W + ix) * p.Cin + ch * 8);
-        *reinterpret_cast<bf16x8 *>(patch + pix * stride + ch * 16) = v;
+        pv[k] = zero8();
+        if (!(C3_DBG & 1) && i < npiece && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+            pv[k] = *reinterpret_cast<const bf16x8 *>(ximg + ((long)iy * p.W + ix) * p.Cin + ch * 8);
+    }
+#pragma unroll
+    for (int k = 0; k < C3_NLD; k++) {
+        const int i = threadIdx.x + 256 * k;
+        const int pix = i / nch, ch = i - pix * nch;
+        if (i < npiece) *reinterpret_cast<bf16x8 *>(patch + pix * stride + ch * 16) = pv[k];
     }
     __syncthreads();
     f32x16 acc[2];
@@ -214,20 +234,45 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_lds_kernel(C3Args p) {
     for (int j = 0; j < 2; j++)
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[j][i] = 0.f;
-    const int ncs = p.Cin >> 4;
     const __bf16 *wrow = p.w + (long)r * 9 * p.Cin + 8 * h;
-    for (int tap = 0; tap < 9; tap++) {
-        const int dy = tap / 3, dx = tap % 3;                   // patch coordinates of the tap: (row + dy, col + dx)
-        const unsigned char *b0 = patch + ((2 * wave + dy) * (C3_TW + 2) + r + dx) * stride + 16 * h;
-        const unsigned char *b1 = b0 + (C3_TW + 2) * stride;
-        for (int cs = 0; cs < ncs; cs++) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(wrow + tap * p.Cin + cs * 16);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, *reinterpret_cast<const bf16x8 *>(b0 + cs * 32), acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, *reinterpret_cast<const bf16x8 *>(b1 + cs * 32), acc[1], 0, 0, 0);
+    if (C3_DBG & 2) { acc[0][0] = patch[threadIdx.x]; }
+    else if (NCS > 0) {
+        bf16x8 a_cur[NCS > 0 ? NCS : 1], a_nxt[NCS > 0 ? NCS : 1];
+#pragma unroll
+        for (int cs = 0; cs < NCS; cs++) a_cur[cs] = *reinterpret_cast<const bf16x8 *>(wrow + cs * 16);
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int dy = tap / 3, dx = tap % 3;               // patch coordinates of the tap: (row + dy, col + dx)
+            const unsigned char *b0 = patch + ((2 * wave + dy) * (C3_TW + 2) + r + dx) * stride + 16 * h;
+            const unsigned char *b1 = b0 + (C3_TW + 2) * stride;
+            if (tap < 8) {
+#pragma unroll
+                for (int cs = 0; cs < NCS; cs++) a_nxt[cs] = *reinterpret_cast<const bf16x8 *>(wrow + (tap + 1) * p.Cin + cs * 16);
+            }
+#pragma unroll
+            for (int cs = 0; cs < NCS; cs++) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[cs], *reinterpret_cast<const bf16x8 *>(b0 + cs * 32), acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[cs], *reinterpret_cast<const bf16x8 *>(b1 + cs * 32), acc[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int cs = 0; cs < NCS; cs++) a_cur[cs] = a_nxt[cs];
+        }
+    } else {
+        const int ncs = p.Cin >> 4;
+        for (int tap = 0; tap < 9; tap++) {
+            const int dy = tap / 3, dx = tap % 3;
+            const unsigned char *b0 = patch + ((2 * wave + dy) * (C3_TW + 2) + r + dx) * stride + 16 * h;
+            const unsigned char *b1 = b0 + (C3_TW + 2) * stride;
+            for (int cs = 0; cs < ncs; cs++) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(wrow + tap * p.Cin + cs * 16);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, *reinterpret_cast<const bf16x8 *>(b0 + cs * 32), acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, *reinterpret_cast<const bf16x8 *>(b1 + cs * 32), acc[1], 0, 0, 0);
+            }
         }
     }
     const int U = p.out_up, ox = tx0 + r;
     if (ox >= p.W) return;
+    if ((C3_DBG & 4) && acc[0][0] != 123.25f) return;
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int oy = ty0 + 2 * wave + j;
@@ -244,6 +289,114 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_lds_kernel(C3Args p) {
                 for (int ux = 0; ux < U; ux++)
                     *reinterpret_cast<bf16x4 *>(p.y + (((long)n * p.H * U + oy * U + uy) * ((long)p.W * U) + ox * U + ux) * p.out_ldc + p.out_coff + c) = o;
         }
+    }
+}
+
+// Persistent form for Cin = 16 NCS: a workgroup walks tiles (image-major), the patch of tile t+1 travels global -> registers while
+// tile t computes, and the outputs leave through LDS as 16-byte pieces (a pixel's cstore channels are contiguous: 48 bytes for 24
+// channels = three pieces instead of six 8-byte stores into a 192-byte-stride concat buffer).  Measured on the 32 x 184 x 320 layer
+// before: patch loads 170 us + MFMA loop 185 us (LDS-feed bound) + stores 105 us, added up (one block does them one after the other
+// and only two fit a CU): 345 us.
+template <int NCS>
+__global__ __launch_bounds__(256) void conv3x3_bf16_pers_kernel(C3Args p, int tiles_x, int tiles_per_img, int total) {
+    constexpr int NCH = 2 * NCS, STRIDE = 16 * NCH + 16;
+    constexpr int NPIECE = (C3_TH + 2) * (C3_TW + 2) * NCH;
+    constexpr int NLD = (NPIECE + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char patch[(C3_TH + 2) * (C3_TW + 2) * STRIDE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    bf16x8 pv[NLD];
+    int n, ty0, tx0;
+    auto decode = [&](int t) {
+        n = t / tiles_per_img;
+        const int rem = t - n * tiles_per_img;
+        ty0 = (rem / tiles_x) * C3_TH; tx0 = (rem % tiles_x) * C3_TW;
+    };
+    auto gload = [&]() {
+        const __bf16 *ximg = p.x + (long)n * p.H * p.W * p.Cin;
+#pragma unroll
+        for (int k = 0; k < NLD; k++) {
+            const int i = threadIdx.x + 256 * k;
+            const int pix = i / NCH, ch = i - pix * NCH;
+            const int iy = ty0 - 1 + pix / (C3_TW + 2), ix = tx0 - 1 + pix % (C3_TW + 2);
+            pv[k] = zero8();
+            if (i < NPIECE && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                pv[k] = *reinterpret_cast<const bf16x8 *>(ximg + ((long)iy * p.W + ix) * p.Cin + ch * 8);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int k = 0; k < NLD; k++) {
+            const int i = threadIdx.x + 256 * k;
+            const int pix = i / NCH, ch = i - pix * NCH;
+            if (i < NPIECE) *reinterpret_cast<bf16x8 *>(patch + pix * STRIDE + ch * 16) = pv[k];
+        }
+    };
+    const __bf16 *wrow = p.w + (long)r * 9 * p.Cin + 8 * h;
+    const int U = p.out_up, CS = p.cstore, PCS = CS >> 3;            // 16-byte pieces per output pixel
+
+    int tile = blockIdx.x;
+    decode(tile);
+    gload();
+    lstore();
+    __syncthreads();
+    for (;;) {
+        const int c_n = n, c_ty0 = ty0, c_tx0 = tx0;
+        const int next = tile + (int)gridDim.x;
+        const bool has_next = next < total;
+        if (has_next) { decode(next); gload(); }                 // in flight during this tile's MFMAs
+
+        f32x16 acc[2];
+        acc[0] = (f32x16)(0.f); acc[1] = (f32x16)(0.f);
+        bf16x8 a_cur[NCS], a_nxt[NCS];
+#pragma unroll
+        for (int cs = 0; cs < NCS; cs++) a_cur[cs] = *reinterpret_cast<const bf16x8 *>(wrow + cs * 16);
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int dy = tap / 3, dx = tap % 3;
+            const unsigned char *b0 = patch + ((2 * wave + dy) * (C3_TW + 2) + r + dx) * STRIDE + 16 * h;
+            const unsigned char *b1 = b0 + (C3_TW + 2) * STRIDE;
+            if (tap < 8) {
+#pragma unroll
+                for (int cs = 0; cs < NCS; cs++) a_nxt[cs] = *reinterpret_cast<const bf16x8 *>(wrow + (tap + 1) * p.Cin + cs * 16);
+            }
+#pragma unroll
+            for (int cs = 0; cs < NCS; cs++) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[cs], *reinterpret_cast<const bf16x8 *>(b0 + cs * 32), acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[cs], *reinterpret_cast<const bf16x8 *>(b1 + cs * 32), acc[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int cs = 0; cs < NCS; cs++) a_cur[cs] = a_nxt[cs];
+        }
+        __syncthreads();                                         // the patch is consumed: its LDS now stages the outputs
+        __bf16 *ob = reinterpret_cast<__bf16 *>(patch);          // [8 rows][32 cols][CS]
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int c = 8 * g + 4 * h;
+                if (c >= CS) continue;
+                const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + c);
+                bf16x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; q++) o[q] = (__bf16)actf(acc[j][4 * g + q] + bias[q], p.act);
+                *reinterpret_cast<bf16x4 *>(ob + ((2 * wave + j) * C3_TW + r) * CS + c) = o;
+            }
+        __syncthreads();
+        for (int i = threadIdx.x; i < C3_TH * C3_TW * PCS; i += 256) {
+            const int px = i / PCS, part = i - px * PCS;
+            const int oy = c_ty0 + px / C3_TW, ox = c_tx0 + px % C3_TW;
+            if (oy >= p.H || ox >= p.W) continue;
+            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(ob + px * CS + part * 8);
+            __bf16 *dst = p.y + (((long)c_n * p.H * U + oy * U) * ((long)p.W * U) + ox * U) * p.out_ldc + p.out_coff + part * 8;
+            for (int uy = 0; uy < U; uy++)
+                for (int ux = 0; ux < U; ux++) *reinterpret_cast<bf16x8 *>(dst + ((long)uy * p.W * U + ux) * p.out_ldc) = v;
+        }
+        if (!has_next) break;
+        __syncthreads();                                         // output staging read: the LDS takes the next patch
+        lstore();
+        __syncthreads();
+        tile = next;
     }
 }
 
@@ -270,40 +423,74 @@ struct DwArgs {
     int H, W, C, k, stride, Ho, Wo, act, nblk, chunk;
 };
 
+// K, S compile-time (taps unrolled); a thread walks RUNS of 4 consecutive outputs of one row: the (3 S + K) input columns of a run are
+// loaded once per kernel row and feed all four outputs (5x5 / s1: 40 loads per 4 outputs instead of 100), the weights and the bias
+// sit in LDS (the first version re-read them from global memory per tap: 75 loads per output pixel made the layer issue-bound at
+// 7x its HBM time).  A block owns whole output rows (p.chunk of them).
+template <int K, int S>
 __global__ __launch_bounds__(256) void dwconv_bf16_kernel(DwArgs p) {
-    __shared__ float red[256][8];
+    constexpr int R = 4, NC = (R - 1) * S + K, PAD = (K - 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) float dw_lds[];
+    float *wl = dw_lds;                                         // [K*K][C] tap-major, then [C] bias
+    float (*red)[8] = reinterpret_cast<float (*)[8]>(dw_lds + (K * K + 1) * p.C);
+    for (int i = threadIdx.x; i < (K * K) * p.C; i += 256) wl[i] = p.w[i];
+    for (int i = threadIdx.x; i < p.C; i += 256) wl[K * K * p.C + i] = p.bias[i];
+    __syncthreads();
     const int n = blockIdx.y, blk = blockIdx.x;
     const int C8 = p.C >> 3;
     const int L = 256 / C8;
     const int q = threadIdx.x % C8, pl = threadIdx.x / C8;
-    const int pad = (p.k - 1) >> 1;
-    const int HWo = p.Ho * p.Wo;
-    const int p0 = blk * p.chunk, p1 = min(p0 + p.chunk, HWo);
+    const int runs_x = (p.Wo + R - 1) / R;
+    const int r0 = blk * p.chunk, r1 = min(r0 + p.chunk, p.Ho);
+    const int nruns = (r1 - r0) * runs_x;
     float sum[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) sum[j] = 0.f;
     if (pl < L) {
-        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(p.bias + q * 8), b1 = *reinterpret_cast<const f32x4 *>(p.bias + q * 8 + 4);
-        for (int pix = p0 + pl; pix < p1; pix += L) {
-            const int oy = pix / p.Wo, ox = pix - oy * p.Wo;
-            float acc[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-            for (int a = 0; a < p.k; a++) {
-                const int iy = oy * p.stride - pad + a;
-                if ((unsigned)iy >= (unsigned)p.H) continue;
-                for (int b = 0; b < p.k; b++) {
-                    const int ix = ox * p.stride - pad + b;
-                    if ((unsigned)ix >= (unsigned)p.W) continue;
-                    const bf16x8 v = *reinterpret_cast<const bf16x8 *>(p.x + (((long)n * p.H + iy) * p.W + ix) * p.C + q * 8);
-                    const float *wp = p.w + (long)(a * p.k + b) * p.C + q * 8;
-                    const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wp), w1 = *reinterpret_cast<const f32x4 *>(wp + 4);
+        const float *bl = wl + K * K * p.C + q * 8;
+        for (int run = pl; run < nruns; run += L) {
+            const int ry = run / runs_x;
+            const int oy = r0 + ry, ox0 = (run - ry * runs_x) * R;
+            float acc[R][8];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) { acc[j] += (float)v[j] * w0[j]; acc[4 + j] += (float)v[4 + j] * w1[j]; }
+            for (int r = 0; r < R; r++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc[r][j] = bl[j];
+#pragma unroll
+            for (int a = 0; a < K; a++) {
+                const int iy = oy * S - PAD + a;
+                if ((unsigned)iy >= (unsigned)p.H) continue;
+                float wr[K][8];
+#pragma unroll
+                for (int b = 0; b < K; b++) {
+                    const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wl + (a * K + b) * p.C + q * 8), w1 = *reinterpret_cast<const f32x4 *>(wl + (a * K + b) * p.C + q * 8 + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { wr[b][j] = w0[j]; wr[b][4 + j] = w1[j]; }
+                }
+                const __bf16 *row = p.x + (((long)n * p.H + iy) * p.W) * p.C + q * 8;
+#pragma unroll
+                for (int ci = 0; ci < NC; ci++) {
+                    const int ix = ox0 * S - PAD + ci;
+                    if ((unsigned)ix >= (unsigned)p.W) continue;
+                    const bf16x8 v = *reinterpret_cast<const bf16x8 *>(row + (long)ix * p.C);
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int b = ci - r * S;                 // compile-time: the tap this column is for output r of the run
+                        if (b >= 0 && b < K) {
+#pragma unroll
+                            for (int j = 0; j < 8; j++) acc[r][j] += (float)v[j] * wr[b][j];
+                        }
+                    }
                 }
             }
-            bf16x8 o;
 #pragma unroll
-            for (int j = 0; j < 8; j++) { const float t = actf(acc[j], p.act); sum[j] += t; o[j] = (__bf16)t; }
-            *reinterpret_cast<bf16x8 *>(p.y + ((long)n * HWo + pix) * p.C + q * 8) = o;
+            for (int r = 0; r < R; r++) {
+                if (ox0 + r >= p.Wo) continue;
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; j++) { const float t = actf(acc[r][j], p.act); sum[j] += t; o[j] = (__bf16)t; }
+                *reinterpret_cast<bf16x8 *>(p.y + (((long)n * p.Ho + oy) * p.Wo + ox0 + r) * p.C + q * 8) = o;
+            }
         }
     }
     if (!p.partial) return;
@@ -318,6 +505,24 @@ __global__ __launch_bounds__(256) void dwconv_bf16_kernel(DwArgs p) {
 #pragma unroll
         for (int j = 0; j < 8; j++) dst[j] = sum[j];
     }
+}
+
+template <int K, int S>
+static int launch_dw(const DwArgs &p, int N, hipStream_t stream) {
+    const size_t lds = sizeof(float) * ((size_t)(K * K + 1) * p.C + 256 * 8);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dwconv_bf16_kernel<K, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL((dwconv_bf16_kernel<K, S>), dim3(p.nblk, N), dim3(256), lds, stream, p);
+    return launch_ok("dwconv_bf16_kernel");
+}
+
+// output rows per block: the pixel budget of dw_chunk in whole rows
+static inline int dw_rows(int N, int Ho, int Wo) {
+    const int r = dw_chunk(N, Ho * Wo) / Wo;
+    return r < 1 ? 1 : r;
 }
 
 // ---------------------------------------------------------------------------------------------- stem: 3x3 / stride 2 / pad 1, RGB
@@ -443,8 +648,23 @@ extern "C" int ptocr_conv3x3_bf16(const void *d_x, const void *d_w, const float 
     const long blocks = (p.M + 127) / 128;
     PT_CHECK(blocks < (1L << 31), "ptocr_conv3x3_bf16: too many pixels");
     static const bool use_lds = !(getenv("PTOCR_BF16_C3_LDS") && atoi(getenv("PTOCR_BF16_C3_LDS")) == 0);
+    if (use_lds && Cin == 96 && cstore % 8 == 0 && out_coff % 8 == 0 && out_ldc % 8 == 0) {     // the FPN / head convs of the mbv3 detector
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            PT_HIP(hipGetDevice(&dev));
+            PT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        }
+        const int tiles_x = cdiv(W, C3_TW), tpi = tiles_x * cdiv(H, C3_TH);
+        const long total = (long)N * tpi;
+        PT_CHECK(total < (1L << 31), "ptocr_conv3x3_bf16: too many tiles");
+        const int grid = total < 2L * n_cu ? (int)total : 2 * n_cu;          // two persistent workgroups per CU (71 KB of LDS each)
+        hipLaunchKernelGGL(conv3x3_bf16_pers_kernel<6>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, tiles_x, tpi, (int)total);
+        return launch_ok("conv3x3_bf16_pers_kernel");
+    }
     if (use_lds && Cin <= C3_MAXCIN && N <= 65535) {
-        hipLaunchKernelGGL(conv3x3_bf16_lds_kernel, dim3(cdiv(W, C3_TW) * cdiv(H, C3_TH), N), dim3(256), 0, (hipStream_t)stream, p);
+        if (Cin == 96) hipLaunchKernelGGL(conv3x3_bf16_lds_kernel<6>, dim3(cdiv(W, C3_TW) * cdiv(H, C3_TH), N), dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(conv3x3_bf16_lds_kernel<0>, dim3(cdiv(W, C3_TW) * cdiv(H, C3_TH), N), dim3(256), 0, (hipStream_t)stream, p);
         return launch_ok("conv3x3_bf16_lds_kernel");
     }
     hipLaunchKernelGGL(conv3x3_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
@@ -459,16 +679,17 @@ extern "C" int ptocr_dwconv_bf16(const void *d_x, const float *d_w, const float 
     DwArgs p;
     p.x = (const __bf16 *)d_x; p.w = d_w; p.bias = d_bias; p.y = (__bf16 *)d_y; p.partial = d_partial; p.H = H; p.W = W; p.C = C; p.k = k;
     p.stride = stride; p.Ho = (H + 2 * pad - k) / stride + 1; p.Wo = (W + 2 * pad - k) / stride + 1; p.act = act;
-    p.chunk = dw_chunk(N, p.Ho * p.Wo);
-    p.nblk = cdiv(p.Ho * p.Wo, p.chunk);
-    hipLaunchKernelGGL(dwconv_bf16_kernel, dim3(p.nblk, N), dim3(256), 0, (hipStream_t)stream, p);
-    return launch_ok("dwconv_bf16_kernel");
+    p.chunk = dw_rows(N, p.Ho, p.Wo);
+    p.nblk = cdiv(p.Ho, p.chunk);
+    PT_CHECK((size_t)(k * k + 1) * C * 4 + 8192 <= 160 * 1024, "ptocr_dwconv_bf16: weights do not fit LDS (C = %d)", C);
+    if (k == 3) return stride == 1 ? launch_dw<3, 1>(p, N, (hipStream_t)stream) : launch_dw<3, 2>(p, N, (hipStream_t)stream);
+    return stride == 1 ? launch_dw<5, 1>(p, N, (hipStream_t)stream) : launch_dw<5, 2>(p, N, (hipStream_t)stream);
 }
 
 extern "C" int ptocr_dwconv_bf16_nblk(int N, int H, int W, int k, int stride) {
     const int pad = (k - 1) / 2;
-    const int HWo = ((H + 2 * pad - k) / stride + 1) * ((W + 2 * pad - k) / stride + 1);
-    return cdiv(HWo, dw_chunk(N, HWo));
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    return cdiv(Ho, dw_rows(N, Ho, Wo));
 }
 
 extern "C" int ptocr_stem3x3s2_bf16(const float *d_x, const float *d_w, const float *d_bias, void *d_y, int N, int H, int W, int act, void *stream) {

@@ -94,6 +94,66 @@ __global__ __launch_bounds__(256) void se_fc_kernel(const float *__restrict__ pa
     }
 }
 
+// the same gate from TRANSPOSED weights (w1t f32[C][S], w2t f32[S][C]): a thread per output whose loads are coalesced across the
+// threads and independent of each other -- with the row-major layouts above a thread walks its own row (576 dependent strided
+// loads: 74 us for a 32 x 576 vector); this form takes a few microseconds
+__global__ __launch_bounds__(256) void se_fc_t_kernel(const float *__restrict__ partial, const float *__restrict__ w1t, const float *__restrict__ b1,
+                                                      const float *__restrict__ w2t, const float *__restrict__ b2, float *__restrict__ scale,
+                                                      int HW, int C, int S, int nblk) {
+    const int n = blockIdx.x;
+    __shared__ float mean[1024], mid[256];
+    for (int c = threadIdx.x; c < C; c += 256) {                 // block sums in their fixed order, eight loads in flight
+        const float *pp = partial + (long)n * nblk * C + c;
+        float s = 0.f;
+        int b = 0;
+        for (; b + 7 < nblk; b += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = pp[(long)(b + u) * C];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += v[u];
+        }
+        for (; b < nblk; b++) s += pp[(long)b * C];
+        mean[c] = s / (float)HW;
+    }
+    __syncthreads();
+    // latency, not bandwidth, is what these tiny products cost (one block per image, a handful of waves per CU): sixteen independent
+    // loads in flight per thread and round
+    for (int j = threadIdx.x; j < S; j += 256) {
+        float a[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) a[u] = 0.f;
+        int c = 0;
+        for (; c + 15 < C; c += 16) {
+#pragma unroll
+            for (int u = 0; u < 16; u++) a[u] += w1t[(c + u) * S + j] * mean[c + u];
+        }
+        for (; c < C; c++) a[0] += w1t[c * S + j] * mean[c];
+#pragma unroll
+        for (int u = 8; u > 0; u >>= 1)
+#pragma unroll
+            for (int v = 0; v < u; v++) a[v] += a[v + u];
+        mid[j] = fmaxf(a[0] + b1[j], 0.f);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) a[u] = 0.f;
+        int j = 0;
+        for (; j + 15 < S; j += 16) {
+#pragma unroll
+            for (int u = 0; u < 16; u++) a[u] += w2t[(j + u) * C + c] * mid[j + u];
+        }
+        for (; j < S; j++) a[0] += w2t[j * C + c] * mid[j];
+#pragma unroll
+        for (int u = 8; u > 0; u >>= 1)
+#pragma unroll
+            for (int v = 0; v < u; v++) a[v] += a[v + u];
+        scale[(long)n * C + c] = fminf(fmaxf(a[0] + b2[c] + 3.f, 0.f), 6.f) * (1.f / 6.f);       // hardsigmoid
+    }
+}
+
 __global__ __launch_bounds__(256) void se_apply_kernel(float *__restrict__ x, const float *__restrict__ scale, int HW, int C4, long total) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4);
@@ -183,6 +243,15 @@ extern "C" int ptocr_se_scale_f32(float *d_x, const float *d_w1, const float *d_
 
 // Squeeze-Excitation gate alone (det_mobilenet_v3.py:76-85 without the pooling pass and without the multiply): d_partial
 // f32[N][nblk][C] per-chunk channel sums (left by ptocr_dwconv_bf16) -> d_scale f32[N][C] = hardsigmoid(fc2(relu(fc1(mean)))).
+// the same from transposed weights d_w1t f32[C][S], d_w2t f32[S][C] (coalesced, a few microseconds; same result up to fp32 summation order)
+extern "C" int ptocr_se_fc_t_f32(const float *d_partial, const float *d_w1t, const float *d_b1, const float *d_w2t, const float *d_b2,
+                                 float *d_scale, int N, int HW, int C, int S, int nblk, void *stream) {
+    PT_CHECK(d_partial && d_w1t && d_b1 && d_w2t && d_b2 && d_scale && C <= 1024 && S <= 256 && N >= 1 && HW >= 1 && nblk >= 1,
+             "ptocr_se_fc_t_f32: bad arguments (C <= 1024, S <= 256)");
+    hipLaunchKernelGGL(se_fc_t_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, d_partial, d_w1t, d_b1, d_w2t, d_b2, d_scale, HW, C, S, nblk);
+    return launch_ok("se_fc_t_kernel");
+}
+
 extern "C" int ptocr_se_fc_f32(const float *d_partial, const float *d_w1, const float *d_b1, const float *d_w2, const float *d_b2,
                                float *d_scale, int N, int HW, int C, int S, int nblk, void *stream) {
     PT_CHECK(d_partial && d_w1 && d_b1 && d_w2 && d_b2 && d_scale && C <= 1024 && S <= 256 && N >= 1 && HW >= 1 && nblk >= 1,

@@ -102,6 +102,7 @@ class _Se:
         w2p = torch.zeros(cpad, s, dtype=torch.float64); w2p[:c] = w2
         b2p = torch.full((cpad,), -3.0, dtype=torch.float64); b2p[:c] = se.fc2.bias.detach().double().cpu()
         self.w1, self.b1, self.w2, self.b2, self.s, self.c = _f(w1p, dev), _f(se.fc1.bias.detach().cpu(), dev), _f(w2p, dev), _f(b2p, dev), s, cpad
+        self.w1t, self.w2t = _f(w1p.t().contiguous(), dev), _f(w2p.t().contiguous(), dev)      # [C][S], [S][C]: the gate kernel's coalesced form
 
 
 def _ptr(t):
@@ -155,8 +156,8 @@ def dwconv(x, dw, want_pool):
 def se_gate(partial, nblk, se, hw):
     n = partial.shape[0]
     scale = torch.empty((n, se.c), dtype=torch.float32, device=partial.device)
-    _lib.check(_lib.lib().ptocr_se_fc_f32(_ptr(partial), _ptr(se.w1), _ptr(se.b1), _ptr(se.w2), _ptr(se.b2), _ptr(scale), n, hw, se.c, se.s, nblk,
-                                          _lib.cur_stream()), "ptocr_se_fc_f32")
+    _lib.check(_lib.lib().ptocr_se_fc_t_f32(_ptr(partial), _ptr(se.w1t), _ptr(se.b1), _ptr(se.w2t), _ptr(se.b2), _ptr(scale), n, hw, se.c, se.s, nblk,
+                                            _lib.cur_stream()), "ptocr_se_fc_t_f32")
     return scale
 
 
