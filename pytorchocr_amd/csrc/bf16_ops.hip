@@ -609,6 +609,84 @@ __global__ __launch_bounds__(256) void head_tail_bf16_kernel(const __bf16 *__res
     }
 }
 
+// The same tail on the matrix pipe: GEMM 1 (24 -> 4 x 24, per input pixel) as v_mfma_f32_32x32x16_bf16 with A = weights (rows = mid
+// channels, bf16, zero-padded 24 -> 32 in both directions; eight fragments per lane, loaded once), B = 32 pixels straight from global
+// memory; the lane then holds 16 mid channels of ONE pixel per (a, b) position, and the second contraction (24 -> 4 outputs) is
+// register-local FMAs against per-lane copies of w2 / b1 plus one lane^32 exchange.  The scalar version spent 2304 LDS weight reads
+// per pixel (307 us for 32 x 184 x 320).
+__global__ __launch_bounds__(256) void head_tail_bf16_mfma_kernel(const __bf16 *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1,
+                                                                  const float *__restrict__ w2, float b2, float *__restrict__ maps, int H, int W,
+                                                                  int ldc, long total) {
+    const int lane = threadIdx.x & 63;
+    const int c = lane & 31, h = lane >> 5;
+    // A fragments: A[r = co][k = ci]: lane (r, h) holds ci = 16 ks + 8 h + j
+    bf16x8 af[4][2];
+#pragma unroll
+    for (int ab = 0; ab < 4; ab++)
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int ci = 16 * ks + 8 * h + j;
+                af[ab][ks][j] = (__bf16)((c < HT_C && ci < HT_C) ? w1[(ab * HT_C + ci) * HT_C + c] : 0.f);
+            }
+    // this lane's mid channels: co = (i & 3) + 8 (i >> 2) + 4 h
+    float lb1[16], lw2[4][16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int co = (i & 3) + 8 * (i >> 2) + 4 * h;
+        lb1[i] = co < HT_C ? b1[co] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; q++) lw2[q][i] = co < HT_C ? w2[q * HT_C + co] : 0.f;
+    }
+    const long nwave = (long)gridDim.x * 4, wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (long p0 = wid * 32; p0 < total; p0 += nwave * 32) {
+        const long pix = p0 + c;
+        const bool live = pix < total;
+        const __bf16 *xp = x + (live ? pix : 0) * ldc;
+        bf16x8 bq0 = *reinterpret_cast<const bf16x8 *>(xp + 8 * h);
+        bf16x8 bq1 = zero8();
+        if (h == 0) bq1 = *reinterpret_cast<const bf16x8 *>(xp + 16);       // channels 16..23; 24..31 (h = 1) are padding: zeros
+        float o[4][4];
+#pragma unroll
+        for (int ab = 0; ab < 4; ab++) {
+            f32x16 acc = (f32x16)(0.f);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ab][0], bq0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ab][1], bq1, acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; q++) o[ab][q] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const float mid = fmaxf(acc[i] + lb1[i], 0.f);
+#pragma unroll
+                for (int q = 0; q < 4; q++) o[ab][q] += mid * lw2[q][i];
+            }
+        }
+#pragma unroll
+        for (int ab = 0; ab < 4; ab++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) o[ab][q] += __shfl_xor(o[ab][q], 32);
+        if (live && h == 0) {
+            const int ox = (int)(pix % W);
+            const long t = pix / W;
+            const int oy = (int)(t % H);
+            const long n = t / H;
+            float *out = maps + ((n * 4 * H + 4 * oy) * (4L * W) + 4 * ox);
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int a2 = 0; a2 < 2; a2++) {
+                    f32x4 row;
+                    row[0] = 1.f / (1.f + expf(-(o[a * 2 + 0][a2 * 2 + 0] + b2)));
+                    row[1] = 1.f / (1.f + expf(-(o[a * 2 + 0][a2 * 2 + 1] + b2)));
+                    row[2] = 1.f / (1.f + expf(-(o[a * 2 + 1][a2 * 2 + 0] + b2)));
+                    row[3] = 1.f / (1.f + expf(-(o[a * 2 + 1][a2 * 2 + 1] + b2)));
+                    *reinterpret_cast<f32x4 *>(out + (long)(2 * a + a2) * (4L * W)) = row;
+                }
+        }
+    }
+}
+
 }  // namespace ptocr
 
 using namespace ptocr;
@@ -705,7 +783,15 @@ extern "C" int ptocr_db_head_tail_bf16(const void *d_x, const float *d_w1, const
                                        int N, int H, int W, int C, int ldc, void *stream) {
     PT_CHECK(d_x && d_w1 && d_b1 && d_w2 && d_maps && C == HT_C && ldc >= C && ldc % 8 == 0, "ptocr_db_head_tail_bf16: built for C == %d (got %d)", HT_C, C);
     const long total = (long)N * H * W;
-    hipLaunchKernelGGL(head_tail_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)d_x, d_w1, d_b1,
-                       d_w2, b2, d_maps, H, W, ldc, total);
-    return launch_ok("head_tail_bf16_kernel");
+    static const bool scalar = getenv("PTOCR_BF16_TAIL_SCALAR") && atoi(getenv("PTOCR_BF16_TAIL_SCALAR")) != 0;
+    if (scalar || ldc < 24) {
+        hipLaunchKernelGGL(head_tail_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)d_x, d_w1, d_b1,
+                           d_w2, b2, d_maps, H, W, ldc, total);
+        return launch_ok("head_tail_bf16_kernel");
+    }
+    const long groups = (total + 127) / 128;
+    const unsigned grid = (unsigned)(groups < 1024 ? groups : 1024);   // few, long-lived waves: the per-lane weight registers are set up once per wave
+    hipLaunchKernelGGL(head_tail_bf16_mfma_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)d_x, d_w1, d_b1, d_w2, b2, d_maps,
+                       H, W, ldc, total);
+    return launch_ok("head_tail_bf16_mfma_kernel");
 }
