@@ -405,12 +405,13 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_pers_kernel(C3Args p, int ti
 // computes 8 channels of its pixels (16-byte loads and stores, fp32 arithmetic).  With `partial` set the kernel also leaves the
 // per-channel sum of its chunk (of the ACTIVATED fp32 values, combined over the pixel lanes in a fixed order) for the
 // Squeeze-Excitation average pool, so that pool never reads the tensor again.
-// pixels per block: about 64 blocks per image whatever the map size (a 23 x 40 map in 1024-pixel chunks would put ONE block per
+// pixels per block: about 24 blocks per image whatever the map size (each block first stages the layer's weights in LDS: fewer,
+// longer blocks amortise that; 64 per image cost the 5x5 layers on the small maps a third of their time) (a 23 x 40 map in 1024-pixel chunks would put ONE block per
 // image on a 256-CU chip, each thread walking hundreds of pixels).  A function of the map size only, never of the batch: the
 // chunking fixes the summation order of the SE pool, and an image's result must not depend on the batch it travels in.
 static inline int dw_chunk(int N, int HWo) {
     (void)N;
-    long c = (HWo + 63) / 64;
+    long c = (HWo + 23) / 24;
     c = (c + 15) / 16 * 16;
     return (int)(c < 16 ? 16 : (c > 1024 ? 1024 : c));
 }
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(256) void dwconv_bf16_kernel(DwArgs p) {
     extern __shared__ __attribute__((aligned(16))) float dw_lds[];
     float *wl = dw_lds;                                         // [K*K][C] tap-major, then [C] bias
     float (*red)[8] = reinterpret_cast<float (*)[8]>(dw_lds + (K * K + 1) * p.C);
-    for (int i = threadIdx.x; i < (K * K) * p.C; i += 256) wl[i] = p.w[i];
+    for (int i = threadIdx.x; i < (K * K) * p.C / 4; i += 256) reinterpret_cast<f32x4 *>(wl)[i] = reinterpret_cast<const f32x4 *>(p.w)[i];   // C % 8 == 0
     for (int i = threadIdx.x; i < p.C; i += 256) wl[K * K * p.C + i] = p.bias[i];
     __syncthreads();
     const int n = blockIdx.y, blk = blockIdx.x;
