@@ -190,6 +190,17 @@ def conv2d(x, pc, res=None, res_mode=RES_NONE, out=None, out_up=1, out_coff=0, s
     scale = 2 if pc.convt else out_up
     if out is None:
         out = torch.empty((N, Ho * scale, Wo * scale, pc.c_tensor), dtype=torch.float32, device=x.device)
+    # The fast kernels address their tensors with 32-bit byte offsets.  A batch whose input, output (the 256-channel concat buffer of a
+    # 64-image batch is 3 GB) or residual reaches 2 GiB is run as two half batches into the same output -- images are independent and
+    # every kernel is batch-invariant, so the result is the same; without this the layer fell back to the first-generation kernel
+    # (7.7 ms per layer in the 64-image run_ocr workload).
+    lim = 2 ** 31
+    if N > 1 and (x.numel() * 4 >= lim or out.numel() * 4 >= lim or (res is not None and res.numel() * 4 >= lim)):
+        h = N // 2
+        for a, b in ((0, h), (h, N)):
+            conv2d(x[a:b], pc, res=None if res is None else res[a:b], res_mode=res_mode, out=out[a:b], out_up=out_up, out_coff=out_coff,
+                   store=store)
+        return out
     if USE_STEM_KERNEL and getattr(pc, "stem_w", None) is not None and res is None and out_up == 1 and out_coff == 0 \
             and out.shape[3] == 64 and (store is None or store == 64) and N * H * W * 16 < 2 ** 31:
         if PROFILE is not None:

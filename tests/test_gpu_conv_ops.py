@@ -429,3 +429,28 @@ def test_winograd_narrow_layer_padded_cout():
     fuse = fuse.cpu()
     assert (fuse[..., 48:72].permute(0, 3, 1, 2) - F.interpolate(ref, scale_factor=2, mode="nearest")).abs().max().item() <= tol
     assert float((fuse[..., :48] - 3).abs().max()) == 0 and float((fuse[..., 72:] - 3).abs().max()) == 0
+
+
+def test_conv_on_tensors_beyond_2gib_runs_as_half_batches():
+    """a 3x3 conv whose 256-channel input exceeds 2 GiB (the concat buffer of a 64-image batch in run_ocr): split into half batches,
+    the fast kernel runs (not the first-generation fallback) and every image equals its single-image result"""
+    from pytorchocr_amd.modeling import ops
+    dev = _dev()
+    conv = nn.Conv2d(256, 64, 3, 1, 1, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(_rand(64, 256, 3, 3, seed=1) * 0.02)
+    pc = ops.PackedConv(conv, None, dev, relu=True)
+    N, H, W = 5, 736, 640                                       # 5 x 736 x 640 x 256 x 4 B = 2.4 GB
+    x = torch.empty((N, H, W, 256), dtype=torch.float32, device=dev)
+    for i in range(N):
+        x[i] = torch.from_numpy(np.ascontiguousarray(_nhwc(_rand(1, 256, 64, W, seed=20 + i))[0])).to(dev).repeat(H // 64 + 1, 1, 1)[:H]
+    assert x.numel() * 4 >= 2 ** 31
+    ops.PROFILE, ops.PROFILE_LABELS = [], []
+    try:
+        y = ops.conv2d(x, pc)
+        labels = list(ops.PROFILE_LABELS)
+    finally:
+        ops.PROFILE = ops.PROFILE_LABELS = None
+    assert len(labels) >= 2 and all(l.startswith("wino") for l in labels), labels
+    for i in (0, 2, 4):
+        assert torch.equal(y[i:i + 1], ops.conv2d(x[i:i + 1].contiguous(), pc))
