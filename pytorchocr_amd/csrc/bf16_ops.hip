@@ -23,6 +23,8 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float actf(float v, int act) {
     if (act == 1) return fmaxf(v, 0.f);
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(C3Args p) {
 // the MFMAs of tap t -- with a run-time inner loop every MFMA pair waited for its own 16-byte weight load from global memory (54
 // dependent L1 round trips per tile, several times the MFMA time).
 #ifndef C3_DBG
-#define C3_DBG 0             // timing experiments only: 1 no patch loads, 2 no MFMA loop, 4 no stores
+#define C3_DBG 0             // timing experiments only: 1 no patch loads, 2 no MFMA loop (one tap), 4 no stores, 8 no weight prefetch
 #endif
 constexpr int C3_TH = 8, C3_TW = 32, C3_MAXCIN = 96;
 template <int NCS>
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_lds_kernel(C3Args p) {
 // before: patch loads 170 us + MFMA loop 185 us (LDS-feed bound) + stores 105 us, added up (one block does them one after the other
 // and only two fit a CU): 345 us.
 template <int NCS>
-__global__ __launch_bounds__(256) void conv3x3_bf16_pers_kernel(C3Args p, int tiles_x, int tiles_per_img, int total) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_bf16_pers_kernel(C3Args p, int tiles_x, int tiles_per_img, int total) {
     constexpr int NCH = 2 * NCS, STRIDE = 16 * NCH + 16;
     constexpr int NPIECE = (C3_TH + 2) * (C3_TW + 2) * NCH;
     constexpr int NLD = (NPIECE + 255) / 256;
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_pers_kernel(C3Args p, int ti
             const int pix = i / NCH, ch = i - pix * NCH;
             const int iy = ty0 - 1 + pix / (C3_TW + 2), ix = tx0 - 1 + pix % (C3_TW + 2);
             pv[k] = zero8();
-            if (i < NPIECE && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+            if (!(C3_DBG & 1) && i < NPIECE && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
                 pv[k] = *reinterpret_cast<const bf16x8 *>(ximg + ((long)iy * p.W + ix) * p.Cin + ch * 8);
         }
     };
@@ -332,41 +334,51 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_pers_kernel(C3Args p, int ti
             if (i < NPIECE) *reinterpret_cast<bf16x8 *>(patch + pix * STRIDE + ch * 16) = pv[k];
         }
     };
+    // All 9 x NCS weight fragments of this lane stay in registers for the life of the workgroup (216 VGPRs at Cin = 96: one workgroup per
+    // CU, one wave per SIMD, the 512-entry unified register file).  The first persistent version fetched them per tap from global
+    // memory inside the MFMA loop: memory returns in order, so every such fetch waited behind the 16 loads of the NEXT patch issued
+    // just before the loop -- the prefetch never overlapped anything (measured: 320 us, 155 us without the in-loop fetches).
     const __bf16 *wrow = p.w + (long)r * 9 * p.Cin + 8 * h;
+    bf16x8 aw[9][NCS];
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+        for (int cs = 0; cs < NCS; cs++) aw[tap][cs] = *reinterpret_cast<const bf16x8 *>(wrow + tap * p.Cin + cs * 16);
     const int U = p.out_up, CS = p.cstore, PCS = CS >> 3;            // 16-byte pieces per output pixel
 
-    int tile = blockIdx.x;
+    // XCD-aware tile order: workgroup ids go round the 8 XCDs, so XCD j takes the contiguous eighth [j total / 8, (j + 1) total / 8) of
+    // the tiles and its workgroups walk it side by side -- the halo rows and columns neighbouring tiles share are then hits in
+    // that XCD's L2 instead of a second fetch by another one.
+    int tile, tstep, tend;
+    if ((gridDim.x & 7) == 0) {
+        const int j = blockIdx.x & 7;
+        tile = (int)((long)j * total / 8) + (int)(blockIdx.x >> 3);
+        tstep = (int)(gridDim.x >> 3);
+        tend = (int)((long)(j + 1) * total / 8);
+    } else { tile = blockIdx.x; tstep = gridDim.x; tend = total; }
+    if (tile >= tend) return;
     decode(tile);
     gload();
     lstore();
     __syncthreads();
     for (;;) {
         const int c_n = n, c_ty0 = ty0, c_tx0 = tx0;
-        const int next = tile + (int)gridDim.x;
-        const bool has_next = next < total;
+        const int next = tile + tstep;
+        const bool has_next = next < tend;
         if (has_next) { decode(next); gload(); }                 // in flight during this tile's MFMAs
 
         f32x16 acc[2];
         acc[0] = (f32x16)(0.f); acc[1] = (f32x16)(0.f);
-        bf16x8 a_cur[NCS], a_nxt[NCS];
 #pragma unroll
-        for (int cs = 0; cs < NCS; cs++) a_cur[cs] = *reinterpret_cast<const bf16x8 *>(wrow + cs * 16);
-#pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
+        for (int tap = 0; tap < ((C3_DBG & 2) ? 1 : 9); tap++) {
             const int dy = tap / 3, dx = tap % 3;
             const unsigned char *b0 = patch + ((2 * wave + dy) * (C3_TW + 2) + r + dx) * STRIDE + 16 * h;
             const unsigned char *b1 = b0 + (C3_TW + 2) * STRIDE;
-            if (tap < 8) {
-#pragma unroll
-                for (int cs = 0; cs < NCS; cs++) a_nxt[cs] = *reinterpret_cast<const bf16x8 *>(wrow + (tap + 1) * p.Cin + cs * 16);
-            }
 #pragma unroll
             for (int cs = 0; cs < NCS; cs++) {
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[cs], *reinterpret_cast<const bf16x8 *>(b0 + cs * 32), acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[cs], *reinterpret_cast<const bf16x8 *>(b1 + cs * 32), acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[tap][cs], *reinterpret_cast<const bf16x8 *>(b0 + cs * 32), acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[tap][cs], *reinterpret_cast<const bf16x8 *>(b1 + cs * 32), acc[1], 0, 0, 0);
             }
-#pragma unroll
-            for (int cs = 0; cs < NCS; cs++) a_cur[cs] = a_nxt[cs];
         }
         __syncthreads();                                         // the patch is consumed: its LDS now stages the outputs
         __bf16 *ob = reinterpret_cast<__bf16 *>(patch);          // [8 rows][32 cols][CS]
@@ -388,6 +400,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_pers_kernel(C3Args p, int ti
             const int oy = c_ty0 + px / C3_TW, ox = c_tx0 + px % C3_TW;
             if (oy >= p.H || ox >= p.W) continue;
             const bf16x8 v = *reinterpret_cast<const bf16x8 *>(ob + px * CS + part * 8);
+            if ((C3_DBG & 4) && v[0] != (__bf16)123.f) continue;
             __bf16 *dst = p.y + (((long)c_n * p.H * U + oy * U) * ((long)p.W * U) + ox * U) * p.out_ldc + p.out_coff + part * 8;
             for (int uy = 0; uy < U; uy++)
                 for (int ux = 0; ux < U; ux++) *reinterpret_cast<bf16x8 *>(dst + ((long)uy * p.W * U + ux) * p.out_ldc) = v;
@@ -422,64 +435,100 @@ struct DwArgs {
     __bf16 *y;
     float *partial;                 // f32[N][nblk][C] or null
     int H, W, C, k, stride, Ho, Wo, act, nblk, chunk;
+    int ob;                         // channel octets per block
+    int xcd;                        // 1: XCD-aware workgroup order
 };
 
 // K, S compile-time (taps unrolled); a thread walks RUNS of 4 consecutive outputs of one row: the (3 S + K) input columns of a run are
 // loaded once per kernel row and feed all four outputs (5x5 / s1: 40 loads per 4 outputs instead of 100), the weights and the bias
 // sit in LDS (the first version re-read them from global memory per tap: 75 loads per output pixel made the layer issue-bound at
 // 7x its HBM time).  A block owns whole output rows (p.chunk of them).
+#ifndef DW_DBG
+#define DW_DBG 0            // timing experiments only: 1 no weight staging, 2 no global loads, 4 no stores
+#endif
 template <int K, int S>
 __global__ __launch_bounds__(256) void dwconv_bf16_kernel(DwArgs p) {
     constexpr int R = 4, NC = (R - 1) * S + K, PAD = (K - 1) / 2;
     extern __shared__ __attribute__((aligned(16))) float dw_lds[];
-    float *wl = dw_lds;                                         // [K*K][C] tap-major, then [C] bias
-    float (*red)[8] = reinterpret_cast<float (*)[8]>(dw_lds + (K * K + 1) * p.C);
-    for (int i = threadIdx.x; i < (K * K) * p.C / 4; i += 256) reinterpret_cast<f32x4 *>(wl)[i] = reinterpret_cast<const f32x4 *>(p.w)[i];   // C % 8 == 0
-    for (int i = threadIdx.x; i < p.C; i += 256) wl[K * K * p.C + i] = p.bias[i];
-    __syncthreads();
-    const int n = blockIdx.y, blk = blockIdx.x;
+    // A block owns p.ob channel octets (blockIdx.z picks the group): its slice of the weights is a few KB of LDS instead of (K*K+1)*C
+    // floats, so that occupancy is set by registers -- the loads of a run are K dependent round trips and need many waves to hide.
+    const int OB = p.ob, CB = OB * 8;
     const int C8 = p.C >> 3;
-    const int L = 256 / C8;
-    const int q = threadIdx.x % C8, pl = threadIdx.x / C8;
+    float *wl = dw_lds;                                         // [K*K][CB] tap-major, then [CB] bias
+    // XCD-aware order: consecutive workgroup ids go round the 8 XCDs, and the row chunks of one image share halo rows -- with the plain
+    // (x, y, z) order every XCD's L2 fetched every image.  Virtual id v = (id % 8) * (B / 8) + id / 8 puts whole images on one XCD.
+    int n = blockIdx.y, blk = blockIdx.x, zg = blockIdx.z;
+    if (p.xcd) {
+        const int B = gridDim.x * gridDim.y * gridDim.z, per = B >> 3;
+        const int id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int v = id < per * 8 ? (id & 7) * per + (id >> 3) : id;      // the B % 8 tail maps to itself
+        blk = v % gridDim.x;
+        const int t = v / gridDim.x;
+        zg = t % gridDim.z;
+        n = t / gridDim.z;
+    }
+    const int cg0 = zg * OB;
+    float (*red)[8] = reinterpret_cast<float (*)[8]>(dw_lds + (K * K + 1) * CB);
+#if !(DW_DBG & 1)
+    for (int i = threadIdx.x; i < (K * K + 1) * OB * 2; i += 256) {
+        const int tap = i / (OB * 2), piece = i - tap * (OB * 2);
+        if (cg0 * 2 + piece < C8 * 2)
+            reinterpret_cast<f32x4 *>(wl)[i] = tap < K * K ? reinterpret_cast<const f32x4 *>(p.w)[tap * (C8 * 2) + cg0 * 2 + piece]
+                                                           : reinterpret_cast<const f32x4 *>(p.bias)[cg0 * 2 + piece];
+    }
+#endif
+    __syncthreads();
+    const int L = 256 / OB;
+    const int ql = threadIdx.x % OB, pl = threadIdx.x / OB;
+    const int q = cg0 + ql;                                     // global channel octet
     const int runs_x = (p.Wo + R - 1) / R;
     const int r0 = blk * p.chunk, r1 = min(r0 + p.chunk, p.Ho);
     const int nruns = (r1 - r0) * runs_x;
     float sum[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) sum[j] = 0.f;
-    if (pl < L) {
-        const float *bl = wl + K * K * p.C + q * 8;
+    if (pl < L && q < C8) {
+        const float *bl = wl + K * K * CB + ql * 8;
         for (int run = pl; run < nruns; run += L) {
             const int ry = run / runs_x;
             const int oy = r0 + ry, ox0 = (run - ry * runs_x) * R;
-            float acc[R][8];
+            // The layer is VALU-bound, not memory-bound (5x5: 25 taps x 8 channels per output and thread): the multiply-adds run as
+            // packed fp32 FMAs on channel pairs (v_pk_fma_f32, half the instructions of scalar FMAs, a quarter of the mul + add pairs
+            // the file-wide -ffp-contract=off would give); a bf16 pair becomes two floats with one shift and one mask.
+            f32x2 acc[R][4];
 #pragma unroll
             for (int r = 0; r < R; r++)
 #pragma unroll
-                for (int j = 0; j < 8; j++) acc[r][j] = bl[j];
+                for (int j = 0; j < 4; j++) acc[r][j] = f32x2{bl[2 * j], bl[2 * j + 1]};
 #pragma unroll
             for (int a = 0; a < K; a++) {
                 const int iy = oy * S - PAD + a;
                 if ((unsigned)iy >= (unsigned)p.H) continue;
-                float wr[K][8];
+                f32x2 wr[K][4];
 #pragma unroll
                 for (int b = 0; b < K; b++) {
-                    const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wl + (a * K + b) * p.C + q * 8), w1 = *reinterpret_cast<const f32x4 *>(wl + (a * K + b) * p.C + q * 8 + 4);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) { wr[b][j] = w0[j]; wr[b][4 + j] = w1[j]; }
+                    const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wl + (a * K + b) * CB + ql * 8), w1 = *reinterpret_cast<const f32x4 *>(wl + (a * K + b) * CB + ql * 8 + 4);
+                    wr[b][0] = f32x2{w0[0], w0[1]}; wr[b][1] = f32x2{w0[2], w0[3]}; wr[b][2] = f32x2{w1[0], w1[1]}; wr[b][3] = f32x2{w1[2], w1[3]};
                 }
                 const __bf16 *row = p.x + (((long)n * p.H + iy) * p.W) * p.C + q * 8;
 #pragma unroll
                 for (int ci = 0; ci < NC; ci++) {
                     const int ix = ox0 * S - PAD + ci;
                     if ((unsigned)ix >= (unsigned)p.W) continue;
-                    const bf16x8 v = *reinterpret_cast<const bf16x8 *>(row + (long)ix * p.C);
+#if DW_DBG & 2
+                    const u32x4 d = {(unsigned)ix, (unsigned)iy, 0u, 0u};
+#else
+                    const u32x4 d = *reinterpret_cast<const u32x4 *>(row + (long)ix * p.C);
+#endif
+                    f32x2 v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v[j] = f32x2{__builtin_bit_cast(float, d[j] << 16), __builtin_bit_cast(float, d[j] & 0xffff0000u)};
 #pragma unroll
                     for (int r = 0; r < R; r++) {
                         const int b = ci - r * S;                 // compile-time: the tap this column is for output r of the run
                         if (b >= 0 && b < K) {
 #pragma unroll
-                            for (int j = 0; j < 8; j++) acc[r][j] += (float)v[j] * wr[b][j];
+                            for (int j = 0; j < 4; j++) acc[r][j] = __builtin_elementwise_fma(v[j], wr[b][j], acc[r][j]);
                         }
                     }
                 }
@@ -489,8 +538,8 @@ __global__ __launch_bounds__(256) void dwconv_bf16_kernel(DwArgs p) {
                 if (ox0 + r >= p.Wo) continue;
                 bf16x8 o;
 #pragma unroll
-                for (int j = 0; j < 8; j++) { const float t = actf(acc[r][j], p.act); sum[j] += t; o[j] = (__bf16)t; }
-                *reinterpret_cast<bf16x8 *>(p.y + (((long)n * p.Ho + oy) * p.Wo + ox0 + r) * p.C + q * 8) = o;
+                for (int j = 0; j < 8; j++) { const float t = actf(acc[r][j >> 1][j & 1], p.act); sum[j] += t; o[j] = (__bf16)t; }
+                if (!(DW_DBG & 4) || o[0] == (__bf16)123.f) *reinterpret_cast<bf16x8 *>(p.y + (((long)n * p.Ho + oy) * p.Wo + ox0 + r) * p.C + q * 8) = o;
             }
         }
     }
@@ -498,10 +547,10 @@ __global__ __launch_bounds__(256) void dwconv_bf16_kernel(DwArgs p) {
 #pragma unroll
     for (int j = 0; j < 8; j++) red[threadIdx.x][j] = sum[j];
     __syncthreads();
-    if (pl == 0) {
+    if (pl == 0 && q < C8) {
         for (int l = 1; l < L; l++)
 #pragma unroll
-            for (int j = 0; j < 8; j++) sum[j] += red[l * C8 + q][j];
+            for (int j = 0; j < 8; j++) sum[j] += red[l * OB + ql][j];
         float *dst = p.partial + ((long)n * p.nblk + blk) * p.C + q * 8;
 #pragma unroll
         for (int j = 0; j < 8; j++) dst[j] = sum[j];
@@ -510,14 +559,24 @@ __global__ __launch_bounds__(256) void dwconv_bf16_kernel(DwArgs p) {
 
 template <int K, int S>
 static int launch_dw(const DwArgs &p, int N, hipStream_t stream) {
-    const size_t lds = sizeof(float) * ((size_t)(K * K + 1) * p.C + 256 * 8);
+    const size_t lds = sizeof(float) * ((size_t)(K * K + 1) * p.ob * 8 + 256 * 8);
     static size_t lds_set = 0;
     if (lds > lds_set) {
         PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dwconv_bf16_kernel<K, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set = lds;
     }
-    hipLaunchKernelGGL((dwconv_bf16_kernel<K, S>), dim3(p.nblk, N), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((dwconv_bf16_kernel<K, S>), dim3(p.nblk, N, cdiv(p.C / 8, p.ob)), dim3(256), lds, stream, p);
     return launch_ok("dwconv_bf16_kernel");
+}
+
+// channel octets per block: all of them up to 16, else the largest divisor in [6, 16] (no idle lanes), else 16 with a ragged last group.
+// A function of C only (the SE pool's summation order follows the lane layout).
+static inline int dw_octets(int C8) {
+    static const int mx = getenv("PTOCR_DW_OB") ? atoi(getenv("PTOCR_DW_OB")) : 36;    // measured: 16 / 36 / 72 -> 3667 / 3611 / 3666 us per forward
+    if (C8 <= mx) return C8;
+    for (int d = mx; d >= 6; d--)
+        if (C8 % d == 0) return d;
+    return mx;
 }
 
 // output rows per block: the pixel budget of dw_chunk in whole rows
@@ -531,7 +590,7 @@ static inline int dw_rows(int N, int Ho, int Wo) {
 // channels per pixel on the VALU, weights (f32[27][16], row (c*3 + ky)*3 + kx) and bias broadcast from LDS.
 __global__ __launch_bounds__(256) void stem3x3s2_bf16_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                                                              __bf16 *__restrict__ y, int H, int W, int Ho, int Wo, int act, long total) {
-    __shared__ float sw[27 * 16 + 16];
+    __shared__ __attribute__((aligned(16))) float sw[27 * 16 + 16];
     for (int i = threadIdx.x; i < 27 * 16 + 16; i += 256) sw[i] = i < 27 * 16 ? w[i] : bias[i - 27 * 16];
     __syncthreads();
     const long i = blockIdx.x * 256L + threadIdx.x;
@@ -540,9 +599,9 @@ __global__ __launch_bounds__(256) void stem3x3s2_bf16_kernel(const float *__rest
     const long t = i / Wo;
     const int oy = (int)(t % Ho);
     const long n = t / Ho;
-    float acc[16];
+    f32x2 acc[8];                                                // packed fp32 FMAs on channel pairs: the 432 multiply-adds per pixel bound this kernel
 #pragma unroll
-    for (int j = 0; j < 16; j++) acc[j] = sw[27 * 16 + j];
+    for (int j = 0; j < 8; j++) acc[j] = *reinterpret_cast<const f32x2 *>(sw + 27 * 16 + 2 * j);
     for (int c = 0; c < 3; c++)
         for (int ky = 0; ky < 3; ky++) {
             const int iy = 2 * oy - 1 + ky;
@@ -551,14 +610,15 @@ __global__ __launch_bounds__(256) void stem3x3s2_bf16_kernel(const float *__rest
                 const int ix = 2 * ox - 1 + kx;
                 if ((unsigned)ix >= (unsigned)W) continue;
                 const float v = x[((n * 3 + c) * H + iy) * (long)W + ix];
-                const float *wr = sw + ((c * 3 + ky) * 3 + kx) * 16;
+                const f32x2 vv = {v, v};
+                const f32x2 *wr = reinterpret_cast<const f32x2 *>(sw + ((c * 3 + ky) * 3 + kx) * 16);
 #pragma unroll
-                for (int j = 0; j < 16; j++) acc[j] += v * wr[j];
+                for (int j = 0; j < 8; j++) acc[j] = __builtin_elementwise_fma(vv, wr[j], acc[j]);
             }
         }
     bf16x8 o0, o1;
 #pragma unroll
-    for (int j = 0; j < 8; j++) { o0[j] = (__bf16)actf(acc[j], act); o1[j] = (__bf16)actf(acc[8 + j], act); }
+    for (int j = 0; j < 8; j++) { o0[j] = (__bf16)actf(acc[j >> 1][j & 1], act); o1[j] = (__bf16)actf(acc[4 + (j >> 1)][j & 1], act); }
     *reinterpret_cast<bf16x8 *>(y + i * 16) = o0;
     *reinterpret_cast<bf16x8 *>(y + i * 16 + 8) = o1;
 }
@@ -737,7 +797,7 @@ extern "C" int ptocr_conv3x3_bf16(const void *d_x, const void *d_w, const float 
         const int tiles_x = cdiv(W, C3_TW), tpi = tiles_x * cdiv(H, C3_TH);
         const long total = (long)N * tpi;
         PT_CHECK(total < (1L << 31), "ptocr_conv3x3_bf16: too many tiles");
-        const int grid = total < 2L * n_cu ? (int)total : 2 * n_cu;          // two persistent workgroups per CU (71 KB of LDS each)
+        const int grid = total < (long)n_cu ? (int)total : n_cu;             // one persistent workgroup per CU (weights in its registers)
         hipLaunchKernelGGL(conv3x3_bf16_pers_kernel<6>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, tiles_x, tpi, (int)total);
         return launch_ok("conv3x3_bf16_pers_kernel");
     }
@@ -760,7 +820,9 @@ extern "C" int ptocr_dwconv_bf16(const void *d_x, const float *d_w, const float 
     p.stride = stride; p.Ho = (H + 2 * pad - k) / stride + 1; p.Wo = (W + 2 * pad - k) / stride + 1; p.act = act;
     p.chunk = dw_rows(N, p.Ho, p.Wo);
     p.nblk = cdiv(p.Ho, p.chunk);
-    PT_CHECK((size_t)(k * k + 1) * C * 4 + 8192 <= 160 * 1024, "ptocr_dwconv_bf16: weights do not fit LDS (C = %d)", C);
+    p.ob = dw_octets(C / 8);
+    static const int xcd = getenv("PTOCR_DW_XCD") ? atoi(getenv("PTOCR_DW_XCD")) : 1;
+    p.xcd = xcd;
     if (k == 3) return stride == 1 ? launch_dw<3, 1>(p, N, (hipStream_t)stream) : launch_dw<3, 2>(p, N, (hipStream_t)stream);
     return stride == 1 ? launch_dw<5, 1>(p, N, (hipStream_t)stream) : launch_dw<5, 2>(p, N, (hipStream_t)stream);
 }
