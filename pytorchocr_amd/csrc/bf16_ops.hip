@@ -15,6 +15,7 @@
 // half = lane >> 5) then holds, per register quad g, four CONSECUTIVE output channels 8g + 4*half + {0..3} of its pixel: one packed
 // 8-byte bf16 store per quad, no shuffle, no LDS.
 #include "common.h"
+#include <type_traits>
 #include <cstdlib>
 
 namespace ptocr {
@@ -32,6 +33,16 @@ __device__ __forceinline__ float actf(float v, int act) {
     return v;
 }
 
+// The activation code is a compile-time parameter of the hot kernels: with a run-time code the compiler turned every actf() into a
+// tree of scalar branches (the code is wave-uniform) -- 144 branches in one 3x3 epilogue, ~100 per depthwise run.
+template <int ACT>
+__device__ __forceinline__ float actc(float v) {
+    if (ACT == 1) return fmaxf(v, 0.f);
+    if (ACT == 2) return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);       // Hardswish
+    return v;
+}
+#define PT_ACT_SWITCH(act, F) do { if ((act) == 0) { F(0); } else if ((act) == 1) { F(1); } else { F(2); } } while (0)
+
 __device__ __forceinline__ bf16x8 zero8() { bf16x8 z; for (int j = 0; j < 8; j++) z[j] = (__bf16)0.f; return z; }
 
 // ---------------------------------------------------------------------------------------------- 1x1 convolution
@@ -48,7 +59,7 @@ struct PwArgs {
     int out_ldc, out_coff, res_ldc;
 };
 
-template <int NT>
+template <int NT, bool RES, int ACT>
 __global__ __launch_bounds__(256) void pw_bf16_kernel(PwArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -82,40 +93,38 @@ __global__ __launch_bounds__(256) void pw_bf16_kernel(PwArgs p) {
     }
     // Epilogue through LDS: a lane's accumulator quads are 8-byte pieces of its pixel's row, 160 bytes apart from the next lane's --
     // stored directly they reach HBM as partial sectors (measured 2.4x write amplification).  Each wave parks its 32 pixels x
-    // NT*32 channels as bf16 in its own LDS tile and writes it back row-major, 16 bytes per lane, consecutive lanes on consecutive
-    // chunks of a pixel row.  Bias, residual, activation and the FPN top-down add are applied in fp32 on the way in.
-    constexpr int TW = NT * 32 + 8;                             // tile row stride in bf16 (16-byte padded: conflict-free 16-B reads)
-    __shared__ __attribute__((aligned(16))) __bf16 tile[4][32][TW];
+    // NT*32 channels in its own LDS tile and writes it back row-major, 16 bytes per lane, consecutive lanes on consecutive
+    // chunks of a pixel row.  Everything is added in fp32 BEFORE the one rounding to bf16.
+    // RES = false: bias + activation on the way in, the tile holds bf16.
+    // RES = true (block residual / FPN top-down add): the tile holds fp32 (conv + bias) and the residual is read in the write-back
+    // phase, where it is one coalesced 16-byte load per lane -- read on the way in it was twelve 8-byte loads per lane, 192 bytes
+    // apart from the neighbouring lane's.
+    constexpr int TW = RES ? NT * 32 + 4 : NT * 32 + 8;         // tile row stride in elements (16-byte padded: conflict-free 16-B accesses)
+    typedef typename std::conditional<RES, float, __bf16>::type tile_t;
+    __shared__ __attribute__((aligned(16))) tile_t tile[4][32][TW];
 #pragma unroll
     for (int t = 0; t < NT; t++)
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            const int c = (t0 + t) * 32 + 8 * g + 4 * h;             // everything is added in fp32 BEFORE the one rounding to bf16
+            const int c = (t0 + t) * 32 + 8 * g + 4 * h;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (t0 + t < p.ntile && c < p.cstore) {
                 const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + c);
 #pragma unroll
                 for (int j = 0; j < 4; j++) v[j] = acc[t][4 * g + j] + bias[j];
-                if (p.res_mode == 1 && m < p.M) {
-                    const bf16x4 rr = *reinterpret_cast<const bf16x4 *>(p.res + m * p.res_ldc + c);
+                if (!RES) {
 #pragma unroll
-                    for (int j = 0; j < 4; j++) v[j] += (float)rr[j];
-                }
-#pragma unroll
-                for (int j = 0; j < 4; j++) v[j] = actf(v[j], p.act);
-                if (p.res_mode == 2 && m < p.M) {
-                    const int n = (int)(m / HW);
-                    const int rem = (int)(m - (long)n * HW);
-                    const int oy = rem / p.W, ox = rem - oy * p.W;
-                    const bf16x4 rr = *reinterpret_cast<const bf16x4 *>(p.res + (((long)n * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) * p.res_ldc + c);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) v[j] += (float)rr[j];
+                    for (int j = 0; j < 4; j++) v[j] = actc<ACT>(v[j]);
                 }
             }
-            bf16x4 o;
+            if constexpr (RES) {
+                *reinterpret_cast<f32x4 *>(&tile[wave][r][t * 32 + 8 * g + 4 * h]) = v;
+            } else {
+                bf16x4 o;
 #pragma unroll
-            for (int j = 0; j < 4; j++) o[j] = (__bf16)v[j];
-            *reinterpret_cast<bf16x4 *>(&tile[wave][r][t * 32 + 8 * g + 4 * h]) = o;
+                for (int j = 0; j < 4; j++) o[j] = (__bf16)v[j];
+                *reinterpret_cast<bf16x4 *>(&tile[wave][r][t * 32 + 8 * g + 4 * h]) = o;
+            }
         }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -131,9 +140,34 @@ __global__ __launch_bounds__(256) void pw_bf16_kernel(PwArgs p) {
         const long mm = mw0 + pr;
         if (mm >= p.M) continue;
         const int c = cbase + ch * 8;
+        const bool full = c + 8 <= cend;
         __bf16 *dst = p.y + mm * p.out_ldc + p.out_coff + c;
-        if (c + 8 <= cend) *reinterpret_cast<bf16x8 *>(dst) = *reinterpret_cast<const bf16x8 *>(&tile[wave][pr][ch * 8]);
-        else *reinterpret_cast<bf16x4 *>(dst) = *reinterpret_cast<const bf16x4 *>(&tile[wave][pr][ch * 8]);
+        if constexpr (RES) {
+            const __bf16 *rsrc;
+            if (p.res_mode == 1) rsrc = p.res + mm * p.res_ldc + c;
+            else {
+                const int n = (int)(mm / HW);
+                const int rem = (int)(mm - (long)n * HW);
+                const int oy = rem / p.W, ox = rem - oy * p.W;
+                rsrc = p.res + (((long)n * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) * p.res_ldc + c;
+            }
+            bf16x4 r0 = *reinterpret_cast<const bf16x4 *>(rsrc), r1 = r0;
+            if (full) r1 = *reinterpret_cast<const bf16x4 *>(rsrc + 4);
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(&tile[wave][pr][ch * 8]), v1 = *reinterpret_cast<const f32x4 *>(&tile[wave][pr][ch * 8 + 4]);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float a0 = v0[j], a1 = v1[j];
+                if (p.res_mode == 1) { a0 = actc<ACT>(a0 + (float)r0[j]); a1 = actc<ACT>(a1 + (float)r1[j]); }
+                else { a0 = actc<ACT>(a0) + (float)r0[j]; a1 = actc<ACT>(a1) + (float)r1[j]; }
+                o[j] = (__bf16)a0; o[4 + j] = (__bf16)a1;
+            }
+            if (full) *reinterpret_cast<bf16x8 *>(dst) = o;
+            else { bf16x4 oh = {o[0], o[1], o[2], o[3]}; *reinterpret_cast<bf16x4 *>(dst) = oh; }
+        } else {
+            if (full) *reinterpret_cast<bf16x8 *>(dst) = *reinterpret_cast<const bf16x8 *>(&tile[wave][pr][ch * 8]);
+            else *reinterpret_cast<bf16x4 *>(dst) = *reinterpret_cast<const bf16x4 *>(&tile[wave][pr][ch * 8]);
+        }
     }
 }
 
@@ -200,6 +234,13 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(C3Args p) {
 #define C3_DBG 0             // timing experiments only: 1 no patch loads, 2 no MFMA loop (one tap), 4 no stores, 8 no weight prefetch
 #endif
 constexpr int C3_TH = 8, C3_TW = 32, C3_MAXCIN = 96;
+#if C3_DBG & 16
+__device__ unsigned long long c3_dbg_t[16 * 10];
+#define C3_PROBE(i) do { if (blockIdx.x == 8 && threadIdx.x == 0 && c3_it >= 2 && c3_it < 18) c3_dbg_t[(c3_it - 2) * 10 + (i)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int ptocr_c3_dbg_read(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(c3_dbg_t), sizeof(c3_dbg_t)); }
+#else
+#define C3_PROBE(i)
+#endif
 template <int NCS>
 __global__ __launch_bounds__(256) void conv3x3_bf16_lds_kernel(C3Args p) {
     __shared__ __attribute__((aligned(16))) unsigned char patch[(C3_TH + 2) * (C3_TW + 2) * (2 * C3_MAXCIN + 16)];
@@ -294,62 +335,90 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_lds_kernel(C3Args p) {
     }
 }
 
-// Persistent form for Cin = 16 NCS: a workgroup walks tiles (image-major), the patch of tile t+1 travels global -> registers while
+// Persistent form for Cin = 16 NCS: a workgroup walks tiles (XCD-aware order), the patch of tile t+1 travels global -> registers while
 // tile t computes, and the outputs leave through LDS as 16-byte pieces (a pixel's cstore channels are contiguous: 48 bytes for 24
-// channels = three pieces instead of six 8-byte stores into a 192-byte-stride concat buffer).  Measured on the 32 x 184 x 320 layer
-// before: patch loads 170 us + MFMA loop 185 us (LDS-feed bound) + stores 105 us, added up (one block does them one after the other
-// and only two fit a CU): 345 us.
-template <int NCS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_bf16_pers_kernel(C3Args p, int tiles_x, int tiles_per_img, int total) {
+// channels = three pieces instead of six 8-byte stores into a 192-byte-stride concat buffer).  History of the 32 x 184 x 320 layer:
+// non-persistent 345 us (patch loads 170 + MFMA loop 185 + stores 105, added up); persistent with the weight fragments fetched per
+// tap from global memory 320 us -- memory returns in order, so every such fetch waited behind the 16 loads of the NEXT patch
+// issued just before the loop and the prefetch never overlapped anything (155 us without the in-loop fetches); all 54 fragments
+// resident in registers (216 VGPRs, one wave per SIMD) 200 us; taller tiles (12 / 16 rows) spill: 305 / 540 us.
+// Eight waves, two per SIMD, so that one wave's LDS reads and address arithmetic hide behind the other's MFMAs.  The 216 weight registers
+// do not fit twice in a SIMD's file, so the K dimension is split: waves 0-3 hold the weight fragments of channel slices [0, NCS/2),
+// waves 4-7 of [NCS/2, NCS) (108 registers each); both halves compute the same two output rows per wave, swap one row's partial
+// sums through LDS and finish one row each.  s_memtime probes (-DC3_DBG=16, tools/dbg/c3_probe.sh), cycles per tile: first
+// eight-wave version 14.2 k (prefetch address arithmetic 1.35 k, MFMA phase 4.8 k, partial-sum exchange with 64-way bank conflicts
+// + an epilogue of 144 scalar branches around run-time activation codes and a bias load queued behind the prefetch 5.8 k, stores
+// 1.15 k, patch to LDS 0.8 k); now 9.6 k (0.8 / 4.8 / 2.0 / 0.65 / 0.5), 155 us.
+template <int NCS, int ACT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_bf16_pers8_kernel(C3Args p, int tiles_x, int tiles_per_img, int total) {
+    constexpr int TH = 8, HC = NCS / 2;
     constexpr int NCH = 2 * NCS, STRIDE = 16 * NCH + 16;
-    constexpr int NPIECE = (C3_TH + 2) * (C3_TW + 2) * NCH;
-    constexpr int NLD = (NPIECE + 255) / 256;
-    __shared__ __attribute__((aligned(16))) unsigned char patch[(C3_TH + 2) * (C3_TW + 2) * STRIDE];
+    constexpr int NPIECE = (TH + 2) * (C3_TW + 2) * NCH;
+    constexpr int NLD = (NPIECE + 511) / 512;
+    __shared__ __attribute__((aligned(16))) unsigned char patch[(TH + 2) * (C3_TW + 2) * STRIDE];
+    static_assert(sizeof(patch) >= 4 * 64 * 32 * 4 + TH * C3_TW * 32 * 2, "patch buffer doubles as partial-sum + output staging");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
+    const int rw = wave & 3, half = wave >> 2;
     bf16x8 pv[NLD];
     int n, ty0, tx0;
     auto decode = [&](int t) {
         n = t / tiles_per_img;
         const int rem = t - n * tiles_per_img;
-        ty0 = (rem / tiles_x) * C3_TH; tx0 = (rem % tiles_x) * C3_TW;
+        ty0 = (rem / tiles_x) * TH; tx0 = (rem % tiles_x) * C3_TW;
     };
+    // Tile-invariant part of the patch addressing, once per thread: piece k of this thread is pixel (py, px) of the patch, channels
+    // 8 ch..  Per tile the loads go through a buffer descriptor of the IMAGE: rows above and below it fall outside the descriptor
+    // and return zeros by themselves, columns left and right of it are sent out of range by hand -- four VALU instructions per piece
+    // (64-bit addresses, two range checks and a branch around every load were 27, 1.7 k cycles per tile).
+    unsigned pbyte[NLD];
+    int ppx[NLD], lds_off[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+        const int i = threadIdx.x + 512 * k;
+        const int pix = i / NCH, ch = i - pix * NCH;
+        const int py = pix / (C3_TW + 2), px = pix - py * (C3_TW + 2);
+        pbyte[k] = (unsigned)(((py * p.W + px) * p.Cin + ch * 8) * 2);
+        ppx[k] = i < NPIECE ? px : (1 << 20);                    // beyond any width: never loaded, never stored
+        lds_off[k] = pix * STRIDE + ch * 16;
+    }
+    const int img_bytes = p.H * p.W * p.Cin * 2;                 // < 2^31 (host check)
     auto gload = [&]() {
-        const __bf16 *ximg = p.x + (long)n * p.H * p.W * p.Cin;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(p.x + (long)n * p.H * p.W * p.Cin), 0, img_bytes, 0x00020000);
+        const unsigned org = (unsigned)(((ty0 - 1) * p.W + (tx0 - 1)) * p.Cin * 2);      // negative for the first row / column: wraps out of range
 #pragma unroll
         for (int k = 0; k < NLD; k++) {
-            const int i = threadIdx.x + 256 * k;
-            const int pix = i / NCH, ch = i - pix * NCH;
-            const int iy = ty0 - 1 + pix / (C3_TW + 2), ix = tx0 - 1 + pix % (C3_TW + 2);
-            pv[k] = zero8();
-            if (!(C3_DBG & 1) && i < NPIECE && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                pv[k] = *reinterpret_cast<const bf16x8 *>(ximg + ((long)iy * p.W + ix) * p.Cin + ch * 8);
+            const unsigned vo = (unsigned)(tx0 - 1 + ppx[k]) < (unsigned)p.W ? org + pbyte[k] : 0xffffffffu;
+            pv[k] = (C3_DBG & 1) ? zero8() : __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xr, vo, 0, 0));
         }
     };
     auto lstore = [&]() {
 #pragma unroll
-        for (int k = 0; k < NLD; k++) {
-            const int i = threadIdx.x + 256 * k;
-            const int pix = i / NCH, ch = i - pix * NCH;
-            if (i < NPIECE) *reinterpret_cast<bf16x8 *>(patch + pix * STRIDE + ch * 16) = pv[k];
-        }
+        for (int k = 0; k < NLD; k++)
+            if (ppx[k] < (1 << 20)) *reinterpret_cast<bf16x8 *>(patch + lds_off[k]) = pv[k];
     };
-    // All 9 x NCS weight fragments of this lane stay in registers for the life of the workgroup (216 VGPRs at Cin = 96: one workgroup per
-    // CU, one wave per SIMD, the 512-entry unified register file).  The first persistent version fetched them per tap from global
-    // memory inside the MFMA loop: memory returns in order, so every such fetch waited behind the 16 loads of the NEXT patch issued
-    // just before the loop -- the prefetch never overlapped anything (measured: 320 us, 155 us without the in-loop fetches).
-    const __bf16 *wrow = p.w + (long)r * 9 * p.Cin + 8 * h;
-    bf16x8 aw[9][NCS];
+    const __bf16 *wrow = p.w + (long)r * 9 * p.Cin + 8 * h + half * HC * 16;
+    bf16x8 aw[9][HC];
 #pragma unroll
     for (int tap = 0; tap < 9; tap++)
 #pragma unroll
-        for (int cs = 0; cs < NCS; cs++) aw[tap][cs] = *reinterpret_cast<const bf16x8 *>(wrow + tap * p.Cin + cs * 16);
+        for (int cs = 0; cs < HC; cs++) aw[tap][cs] = *reinterpret_cast<const bf16x8 *>(wrow + tap * p.Cin + cs * 16);
     const int U = p.out_up, CS = p.cstore, PCS = CS >> 3;            // 16-byte pieces per output pixel
+    f32x4 biasr[4];                                                  // a global load inside the tile loop would queue behind the prefetch (in-order return)
+#pragma unroll
+    for (int g = 0; g < 4; g++) biasr[g] = 8 * g + 4 * h < CS ? *reinterpret_cast<const f32x4 *>(p.bias + 8 * g + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};       // cstore % 4 == 0
+    constexpr int NWB = 2;                                           // write-back items per thread: TH * C3_TW * PCS <= 2 * 512 (PCS <= 4)
+    int wb_src[NWB], wb_yx[NWB], wb_part[NWB];
+#pragma unroll
+    for (int w = 0; w < NWB; w++) {
+        const int i = threadIdx.x + 512 * w;
+        const int px = i / PCS, part_i = i - px * PCS;
+        wb_src[w] = i < TH * C3_TW * PCS ? px * 32 + part_i * 8 : -1;
+        wb_yx[w] = ((px / C3_TW) << 16) | (px % C3_TW);
+        wb_part[w] = part_i * 8;
+    }
 
-    // XCD-aware tile order: workgroup ids go round the 8 XCDs, so XCD j takes the contiguous eighth [j total / 8, (j + 1) total / 8) of
-    // the tiles and its workgroups walk it side by side -- the halo rows and columns neighbouring tiles share are then hits in
-    // that XCD's L2 instead of a second fetch by another one.
-    int tile, tstep, tend;
+    int tile, tstep, tend;                                           // XCD-aware tile order, as in the four-wave kernel
     if ((gridDim.x & 7) == 0) {
         const int j = blockIdx.x & 7;
         tile = (int)((long)j * total / 8) + (int)(blockIdx.x >> 3);
@@ -361,55 +430,77 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     gload();
     lstore();
     __syncthreads();
+    f32x4 *part = reinterpret_cast<f32x4 *>(patch);                                    // [8 waves][4 quads][64 lanes] partial sums handed to the other half: a lane's 16-byte pieces are 1 KB apart, a wave's contiguous
+    __bf16 *ob = reinterpret_cast<__bf16 *>(patch + 4 * 64 * 2 * sizeof(f32x16));     // [8 rows][32 cols][CS] output staging
+    int c3_it = 0;
     for (;;) {
+        C3_PROBE(0);
         const int c_n = n, c_ty0 = ty0, c_tx0 = tx0;
         const int next = tile + tstep;
         const bool has_next = next < tend;
-        if (has_next) { decode(next); gload(); }                 // in flight during this tile's MFMAs
+        if (has_next) { decode(next); gload(); }                 // in flight during this tile's MFMAs (no other global load until lstore)
 
+        C3_PROBE(1);
         f32x16 acc[2];
         acc[0] = (f32x16)(0.f); acc[1] = (f32x16)(0.f);
 #pragma unroll
         for (int tap = 0; tap < ((C3_DBG & 2) ? 1 : 9); tap++) {
             const int dy = tap / 3, dx = tap % 3;
-            const unsigned char *b0 = patch + ((2 * wave + dy) * (C3_TW + 2) + r + dx) * STRIDE + 16 * h;
+            const unsigned char *b0 = patch + ((2 * rw + dy) * (C3_TW + 2) + r + dx) * STRIDE + 16 * h + half * HC * 32;
             const unsigned char *b1 = b0 + (C3_TW + 2) * STRIDE;
 #pragma unroll
-            for (int cs = 0; cs < NCS; cs++) {
+            for (int cs = 0; cs < HC; cs++) {
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[tap][cs], *reinterpret_cast<const bf16x8 *>(b0 + cs * 32), acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[tap][cs], *reinterpret_cast<const bf16x8 *>(b1 + cs * 32), acc[1], 0, 0, 0);
             }
         }
-        __syncthreads();                                         // the patch is consumed: its LDS now stages the outputs
-        __bf16 *ob = reinterpret_cast<__bf16 *>(patch);          // [8 rows][32 cols][CS]
+        C3_PROBE(2);
+        __syncthreads();                                         // the patch is consumed: its LDS now carries partial sums and outputs
+        C3_PROBE(3);
+        // both halves finish one output row each: a wave hands the other half its partial sums of the row it does NOT finish (four 16-byte
+        // pieces per lane, lane-contiguous: conflict-free) and adds what it receives to the row it keeps (lower half row 0, upper row 1)
+        // (the two halves are separate straight-line copies: indexing acc[] with the run-time half sends the accumulators to scratch)
+        auto give = [&](const f32x16 &a) {
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+            for (int g = 0; g < 4; g++) part[((wave * 4 + g) << 6) + lane] = f32x4{a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+        };
+        auto finish = [&](const f32x16 &a, int j) {
+            f32x4 o2[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++) o2[g] = part[(((wave ^ 4) * 4 + g) << 6) + lane];
 #pragma unroll
             for (int g = 0; g < 4; g++) {
-                const int c = 8 * g + 4 * h;
-                if (c >= CS) continue;
-                const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + c);
-                bf16x4 o;
+                bf16x4 o;                                        // staging rows are 32 channels wide: no channel test, no branch between the LDS reads
 #pragma unroll
-                for (int q = 0; q < 4; q++) o[q] = (__bf16)actf(acc[j][4 * g + q] + bias[q], p.act);
-                *reinterpret_cast<bf16x4 *>(ob + ((2 * wave + j) * C3_TW + r) * CS + c) = o;
+                for (int q = 0; q < 4; q++) o[q] = (__bf16)actc<ACT>((a[4 * g + q] + o2[g][q]) + biasr[g][q]);
+                *reinterpret_cast<bf16x4 *>(ob + ((2 * rw + j) * C3_TW + r) * 32 + 8 * g + 4 * h) = o;
             }
+        };
+        if (half) give(acc[0]); else give(acc[1]);
         __syncthreads();
-        for (int i = threadIdx.x; i < C3_TH * C3_TW * PCS; i += 256) {
-            const int px = i / PCS, part = i - px * PCS;
-            const int oy = c_ty0 + px / C3_TW, ox = c_tx0 + px % C3_TW;
-            if (oy >= p.H || ox >= p.W) continue;
-            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(ob + px * CS + part * 8);
+        C3_PROBE(4);
+        if (half) finish(acc[1], 1); else finish(acc[0], 0);
+        __syncthreads();
+        C3_PROBE(5);
+#pragma unroll
+        for (int w = 0; w < NWB; w++) {
+            const int oy = c_ty0 + (wb_yx[w] >> 16), ox = c_tx0 + (wb_yx[w] & 0xffff);
+            if (wb_src[w] < 0 || oy >= p.H || ox >= p.W) continue;
+            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(ob + wb_src[w]);
             if ((C3_DBG & 4) && v[0] != (__bf16)123.f) continue;
-            __bf16 *dst = p.y + (((long)c_n * p.H * U + oy * U) * ((long)p.W * U) + ox * U) * p.out_ldc + p.out_coff + part * 8;
+            __bf16 *dst = p.y + (((long)c_n * p.H * U + oy * U) * ((long)p.W * U) + ox * U) * p.out_ldc + p.out_coff + wb_part[w];
             for (int uy = 0; uy < U; uy++)
                 for (int ux = 0; ux < U; ux++) *reinterpret_cast<bf16x8 *>(dst + ((long)uy * p.W * U + ux) * p.out_ldc) = v;
         }
+        C3_PROBE(6);
         if (!has_next) break;
         __syncthreads();                                         // output staging read: the LDS takes the next patch
+        C3_PROBE(7);
         lstore();
+        C3_PROBE(8);
         __syncthreads();
         tile = next;
+        c3_it++;
     }
 }
 
@@ -446,7 +537,7 @@ struct DwArgs {
 #ifndef DW_DBG
 #define DW_DBG 0            // timing experiments only: 1 no weight staging, 2 no global loads, 4 no stores
 #endif
-template <int K, int S>
+template <int K, int S, int ACT>
 __global__ __launch_bounds__(256) void dwconv_bf16_kernel(DwArgs p) {
     constexpr int R = 4, NC = (R - 1) * S + K, PAD = (K - 1) / 2;
     extern __shared__ __attribute__((aligned(16))) float dw_lds[];
@@ -538,7 +629,7 @@ __global__ __launch_bounds__(256) void dwconv_bf16_kernel(DwArgs p) {
                 if (ox0 + r >= p.Wo) continue;
                 bf16x8 o;
 #pragma unroll
-                for (int j = 0; j < 8; j++) { const float t = actf(acc[r][j >> 1][j & 1], p.act); sum[j] += t; o[j] = (__bf16)t; }
+                for (int j = 0; j < 8; j++) { const float t = actc<ACT>(acc[r][j >> 1][j & 1]); sum[j] += t; o[j] = (__bf16)t; }
                 if (!(DW_DBG & 4) || o[0] == (__bf16)123.f) *reinterpret_cast<bf16x8 *>(p.y + (((long)n * p.Ho + oy) * p.Wo + ox0 + r) * p.C + q * 8) = o;
             }
         }
@@ -560,12 +651,10 @@ __global__ __launch_bounds__(256) void dwconv_bf16_kernel(DwArgs p) {
 template <int K, int S>
 static int launch_dw(const DwArgs &p, int N, hipStream_t stream) {
     const size_t lds = sizeof(float) * ((size_t)(K * K + 1) * p.ob * 8 + 256 * 8);
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dwconv_bf16_kernel<K, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = lds;
-    }
-    hipLaunchKernelGGL((dwconv_bf16_kernel<K, S>), dim3(p.nblk, N, cdiv(p.C / 8, p.ob)), dim3(256), lds, stream, p);
+    PT_CHECK(lds <= 64 * 1024, "ptocr_dwconv_bf16: %zu bytes of LDS for %d channel octets per block", lds, p.ob);
+#define PT_DW(A) hipLaunchKernelGGL((dwconv_bf16_kernel<K, S, A>), dim3(p.nblk, N, cdiv(p.C / 8, p.ob)), dim3(256), lds, stream, p)
+    PT_ACT_SWITCH(p.act, PT_DW);
+#undef PT_DW
     return launch_ok("dwconv_bf16_kernel");
 }
 
@@ -588,8 +677,9 @@ static inline int dw_rows(int N, int Ho, int Wo) {
 // ---------------------------------------------------------------------------------------------- stem: 3x3 / stride 2 / pad 1, RGB
 // reads the model's own input f32[N,3,H,W] (no layout pass), writes bf16[N,Ho,Wo,16] (+ folded BN + Hardswish): 27 taps x 16
 // channels per pixel on the VALU, weights (f32[27][16], row (c*3 + ky)*3 + kx) and bias broadcast from LDS.
+template <int ACT>
 __global__ __launch_bounds__(256) void stem3x3s2_bf16_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
-                                                             __bf16 *__restrict__ y, int H, int W, int Ho, int Wo, int act, long total) {
+                                                             __bf16 *__restrict__ y, int H, int W, int Ho, int Wo, long total) {
     __shared__ __attribute__((aligned(16))) float sw[27 * 16 + 16];
     for (int i = threadIdx.x; i < 27 * 16 + 16; i += 256) sw[i] = i < 27 * 16 ? w[i] : bias[i - 27 * 16];
     __syncthreads();
@@ -618,7 +708,7 @@ __global__ __launch_bounds__(256) void stem3x3s2_bf16_kernel(const float *__rest
         }
     bf16x8 o0, o1;
 #pragma unroll
-    for (int j = 0; j < 8; j++) { o0[j] = (__bf16)actf(acc[j >> 1][j & 1], act); o1[j] = (__bf16)actf(acc[4 + (j >> 1)][j & 1], act); }
+    for (int j = 0; j < 8; j++) { o0[j] = (__bf16)actc<ACT>(acc[j >> 1][j & 1]); o1[j] = (__bf16)actc<ACT>(acc[4 + (j >> 1)][j & 1]); }
     *reinterpret_cast<bf16x8 *>(y + i * 16) = o0;
     *reinterpret_cast<bf16x8 *>(y + i * 16 + 8) = o1;
 }
@@ -769,9 +859,18 @@ extern "C" int ptocr_pwconv_bf16(const void *d_x, const void *d_w, const float *
     const long blocks = (p.M + 127) / 128;
     PT_CHECK(blocks < (1L << 31), "ptocr_pwconv_bf16: too many pixels");
     hipStream_t s = (hipStream_t)stream;
-    if (p.ntile >= 3) hipLaunchKernelGGL(pw_bf16_kernel<3>, dim3((unsigned)blocks, cdiv(p.ntile, 3)), dim3(256), 0, s, p);
-    else if (p.ntile == 2) hipLaunchKernelGGL(pw_bf16_kernel<2>, dim3((unsigned)blocks, 1), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(pw_bf16_kernel<1>, dim3((unsigned)blocks, 1), dim3(256), 0, s, p);
+#define PT_PW(A) do { \
+        if (res_mode == 0) { \
+            if (p.ntile >= 3) hipLaunchKernelGGL((pw_bf16_kernel<3, false, A>), dim3((unsigned)blocks, cdiv(p.ntile, 3)), dim3(256), 0, s, p); \
+            else if (p.ntile == 2) hipLaunchKernelGGL((pw_bf16_kernel<2, false, A>), dim3((unsigned)blocks, 1), dim3(256), 0, s, p); \
+            else hipLaunchKernelGGL((pw_bf16_kernel<1, false, A>), dim3((unsigned)blocks, 1), dim3(256), 0, s, p); \
+        } else { \
+            if (p.ntile >= 3) hipLaunchKernelGGL((pw_bf16_kernel<3, true, A>), dim3((unsigned)blocks, cdiv(p.ntile, 3)), dim3(256), 0, s, p); \
+            else if (p.ntile == 2) hipLaunchKernelGGL((pw_bf16_kernel<2, true, A>), dim3((unsigned)blocks, 1), dim3(256), 0, s, p); \
+            else hipLaunchKernelGGL((pw_bf16_kernel<1, true, A>), dim3((unsigned)blocks, 1), dim3(256), 0, s, p); \
+        } } while (0)
+    PT_ACT_SWITCH(act, PT_PW);
+#undef PT_PW
     return launch_ok("pw_bf16_kernel");
 }
 
@@ -794,12 +893,18 @@ extern "C" int ptocr_conv3x3_bf16(const void *d_x, const void *d_w, const float 
             PT_HIP(hipGetDevice(&dev));
             PT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
         }
-        const int tiles_x = cdiv(W, C3_TW), tpi = tiles_x * cdiv(H, C3_TH);
+        const int th = 8;
+        const int tiles_x = cdiv(W, C3_TW), tpi = tiles_x * cdiv(H, th);
         const long total = (long)N * tpi;
         PT_CHECK(total < (1L << 31), "ptocr_conv3x3_bf16: too many tiles");
         const int grid = total < (long)n_cu ? (int)total : n_cu;             // one persistent workgroup per CU (weights in its registers)
-        hipLaunchKernelGGL(conv3x3_bf16_pers_kernel<6>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, tiles_x, tpi, (int)total);
-        return launch_ok("conv3x3_bf16_pers_kernel");
+        PT_CHECK((long)H * W * Cin * 2 < (1L << 31), "ptocr_conv3x3_bf16: image larger than 2 GiB");
+        {
+#define PT_C3(A) hipLaunchKernelGGL((conv3x3_bf16_pers8_kernel<6, A>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p, tiles_x, tpi, (int)total)
+            PT_ACT_SWITCH(act, PT_C3);
+#undef PT_C3
+        }
+        return launch_ok("conv3x3_bf16_pers8_kernel");
     }
     if (use_lds && Cin <= C3_MAXCIN && N <= 65535) {
         if (Cin == 96) hipLaunchKernelGGL(conv3x3_bf16_lds_kernel<6>, dim3(cdiv(W, C3_TW) * cdiv(H, C3_TH), N), dim3(256), 0, (hipStream_t)stream, p);
@@ -837,8 +942,10 @@ extern "C" int ptocr_stem3x3s2_bf16(const float *d_x, const float *d_w, const fl
     PT_CHECK(d_x && d_w && d_bias && d_y && N >= 1 && H >= 2 && W >= 2 && act >= 0 && act <= 2, "ptocr_stem3x3s2_bf16: bad arguments");
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long total = (long)N * Ho * Wo;
-    hipLaunchKernelGGL(stem3x3s2_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_x, d_w, d_bias, (__bf16 *)d_y,
-                       H, W, Ho, Wo, act, total);
+#define PT_STEM(A) hipLaunchKernelGGL(stem3x3s2_bf16_kernel<A>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_x, d_w, d_bias, \
+                                     (__bf16 *)d_y, H, W, Ho, Wo, total)
+    PT_ACT_SWITCH(act, PT_STEM);
+#undef PT_STEM
     return launch_ok("stem3x3s2_bf16_kernel");
 }
 
