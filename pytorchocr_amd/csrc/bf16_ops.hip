@@ -135,39 +135,52 @@ __global__ __launch_bounds__(256) void pw_bf16_kernel(PwArgs p) {
     const int CH = (cend - cbase + 7) >> 3;                      // 16-byte chunks per pixel row (the last may be half: cstore % 8 == 4)
     if (CH <= 0) return;
     const long mw0 = ((long)blockIdx.x * 4 + wave) * 32;
-    for (int i = lane; i < 32 * CH; i += 64) {
-        const int pr = i / CH, ch = i - pr * CH;
+    // No division inside the loop (a run-time integer division is ~40 VALU instructions; the first version did four per item and was
+    // instruction-bound on the large maps): (pixel, chunk) of an item advance incrementally, and for the top-down add the wave's first
+    // pixel is decomposed once and a pixel's (n, y, x) follows by carries.
+    const int step_pr = 64 / CH, step_ch = 64 - step_pr * CH;
+    int pr = lane / CH, ch = lane - pr * CH;
+    int n0 = 0, oy0 = 0, ox0 = 0;
+    if (RES && p.res_mode == 2) {
+        n0 = (int)(mw0 / HW);
+        const int rem = (int)(mw0 - (long)n0 * HW);
+        oy0 = rem / p.W; ox0 = rem - oy0 * p.W;
+    }
+    for (; pr < 32; ) {
         const long mm = mw0 + pr;
-        if (mm >= p.M) continue;
         const int c = cbase + ch * 8;
         const bool full = c + 8 <= cend;
-        __bf16 *dst = p.y + mm * p.out_ldc + p.out_coff + c;
-        if constexpr (RES) {
-            const __bf16 *rsrc;
-            if (p.res_mode == 1) rsrc = p.res + mm * p.res_ldc + c;
-            else {
-                const int n = (int)(mm / HW);
-                const int rem = (int)(mm - (long)n * HW);
-                const int oy = rem / p.W, ox = rem - oy * p.W;
-                rsrc = p.res + (((long)n * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) * p.res_ldc + c;
-            }
-            bf16x4 r0 = *reinterpret_cast<const bf16x4 *>(rsrc), r1 = r0;
-            if (full) r1 = *reinterpret_cast<const bf16x4 *>(rsrc + 4);
-            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(&tile[wave][pr][ch * 8]), v1 = *reinterpret_cast<const f32x4 *>(&tile[wave][pr][ch * 8 + 4]);
-            bf16x8 o;
+        if (mm < p.M) {
+            __bf16 *dst = p.y + mm * p.out_ldc + p.out_coff + c;
+            if constexpr (RES) {
+                const __bf16 *rsrc;
+                if (p.res_mode == 1) rsrc = p.res + mm * p.res_ldc + c;
+                else {
+                    int n = n0, oy = oy0, ox = ox0 + pr;
+                    while (ox >= p.W) { ox -= p.W; oy++; }
+                    while (oy >= p.H) { oy -= p.H; n++; }
+                    rsrc = p.res + (((long)n * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) * p.res_ldc + c;
+                }
+                bf16x4 r0 = *reinterpret_cast<const bf16x4 *>(rsrc), r1 = r0;
+                if (full) r1 = *reinterpret_cast<const bf16x4 *>(rsrc + 4);
+                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(&tile[wave][pr][ch * 8]), v1 = *reinterpret_cast<const f32x4 *>(&tile[wave][pr][ch * 8 + 4]);
+                bf16x8 o;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                float a0 = v0[j], a1 = v1[j];
-                if (p.res_mode == 1) { a0 = actc<ACT>(a0 + (float)r0[j]); a1 = actc<ACT>(a1 + (float)r1[j]); }
-                else { a0 = actc<ACT>(a0) + (float)r0[j]; a1 = actc<ACT>(a1) + (float)r1[j]; }
-                o[j] = (__bf16)a0; o[4 + j] = (__bf16)a1;
+                for (int j = 0; j < 4; j++) {
+                    float a0 = v0[j], a1 = v1[j];
+                    if (p.res_mode == 1) { a0 = actc<ACT>(a0 + (float)r0[j]); a1 = actc<ACT>(a1 + (float)r1[j]); }
+                    else { a0 = actc<ACT>(a0) + (float)r0[j]; a1 = actc<ACT>(a1) + (float)r1[j]; }
+                    o[j] = (__bf16)a0; o[4 + j] = (__bf16)a1;
+                }
+                if (full) *reinterpret_cast<bf16x8 *>(dst) = o;
+                else { bf16x4 oh = {o[0], o[1], o[2], o[3]}; *reinterpret_cast<bf16x4 *>(dst) = oh; }
+            } else {
+                if (full) *reinterpret_cast<bf16x8 *>(dst) = *reinterpret_cast<const bf16x8 *>(&tile[wave][pr][ch * 8]);
+                else *reinterpret_cast<bf16x4 *>(dst) = *reinterpret_cast<const bf16x4 *>(&tile[wave][pr][ch * 8]);
             }
-            if (full) *reinterpret_cast<bf16x8 *>(dst) = o;
-            else { bf16x4 oh = {o[0], o[1], o[2], o[3]}; *reinterpret_cast<bf16x4 *>(dst) = oh; }
-        } else {
-            if (full) *reinterpret_cast<bf16x8 *>(dst) = *reinterpret_cast<const bf16x8 *>(&tile[wave][pr][ch * 8]);
-            else *reinterpret_cast<bf16x4 *>(dst) = *reinterpret_cast<const bf16x4 *>(&tile[wave][pr][ch * 8]);
         }
+        pr += step_pr; ch += step_ch;
+        if (ch >= CH) { ch -= CH; pr++; }
     }
 }
 
@@ -679,16 +692,15 @@ static inline int dw_rows(int N, int Ho, int Wo) {
 // channels per pixel on the VALU, weights (f32[27][16], row (c*3 + ky)*3 + kx) and bias broadcast from LDS.
 template <int ACT>
 __global__ __launch_bounds__(256) void stem3x3s2_bf16_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
-                                                             __bf16 *__restrict__ y, int H, int W, int Ho, int Wo, long total) {
+                                                             __bf16 *__restrict__ y, int H, int W, int Ho, int Wo) {
     __shared__ __attribute__((aligned(16))) float sw[27 * 16 + 16];
     for (int i = threadIdx.x; i < 27 * 16 + 16; i += 256) sw[i] = i < 27 * 16 ? w[i] : bias[i - 27 * 16];
     __syncthreads();
-    const long i = blockIdx.x * 256L + threadIdx.x;
-    if (i >= total) return;
-    const int ox = (int)(i % Wo);
-    const long t = i / Wo;
-    const int oy = (int)(t % Ho);
-    const long n = t / Ho;
+    // grid = (column blocks, rows, images): no division per pixel (the flat 64-bit index of the first version cost two 64-bit divisions)
+    const long n = blockIdx.z;
+    const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;
+    if (ox >= Wo) return;
+    const long i = (n * Ho + oy) * Wo + ox;
     f32x2 acc[8];                                                // packed fp32 FMAs on channel pairs: the 432 multiply-adds per pixel bound this kernel
 #pragma unroll
     for (int j = 0; j < 8; j++) acc[j] = *reinterpret_cast<const f32x2 *>(sw + 27 * 16 + 2 * j);
@@ -711,6 +723,52 @@ __global__ __launch_bounds__(256) void stem3x3s2_bf16_kernel(const float *__rest
     for (int j = 0; j < 8; j++) { o0[j] = (__bf16)actc<ACT>(acc[j >> 1][j & 1]); o1[j] = (__bf16)actc<ACT>(acc[4 + (j >> 1)][j & 1]); }
     *reinterpret_cast<bf16x8 *>(y + i * 16) = o0;
     *reinterpret_cast<bf16x8 *>(y + i * 16 + 8) = o1;
+}
+
+// Two output pixels per thread (W % 4 == 0): the five input columns 4t-1 .. 4t+3 of a (channel, kernel row) are ONE aligned 16-byte load
+// (lane-contiguous: a wave reads 1 KB of a row) plus the left neighbour, instead of six 4-byte loads two floats apart.
+template <int ACT>
+__global__ __launch_bounds__(512) void stem3x3s2_bf16_pair_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                                                                  __bf16 *__restrict__ y, int H, int W, int Ho, int Wo) {
+    __shared__ __attribute__((aligned(16))) float sw[27 * 16 + 16];
+    for (int i = threadIdx.x; i < 27 * 16 + 16; i += blockDim.x) sw[i] = i < 27 * 16 ? w[i] : bias[i - 27 * 16];
+    __syncthreads();
+    const long n = blockIdx.z;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y;
+    if (2 * t >= Wo) return;
+    f32x2 accA[8], accB[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) accA[j] = accB[j] = *reinterpret_cast<const f32x2 *>(sw + 27 * 16 + 2 * j);
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) {
+            const int iy = 2 * oy - 1 + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;            // block-uniform
+            const float *row = x + ((n * 3 + c) * H + iy) * (long)W;
+            const f32x4 q = *reinterpret_cast<const f32x4 *>(row + 4 * t);
+            const float left = t > 0 ? row[4 * t - 1] : 0.f;
+            const f32x2 *wr = reinterpret_cast<const f32x2 *>(sw + ((c * 3 + ky) * 3) * 16);
+            const float va[3] = {left, q[0], q[1]}, vb[3] = {q[1], q[2], q[3]};
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) {
+                const f32x2 a2 = {va[kx], va[kx]}, b2 = {vb[kx], vb[kx]};
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    accA[j] = __builtin_elementwise_fma(a2, wr[kx * 8 + j], accA[j]);
+                    accB[j] = __builtin_elementwise_fma(b2, wr[kx * 8 + j], accB[j]);
+                }
+            }
+        }
+    bf16x8 o[4];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        o[0][j] = (__bf16)actc<ACT>(accA[j >> 1][j & 1]); o[1][j] = (__bf16)actc<ACT>(accA[4 + (j >> 1)][j & 1]);
+        o[2][j] = (__bf16)actc<ACT>(accB[j >> 1][j & 1]); o[3][j] = (__bf16)actc<ACT>(accB[4 + (j >> 1)][j & 1]);
+    }
+    bf16x8 *dst = reinterpret_cast<bf16x8 *>(y + ((n * Ho + oy) * Wo + 2 * t) * 16);
+#pragma unroll
+    for (int k = 0; k < 4; k++) dst[k] = o[k];
 }
 
 // ---------------------------------------------------------------------------------------------- DB head tail
@@ -941,10 +999,15 @@ extern "C" int ptocr_dwconv_bf16_nblk(int N, int H, int W, int k, int stride) {
 extern "C" int ptocr_stem3x3s2_bf16(const float *d_x, const float *d_w, const float *d_bias, void *d_y, int N, int H, int W, int act, void *stream) {
     PT_CHECK(d_x && d_w && d_bias && d_y && N >= 1 && H >= 2 && W >= 2 && act >= 0 && act <= 2, "ptocr_stem3x3s2_bf16: bad arguments");
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const long total = (long)N * Ho * Wo;
-#define PT_STEM(A) hipLaunchKernelGGL(stem3x3s2_bf16_kernel<A>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_x, d_w, d_bias, \
-                                     (__bf16 *)d_y, H, W, Ho, Wo, total)
-    PT_ACT_SWITCH(act, PT_STEM);
+    PT_CHECK(N <= 65535 && Ho <= 65535, "ptocr_stem3x3s2_bf16: batch or height > 65535");
+#define PT_STEM(A) hipLaunchKernelGGL(stem3x3s2_bf16_kernel<A>, dim3((unsigned)((Wo + 255) / 256), (unsigned)Ho, (unsigned)N), dim3(256), 0, (hipStream_t)stream, d_x, d_w, d_bias, \
+                                     (__bf16 *)d_y, H, W, Ho, Wo)
+    const int pairs = Wo / 2, pblocks = cdiv(pairs, 512), pthreads = cdiv(cdiv(pairs, pblocks), 64) * 64;     // whole waves, no idle tail block (320 pairs: one block of 320)
+#define PT_STEM2(A) hipLaunchKernelGGL(stem3x3s2_bf16_pair_kernel<A>, dim3((unsigned)pblocks, (unsigned)Ho, (unsigned)N), dim3(pthreads), 0, (hipStream_t)stream, \
+                                      d_x, d_w, d_bias, (__bf16 *)d_y, H, W, Ho, Wo)
+    if (W % 4 == 0 && (reinterpret_cast<size_t>(d_x) & 15) == 0) PT_ACT_SWITCH(act, PT_STEM2);
+    else PT_ACT_SWITCH(act, PT_STEM);
+#undef PT_STEM2
 #undef PT_STEM
     return launch_ok("stem3x3s2_bf16_kernel");
 }
