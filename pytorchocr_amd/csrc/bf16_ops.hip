@@ -59,7 +59,7 @@ struct PwArgs {
     int out_ldc, out_coff, res_ldc;
 };
 
-template <int NT, bool RES, int ACT>
+template <int NT, bool RES, int ACT, int GRP>
 __global__ __launch_bounds__(256) void pw_bf16_kernel(PwArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -76,20 +76,46 @@ __global__ __launch_bounds__(256) void pw_bf16_kernel(PwArgs p) {
         for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
     const __bf16 *wrow = p.w + ((long)t0 * 32 + r) * p.Cin + 8 * h;
     const int nks = p.Cin >> 4;
-    for (int ks = 0; ks < nks; ks++) {
-        bf16x8 b = *reinterpret_cast<const bf16x8 *>(xrow + ks * 16);
+    // K loop in groups of four slices, all loads of a group issued before its first MFMA, no branch inside: the small maps have one or
+    // two waves per SIMD and Cin up to 576 -- with one slice per iteration every MFMA waited for its own operands' round trip to L2
+    // (36 dependent round trips for the 576-channel layers).  GRP = 1 (Cin < 64) keeps the one-slice loop: the 64 extra registers of the
+    // group cost the large-map layers a third of their waves (97 -> 129 us).  Tiles beyond ntile read tile 0's rows (valid memory) and are dropped below.
+    const __bf16 *wr[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) wr[t] = wrow + (t0 + t < p.ntile ? (long)t * 32 * p.Cin : 0L);
+    auto scaled = [&](bf16x8 b, int ks) {
+        const f32x4 s0 = *reinterpret_cast<const f32x4 *>(srow + ks * 16), s1 = *reinterpret_cast<const f32x4 *>(srow + ks * 16 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { b[j] = (__bf16)((float)b[j] * s0[j]); b[4 + j] = (__bf16)((float)b[4 + j] * s1[j]); }
+        return b;
+    };
+    int ks = 0;
+    if constexpr (GRP == 4)
+    for (; ks + 4 <= nks; ks += 4) {
+        bf16x8 b[4], a[NT][4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) b[u] = *reinterpret_cast<const bf16x8 *>(xrow + (ks + u) * 16);
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int u = 0; u < 4; u++) a[t][u] = *reinterpret_cast<const bf16x8 *>(wr[t] + (ks + u) * 16);
         if (srow) {
-            const f32x4 s0 = *reinterpret_cast<const f32x4 *>(srow + ks * 16), s1 = *reinterpret_cast<const f32x4 *>(srow + ks * 16 + 4);
 #pragma unroll
-            for (int j = 0; j < 4; j++) { b[j] = (__bf16)((float)b[j] * s0[j]); b[4 + j] = (__bf16)((float)b[4 + j] * s1[j]); }
+            for (int u = 0; u < 4; u++) b[u] = scaled(b[u], ks + u);
         }
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            if (t0 + t < p.ntile) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(wrow + (long)t * 32 * p.Cin + ks * 16);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
-            }
-        }
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][u], b[u], acc[t], 0, 0, 0);
+    }
+    for (; ks < nks; ks++) {
+        bf16x8 b = *reinterpret_cast<const bf16x8 *>(xrow + ks * 16);
+        bf16x8 a[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) a[t] = *reinterpret_cast<const bf16x8 *>(wr[t] + ks * 16);
+        if (srow) b = scaled(b, ks);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], b, acc[t], 0, 0, 0);
     }
     // Epilogue through LDS: a lane's accumulator quads are 8-byte pieces of its pixel's row, 160 bytes apart from the next lane's --
     // stored directly they reach HBM as partial sectors (measured 2.4x write amplification).  Each wave parks its 32 pixels x
@@ -99,16 +125,31 @@ __global__ __launch_bounds__(256) void pw_bf16_kernel(PwArgs p) {
     // RES = true (block residual / FPN top-down add): the tile holds fp32 (conv + bias) and the residual is read in the write-back
     // phase, where it is one coalesced 16-byte load per lane -- read on the way in it was twelve 8-byte loads per lane, 192 bytes
     // apart from the neighbouring lane's.
-    constexpr int TW = RES ? NT * 32 + 4 : NT * 32 + 8;         // tile row stride in elements (16-byte padded: conflict-free 16-B accesses)
+    // One 32-channel tile at a time (4.6 KB of LDS per wave in fp32 instead of 12.8 KB for three): the kernel is latency-bound on the
+    // large maps and LDS was what limited the waves per CU (12 -> 32).  A pixel's 32 channels are four 16-byte chunks: lane l takes
+    // chunk l % 4 of pixel l / 4 (+ 16 in the second round) -- no division anywhere; for the top-down add the wave's first pixel is
+    // decomposed once and a pixel's (n, y, x) follows by carries (run-time integer divisions, ~40 VALU instructions each, four per item,
+    // made the first version instruction-bound).
+    constexpr int TW = RES ? 32 + 4 : 32 + 8;                   // tile row stride in elements (16-byte padded: conflict-free 16-B accesses)
     typedef typename std::conditional<RES, float, __bf16>::type tile_t;
     __shared__ __attribute__((aligned(16))) tile_t tile[4][32][TW];
+    const long mw0 = ((long)blockIdx.x * 4 + wave) * 32;
+    int n0 = 0, oy0 = 0, ox0 = 0;
+    if (RES && p.res_mode == 2) {
+        n0 = (int)(mw0 / HW);
+        const int rem = (int)(mw0 - (long)n0 * HW);
+        oy0 = rem / p.W; ox0 = rem - oy0 * p.W;
+    }
+    const int ch = lane & 3;
 #pragma unroll
-    for (int t = 0; t < NT; t++)
+    for (int t = 0; t < NT; t++) {
+        const int tbase = (t0 + t) * 32, tend = min(p.cstore, tbase + 32);
+        if (t0 + t >= p.ntile || tend <= tbase) break;          // wave-uniform
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            const int c = (t0 + t) * 32 + 8 * g + 4 * h;
+            const int c = tbase + 8 * g + 4 * h;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (t0 + t < p.ntile && c < p.cstore) {
+            if (c < tend) {
                 const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + c);
 #pragma unroll
                 for (int j = 0; j < 4; j++) v[j] = acc[t][4 * g + j] + bias[j];
@@ -118,39 +159,24 @@ __global__ __launch_bounds__(256) void pw_bf16_kernel(PwArgs p) {
                 }
             }
             if constexpr (RES) {
-                *reinterpret_cast<f32x4 *>(&tile[wave][r][t * 32 + 8 * g + 4 * h]) = v;
+                *reinterpret_cast<f32x4 *>(&tile[wave][r][8 * g + 4 * h]) = v;
             } else {
                 bf16x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; j++) o[j] = (__bf16)v[j];
-                *reinterpret_cast<bf16x4 *>(&tile[wave][r][t * 32 + 8 * g + 4 * h]) = o;
+                *reinterpret_cast<bf16x4 *>(&tile[wave][r][8 * g + 4 * h]) = o;
             }
         }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // write-back: chunks of 8 channels; lane l takes chunk l % CH of pixel l / CH (+ 64 / CH per round)
-    const int cbase = t0 * 32;
-    const int cend = min(p.cstore, (t0 + NT) * 32);              // channels [cbase, cend) belong to this workgroup
-    const int CH = (cend - cbase + 7) >> 3;                      // 16-byte chunks per pixel row (the last may be half: cstore % 8 == 4)
-    if (CH <= 0) return;
-    const long mw0 = ((long)blockIdx.x * 4 + wave) * 32;
-    // No division inside the loop (a run-time integer division is ~40 VALU instructions; the first version did four per item and was
-    // instruction-bound on the large maps): (pixel, chunk) of an item advance incrementally, and for the top-down add the wave's first
-    // pixel is decomposed once and a pixel's (n, y, x) follows by carries.
-    const int step_pr = 64 / CH, step_ch = 64 - step_pr * CH;
-    int pr = lane / CH, ch = lane - pr * CH;
-    int n0 = 0, oy0 = 0, ox0 = 0;
-    if (RES && p.res_mode == 2) {
-        n0 = (int)(mw0 / HW);
-        const int rem = (int)(mw0 - (long)n0 * HW);
-        oy0 = rem / p.W; ox0 = rem - oy0 * p.W;
-    }
-    for (; pr < 32; ) {
-        const long mm = mw0 + pr;
-        const int c = cbase + ch * 8;
-        const bool full = c + 8 <= cend;
-        if (mm < p.M) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int c = tbase + ch * 8;
+        const bool full = c + 8 <= tend;
+#pragma unroll
+        for (int round = 0; round < 2; round++) {
+            const int pr = (lane >> 2) + 16 * round;
+            const long mm = mw0 + pr;
+            if (c >= tend || mm >= p.M) continue;
             __bf16 *dst = p.y + mm * p.out_ldc + p.out_coff + c;
             if constexpr (RES) {
                 const __bf16 *rsrc;
@@ -179,8 +205,9 @@ __global__ __launch_bounds__(256) void pw_bf16_kernel(PwArgs p) {
                 else *reinterpret_cast<bf16x4 *>(dst) = *reinterpret_cast<const bf16x4 *>(&tile[wave][pr][ch * 8]);
             }
         }
-        pr += step_pr; ch += step_ch;
-        if (ch >= CH) { ch -= CH; pr++; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                        // the tile is read: the next 32 channels may overwrite it
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -917,18 +944,22 @@ extern "C" int ptocr_pwconv_bf16(const void *d_x, const void *d_w, const float *
     const long blocks = (p.M + 127) / 128;
     PT_CHECK(blocks < (1L << 31), "ptocr_pwconv_bf16: too many pixels");
     hipStream_t s = (hipStream_t)stream;
-#define PT_PW(A) do { \
+#define PT_PW_G(A, G) do { \
         if (res_mode == 0) { \
-            if (p.ntile >= 3) hipLaunchKernelGGL((pw_bf16_kernel<3, false, A>), dim3((unsigned)blocks, cdiv(p.ntile, 3)), dim3(256), 0, s, p); \
-            else if (p.ntile == 2) hipLaunchKernelGGL((pw_bf16_kernel<2, false, A>), dim3((unsigned)blocks, 1), dim3(256), 0, s, p); \
-            else hipLaunchKernelGGL((pw_bf16_kernel<1, false, A>), dim3((unsigned)blocks, 1), dim3(256), 0, s, p); \
+            if (p.ntile >= 3) hipLaunchKernelGGL((pw_bf16_kernel<3, false, A, G>), dim3((unsigned)blocks, cdiv(p.ntile, 3)), dim3(256), 0, s, p); \
+            else if (p.ntile == 2) hipLaunchKernelGGL((pw_bf16_kernel<2, false, A, G>), dim3((unsigned)blocks, 1), dim3(256), 0, s, p); \
+            else hipLaunchKernelGGL((pw_bf16_kernel<1, false, A, G>), dim3((unsigned)blocks, 1), dim3(256), 0, s, p); \
         } else { \
-            if (p.ntile >= 3) hipLaunchKernelGGL((pw_bf16_kernel<3, true, A>), dim3((unsigned)blocks, cdiv(p.ntile, 3)), dim3(256), 0, s, p); \
-            else if (p.ntile == 2) hipLaunchKernelGGL((pw_bf16_kernel<2, true, A>), dim3((unsigned)blocks, 1), dim3(256), 0, s, p); \
-            else hipLaunchKernelGGL((pw_bf16_kernel<1, true, A>), dim3((unsigned)blocks, 1), dim3(256), 0, s, p); \
+            if (p.ntile >= 3) hipLaunchKernelGGL((pw_bf16_kernel<3, true, A, G>), dim3((unsigned)blocks, cdiv(p.ntile, 3)), dim3(256), 0, s, p); \
+            else if (p.ntile == 2) hipLaunchKernelGGL((pw_bf16_kernel<2, true, A, G>), dim3((unsigned)blocks, 1), dim3(256), 0, s, p); \
+            else hipLaunchKernelGGL((pw_bf16_kernel<1, true, A, G>), dim3((unsigned)blocks, 1), dim3(256), 0, s, p); \
         } } while (0)
-    PT_ACT_SWITCH(act, PT_PW);
-#undef PT_PW
+#define PT_PW1(A) PT_PW_G(A, 1)
+#define PT_PW4(A) PT_PW_G(A, 4)
+    if (Cin >= 64) PT_ACT_SWITCH(act, PT_PW4); else PT_ACT_SWITCH(act, PT_PW1);
+#undef PT_PW1
+#undef PT_PW4
+#undef PT_PW_G
     return launch_ok("pw_bf16_kernel");
 }
 
