@@ -894,6 +894,79 @@ __device__ void rotating_calipers_wave(const F2 *points, int n, float *scratch, 
             break;
         }
     }
+    if (n <= 64) {
+        // The caliper walk is sequential, but it need not live in LDS: lane i keeps edge i and vertex i in registers, the WHOLE wave
+        // runs the walk with wave-uniform state, and an indexed access is a v_readlane (a few cycles) instead of a dependent LDS round
+        // trip (the lane-0 loop below spent ~1.5 k cycles per step on them).  Only the caliper that advanced is re-read.  Same float
+        // operations in the same order as rotating_calipers().
+        const int me = lane < n ? lane : 0;
+        const F2 myv = vect[me], myp = points[me];
+        const float myl = inv_len[me];
+        auto rl = [](float v, int idx) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), idx)); };
+        float minarea = 3.402823466e+38f;
+        float base_a = orientation, base_b = 0;
+        float buf_a = 0, buf_w = 0, buf_b = 0, buf_h = 0, bl_x = 0, bl_y = 0, bb_x = 0, bb_y = 0;
+        int s0 = __builtin_amdgcn_readfirstlane(bottom), s1 = __builtin_amdgcn_readfirstlane(right), s2 = __builtin_amdgcn_readfirstlane(top),
+            s3 = __builtin_amdgcn_readfirstlane(left);
+        float v0x = rl(myv.x, s0), v0y = rl(myv.y, s0), l0 = rl(myl, s0), p0x = rl(myp.x, s0), p0y = rl(myp.y, s0);
+        float v1x = rl(myv.x, s1), v1y = rl(myv.y, s1), l1 = rl(myl, s1), p1x = rl(myp.x, s1), p1y = rl(myp.y, s1);
+        float v2x = rl(myv.x, s2), v2y = rl(myv.y, s2), l2 = rl(myl, s2), p2x = rl(myp.x, s2), p2y = rl(myp.y, s2);
+        float v3x = rl(myv.x, s3), v3y = rl(myv.y, s3), l3 = rl(myl, s3), p3x = rl(myp.x, s3), p3y = rl(myp.y, s3);
+        for (int k = 0; k < n; k++) {
+            float dp[4];
+            dp[0] = +base_a * v0x + base_b * v0y;
+            dp[1] = -base_b * v1x + base_a * v1y;
+            dp[2] = -base_a * v2x - base_b * v2y;
+            dp[3] = +base_b * v3x - base_a * v3y;
+            float maxcos = dp[0] * l0;
+            int main_element = 0;
+            { const float c = dp[1] * l1; if (c > maxcos) { main_element = 1; maxcos = c; } }
+            { const float c = dp[2] * l2; if (c > maxcos) { main_element = 2; maxcos = c; } }
+            { const float c = dp[3] * l3; if (c > maxcos) { main_element = 3; maxcos = c; } }
+            main_element = __builtin_amdgcn_readfirstlane(main_element);
+            if (main_element == 0) {
+                const float lead_x = v0x * l0, lead_y = v0y * l0;
+                base_a = lead_x; base_b = lead_y;
+                s0 = s0 + 1 == n ? 0 : s0 + 1;
+                v0x = rl(myv.x, s0); v0y = rl(myv.y, s0); l0 = rl(myl, s0); p0x = rl(myp.x, s0); p0y = rl(myp.y, s0);
+            } else if (main_element == 1) {
+                const float lead_x = v1x * l1, lead_y = v1y * l1;
+                base_a = lead_y; base_b = -lead_x;
+                s1 = s1 + 1 == n ? 0 : s1 + 1;
+                v1x = rl(myv.x, s1); v1y = rl(myv.y, s1); l1 = rl(myl, s1); p1x = rl(myp.x, s1); p1y = rl(myp.y, s1);
+            } else if (main_element == 2) {
+                const float lead_x = v2x * l2, lead_y = v2y * l2;
+                base_a = -lead_x; base_b = -lead_y;
+                s2 = s2 + 1 == n ? 0 : s2 + 1;
+                v2x = rl(myv.x, s2); v2y = rl(myv.y, s2); l2 = rl(myl, s2); p2x = rl(myp.x, s2); p2y = rl(myp.y, s2);
+            } else {
+                const float lead_x = v3x * l3, lead_y = v3y * l3;
+                base_a = -lead_y; base_b = lead_x;
+                s3 = s3 + 1 == n ? 0 : s3 + 1;
+                v3x = rl(myv.x, s3); v3y = rl(myv.y, s3); l3 = rl(myl, s3); p3x = rl(myp.x, s3); p3y = rl(myp.y, s3);
+            }
+            float dx = p1x - p3x;
+            float dy = p1y - p3y;
+            const float width = dx * base_a + dy * base_b;
+            dx = p2x - p0x;
+            dy = p2y - p0y;
+            const float height = -dx * base_b + dy * base_a;
+            const float area = width * height;
+            if (area <= minarea) {
+                minarea = area;
+                bl_x = p3x; bl_y = p3y; buf_a = base_a; buf_w = width; buf_b = base_b; buf_h = height; bb_x = p0x; bb_y = p0y;
+            }
+        }
+        const float A1 = buf_a, B1 = buf_b, A2 = -buf_b, B2 = buf_a;
+        const float C1 = A1 * bl_x + bl_y * B1;
+        const float C2 = A2 * bb_x + bb_y * B2;
+        const float idet = 1.f / (A1 * B2 - A2 * B1);
+        out[0] = (C1 * B2 - C2 * B1) * idet;
+        out[1] = (A1 * C2 - A2 * C1) * idet;
+        out[2] = A1 * buf_w; out[3] = B1 * buf_w;
+        out[4] = A2 * buf_h; out[5] = B2 * buf_h;
+        return;
+    }
     if (lane != 0) return;
     float minarea = 3.402823466e+38f;
     float base_a = orientation, base_b = 0;
@@ -956,13 +1029,108 @@ __device__ void rotating_calipers_wave(const F2 *points, int n, float *scratch, 
     out[4] = A2 * buf_h; out[5] = B2 * buf_h;
 }
 
+// convex_hull_sorted() for n <= 64 run by the whole wave with wave-uniform state: lane i keeps point i in registers, an indexed point
+// is a v_readlane, the chain's three running points are carried in registers (one new point per step), the index stack stays in
+// LDS (written by lane 0, read back only when a point is popped), and the extreme scans / output copies go one element per lane.
+// Same comparisons and float operations as sklansky() / convex_hull_sorted(); returns the hull size on every lane.
+__device__ int sklansky_wave(float myx, float myy, int start, int end, int *stack, int nsign, int sign2) {
+    const bool l0 = (threadIdx.x & 63) == 0;
+    auto X = [&](int i) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myx), i)); };
+    auto Y = [&](int i) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myy), i)); };
+    start = __builtin_amdgcn_readfirstlane(start); end = __builtin_amdgcn_readfirstlane(end);
+    const int incr = end > start ? 1 : -1;
+    int pprev = start, pcur = pprev + incr, pnext = pcur + incr;
+    int stacksize = 3;
+    if (start == end || (X(start) == X(end) && Y(start) == Y(end))) { if (l0) stack[0] = start; return 1; }
+    const int first = pprev;                                    // stack[0] never changes
+    if (l0) { stack[0] = pprev; stack[1] = pcur; stack[2] = pnext; }
+    end += incr;
+    float ppx = X(pprev), ppy = Y(pprev), pcx = X(pcur), pcy = Y(pcur);
+    while (pnext != end) {
+        const float pnx = X(pnext), pny = Y(pnext);
+        const float by = pny - pcy;
+        if (sgn(by) != nsign) {
+            const float ax = pcx - ppx;
+            const float bx = pnx - pcx;
+            const float ay = pcy - ppy;
+            const double convexity = (double)ay * bx - (double)ax * by;
+            if (sgn(convexity) == sign2 && (ax != 0 || ay != 0)) {
+                pprev = pcur; ppx = pcx; ppy = pcy;
+                pcur = pnext; pcx = pnx; pcy = pny;
+                pnext += incr;
+                if (l0) stack[stacksize] = pnext;
+                stacksize++;
+            } else if (pprev == first) {
+                pcur = pnext; pcx = pnx; pcy = pny;
+                pnext += incr;
+                if (l0) { stack[1] = pcur; stack[2] = pnext; }
+            } else {
+                if (l0) stack[stacksize - 2] = pnext;
+                pcur = pprev; pcx = ppx; pcy = ppy;
+                pprev = __builtin_amdgcn_readfirstlane(stack[stacksize - 4]);
+                ppx = X(pprev); ppy = Y(pprev);
+                stacksize--;
+            }
+        } else {
+            pnext += incr;
+            if (l0) stack[stacksize - 1] = pnext;
+        }
+    }
+    return --stacksize;
+}
+
+__device__ int convex_hull_sorted_wave(const F2 *a, int n, F2 *hull, int *stack) {
+    const int lane = threadIdx.x & 63;
+    const F2 me = a[lane < n ? lane : 0];
+    int miny_ind, maxy_ind;
+    wave_first_extreme(me.y, lane < n ? lane : -1, false, &miny_ind);      // first index of the minimum / maximum, as the strict scans give
+    wave_first_extreme(me.y, lane < n ? lane : -1, true, &maxy_ind);
+    miny_ind = __builtin_amdgcn_readfirstlane(miny_ind); maxy_ind = __builtin_amdgcn_readfirstlane(maxy_ind);
+    int nout = 0;
+    if (a[0].x == a[n - 1].x && a[0].y == a[n - 1].y) { if (lane == 0) hull[0] = a[0]; wave_sync(); return 1; }
+    int *tl_stack = stack;
+    const int tl_count = sklansky_wave(me.x, me.y, 0, maxy_ind, tl_stack, -1, 1);
+    int *tr_stack = stack + tl_count;
+    const int tr_count = sklansky_wave(me.x, me.y, n - 1, maxy_ind, tr_stack, -1, -1);
+    wave_sync();
+    if (lane < tl_count - 1) hull[nout + lane] = a[tl_stack[lane]];
+    nout += tl_count > 1 ? tl_count - 1 : 0;
+    if (lane < tr_count - 1) hull[nout + lane] = a[tr_stack[tr_count - 1 - lane]];
+    nout += tr_count > 1 ? tr_count - 1 : 0;
+    const int stop_idx = tr_count > 2 ? tr_stack[1] : tl_count > 2 ? tl_stack[tl_count - 2] : -1;
+    wave_sync();                                                // the stacks are read: the lower chains reuse their memory
+    int *bl_stack = stack;
+    int bl_count = sklansky_wave(me.x, me.y, 0, miny_ind, bl_stack, 1, -1);
+    int *br_stack = stack + bl_count;
+    int br_count = sklansky_wave(me.x, me.y, n - 1, miny_ind, br_stack, 1, 1);
+    wave_sync();
+    { int *ts = bl_stack; const int tc = bl_count; bl_stack = br_stack; bl_count = br_count; br_stack = ts; br_count = tc; }
+    if (stop_idx >= 0) {
+        const int check_idx = bl_count > 2 ? bl_stack[1] : bl_count + br_count > 2 ? br_stack[2 - bl_count] : -1;
+        if (check_idx == stop_idx || (check_idx >= 0 && a[check_idx].x == a[stop_idx].x && a[check_idx].y == a[stop_idx].y)) {
+            bl_count = bl_count < 2 ? bl_count : 2;
+            br_count = br_count < 2 ? br_count : 2;
+        }
+    }
+    if (lane < bl_count - 1) hull[nout + lane] = a[bl_stack[lane]];
+    nout += bl_count > 1 ? bl_count - 1 : 0;
+    if (lane < br_count - 1) hull[nout + lane] = a[br_stack[br_count - 1 - lane]];
+    nout += br_count > 1 ? br_count - 1 : 0;
+    wave_sync();
+    return nout;
+}
+
 // minAreaRect on an already x-sorted point list, wave-cooperative; the result is valid on lane 0.  sh_hn: one LDS int.
 __device__ RRect min_area_rect_wave(const F2 *sorted, int n, F2 *hull, int *stack, float *scratch, int *sh_hn) {
     RRect box; box.cx = box.cy = box.w = box.h = box.angle = 0.f;
     if (n <= 0) return box;                                     // uniform
-    if ((threadIdx.x & 63) == 0) *sh_hn = convex_hull_sorted(sorted, n, hull, stack);
-    wave_sync();
-    const int hn = *sh_hn;
+    int hn;
+    if (n <= 64) hn = __builtin_amdgcn_readfirstlane(convex_hull_sorted_wave(sorted, n, hull, stack));
+    else {
+        if ((threadIdx.x & 63) == 0) *sh_hn = convex_hull_sorted(sorted, n, hull, stack);
+        wave_sync();
+        hn = *sh_hn;
+    }
     if (hn > 2) {
         float out[6] = {0, 0, 0, 0, 0, 0};
         rotating_calipers_wave(hull, hn, scratch, out);
@@ -1578,8 +1746,10 @@ __global__ __launch_bounds__(64, 5) void unclip_kernel(StageArgs a, DbpostDims d
     __shared__ long long cl_ws[24];
     __shared__ int sh_np;
     const float (*mini)[2] = reinterpret_cast<const float (*)[2]>(a.mini + bi * 8);
+    if (a.dbg_skip & 32) { if (threadIdx.x == 0) res->status = ST_NONE; return; }
     if (threadIdx.x == 0) {
         int n0 = unclip_offset(mini, a.unclip_ratio, raw, S_MH, res, &a.flags[img], cl_ws);
+        if (a.dbg_skip & 16) n0 = 0;
         if (n0 > 0 && n0 <= S_MH && res->distance < UNION_MAX_DISTANCE) n0 = clipper_union_cut(raw, n0, pts, stack);   // Execute's union (scratch: the arrays of the next steps)
         sh_np = n0;
     }
@@ -1599,7 +1769,8 @@ __global__ __launch_bounds__(64, 5) void unclip_kernel(StageArgs a, DbpostDims d
     __shared__ int sh_hn;
     __syncthreads();
     RRect ub;
-    if (np <= 0) { ub.cx = 0; ub.cy = 0; ub.w = 1; ub.h = 1; ub.angle = 0; }
+    if (np <= 0 || (a.dbg_skip & 64)) { ub.cx = 0; ub.cy = 0; ub.w = 1; ub.h = 1; ub.angle = 0; }
+    else if (a.dbg_skip & 128) { ub.cx = 0; ub.cy = 0; ub.h = 1; ub.angle = 0; ub.w = (float)convex_hull_sorted_wave(pts, np < 64 ? np : 64, hull, stack); }
     else ub = min_area_rect_wave(pts, np, hull, stack, scratch, &sh_hn);
     if (threadIdx.x == 0) res->status = unclip_box(ub, res, a.src_wh[2 * img], a.src_wh[2 * img + 1], a.use_padding_resize, d);
 }
