@@ -579,7 +579,7 @@ struct DwArgs {
 #endif
 template <int K, int S, int ACT>
 __global__ __launch_bounds__(256) void dwconv_bf16_kernel(DwArgs p) {
-    constexpr int R = 4, NC = (R - 1) * S + K, PAD = (K - 1) / 2;
+    constexpr int R = (S == 1 && K == 5) ? 8 : 4, NC = (R - 1) * S + K, PAD = (K - 1) / 2;       // 5x5 stride 1: runs of 8 outputs (12 loads per row for 8 outputs instead of 16; 3x3 loses with 8)
     extern __shared__ __attribute__((aligned(16))) float dw_lds[];
     // A block owns p.ob channel octets (blockIdx.z picks the group): its slice of the weights is a few KB of LDS instead of (K*K+1)*C
     // floats, so that occupancy is set by registers -- the loads of a run are K dependent round trips and need many waves to hide.
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(512) void stem3x3s2_bf16_pair_kernel(const float *_
     for (int i = threadIdx.x; i < 27 * 16 + 16; i += blockDim.x) sw[i] = i < 27 * 16 ? w[i] : bias[i - 27 * 16];
     __syncthreads();
     const long n = blockIdx.z;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y;       // (an XCD-aware row order was tried: no change, 178 us)
     if (2 * t >= Wo) return;
     f32x2 accA[8], accB[8];
 #pragma unroll
