@@ -85,7 +85,7 @@ def test_conv3x3_and_dwconv_kernels():
     got = out.float().cpu()
     assert float(((got[..., 24:48].double() - ref).abs() / (ref.abs() + 1)).max()) <= 6e-3
     assert float(got[..., :24].abs().max()) == 0 and float(got[..., 48:].abs().max()) == 0      # other slices of the concat untouched
-    for k, stride, c in ((3, 1, 16), (5, 2, 96), (5, 1, 240)):
+    for k, stride, c in ((3, 1, 16), (5, 2, 96), (5, 1, 240), (5, 1, 576), (3, 2, 72)):     # 576: two channel groups per block row; 72: nine octets
         dw = torch.nn.Conv2d(c, c, k, stride, (k - 1) // 2, groups=c, bias=False)
         bn = torch.nn.BatchNorm2d(c).eval(); bn.running_var.uniform_(0.5, 1.5)
         pd = bp._Dw(dw, bn, torch.device("cuda:0"), 2)
@@ -96,6 +96,46 @@ def test_conv3x3_and_dwconv_kernels():
         assert float(((y.float().cpu().double() - ref).abs() / (ref.abs() + 1)).max()) <= 6e-3
         pooled = partial.sum(1).cpu().double()
         assert float((pooled - ref.sum((1, 2))).abs().max()) <= 1e-2 * ref.shape[1] * ref.shape[2] * 1e-2 + 1e-2
+
+
+def test_conv3x3_many_tiles_images_and_concat_slice():
+    """the persistent 3x3 kernel on a map of several tiles per image (partial tiles on both edges), several images, written into the last
+    slice of a concat buffer whose other slices must stay untouched; and the 32-channel output form the head uses"""
+    from pytorchocr_amd.modeling import bf16_path as bp
+    torch.manual_seed(5)
+    conv = torch.nn.Conv2d(96, 24, 3, 1, 1, bias=False)
+    bn = torch.nn.BatchNorm2d(24).eval(); bn.running_var.uniform_(0.5, 1.5); bn.running_mean.uniform_(-0.2, 0.2)
+    c3 = bp._C3(conv, bn, torch.device("cuda:0"), 1)
+    n, h, w = 5, 37, 75                                          # 5 x 3 tiles of 8 x 32 per image
+    x = _bf(torch.randn(n, h, w, 96))
+    wd = c3.w.cpu().double().reshape(32, 3, 3, 96)[:24].permute(0, 3, 1, 2)
+    ref = F.relu(F.conv2d(x.double().permute(0, 3, 1, 2), wd, c3.b.cpu().double()[:24], 1, 1)).permute(0, 2, 3, 1)
+    out = torch.full((n, h, w, 96), 7.0, dtype=torch.bfloat16, device="cuda:0")
+    bp.conv3x3(x.cuda(), c3, out=out, up=1, coff=72, cstore=24)
+    got = out.float().cpu()
+    assert float(((got[..., 72:].double() - ref).abs() / (ref.abs() + 1)).max()) <= 6e-3
+    assert float((got[..., :72] - 7.0).abs().max()) == 0
+    y = bp.conv3x3(x.cuda(), c3).float().cpu()                  # own tensor, 32 channels wide
+    assert y.shape == (n, h, w, 32) and float(y[..., 24:].abs().max()) == 0
+    assert float(((y[..., :24].double() - ref).abs() / (ref.abs() + 1)).max()) <= 6e-3
+
+
+@pytest.mark.parametrize("hw", [(38, 64), (37, 62)])            # W % 4 == 0: two pixels per thread on 16-byte loads; otherwise one per thread
+def test_stem_kernel_both_forms(hw):
+    import ctypes as C
+    from pytorchocr_amd import _lib
+    from pytorchocr_amd.modeling import bf16_path as bp
+    torch.manual_seed(6)
+    h, w = hw
+    x = torch.randn(3, 3, h, w)
+    wt = torch.randn(16, 3, 3, 3) * 0.3
+    b = torch.randn(16) * 0.1
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    t = torch.empty((3, ho, wo, 16), dtype=torch.bfloat16, device="cuda:0")
+    xd, wd, bd = x.cuda(), wt.permute(1, 2, 3, 0).reshape(27, 16).contiguous().cuda(), b.cuda()
+    _lib.check(_lib.lib().ptocr_stem3x3s2_bf16(bp._ptr(xd), bp._ptr(wd), bp._ptr(bd), bp._ptr(t), 3, h, w, 2, _lib.cur_stream()), "stem")
+    ref = F.hardswish(F.conv2d(x.double(), wt.double(), b.double(), 2, 1)).permute(0, 2, 3, 1)
+    assert float(((t.float().cpu().double() - ref).abs() / (ref.abs() + 1)).max()) <= 6e-3
 
 
 def test_bf16_maps_against_reference_golden_and_oracle(gold_dir, contract):
