@@ -152,6 +152,52 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs &p, f32x16 (&ac
     }
 }
 
+// The common case of the epilogue above (plain store, ReLU or none, optional pre-ReLU residual) with the modes as template
+// parameters: the general form carries them as run-time flags, which the compiler turns into wave-uniform scalar branches around
+// every 16-byte chunk (~250 per tile and wave, several thousand cycles against ~70 k of MFMAs).
+template <int RELU, int RES>
+__device__ __forceinline__ void conv_epilogue_lds_plain(const ConvArgs &p, f32x16 (&acc)[2][2], int m0, int n0, int wm0, int wn0, int lane, float *wsm) {
+    constexpr int EL = 68;
+    const int frow = lane & 31, fh = lane >> 5;
+    const int chunk = lane & 15, rsub = lane >> 4;
+    const int col = n0 + wn0 + chunk * 4;
+    const f32x4 bias4 = *reinterpret_cast<const f32x4 *>(p.bias + col);
+    const bool col_ok = col < p.cout_store;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                wsm[((r & 3) + 8 * (r >> 2) + 4 * fh) * EL + j * 32 + frow] = acc[i][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int mb = m0 + wm0 + i * 32 + rsub;
+        f32x4 v[8], rs[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = *reinterpret_cast<const f32x4 *>(wsm + (rsub + 4 * q) * EL + chunk * 4);
+        if (RES) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int m = mb + 4 * q;
+                rs[q] = (m < p.M && col_ok) ? *reinterpret_cast<const f32x4 *>(p.res + (long)m * p.res_ldc + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int m = mb + 4 * q;
+            f32x4 o = v[q] + bias4;
+            if (RES) o += rs[q];
+            if (RELU) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
+            if (m < p.M && col_ok) *reinterpret_cast<f32x4 *>(p.y + (long)m * p.out_ldc + p.out_coff + col) = o;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // CTC-greedy epilogue (the FC of the CTC head, rec_ctc_head.py:17-36 + rec_postprocess.py:80-84): the logits of this wave's
 // 64 rows x 64 columns are never stored.  Each 32-row half is parked in the wave's LDS tile; two lanes share a row (32 columns
 // each) and reduce it to (max logit, its FIRST column, sum exp(logit - max)); lane pairs combine by shuffle and one float4
@@ -527,8 +573,18 @@ __global__ __launch_bounds__(256) void conv_mfma_v2_kernel(ConvArgs p) {
     }
     static_assert(2 * STAGE >= 4 * 32 * 68, "epilogue tiles must fit in the staging LDS");
     if (p.ctc_part) ctc_epilogue_lds(p, acc, m0, n0, wm0, wn0, lane, smem + wave * (32 * 68));
-    else if (p.vec_epilogue) conv_epilogue_lds(p, acc, m0, n0, wm0, wn0, lane, smem + wave * (32 * 68));
-    else conv_epilogue(p, acc, m0, n0, wm0, wn0, frow, fh);
+    else if (p.vec_epilogue) {
+        const bool plain = !p.convt && p.out_up <= 1 && (p.res_mode == PTOCR_RES_NONE || p.res_mode == PTOCR_RES_ADD_PRE_RELU) && p.relu <= 1;
+        float *wsm = smem + wave * (32 * 68);
+        if (!plain) conv_epilogue_lds(p, acc, m0, n0, wm0, wn0, lane, wsm);
+        else if (p.res_mode == PTOCR_RES_NONE) {
+            if (p.relu) conv_epilogue_lds_plain<1, 0>(p, acc, m0, n0, wm0, wn0, lane, wsm);
+            else conv_epilogue_lds_plain<0, 0>(p, acc, m0, n0, wm0, wn0, lane, wsm);
+        } else {
+            if (p.relu) conv_epilogue_lds_plain<1, 1>(p, acc, m0, n0, wm0, wn0, lane, wsm);
+            else conv_epilogue_lds_plain<0, 1>(p, acc, m0, n0, wm0, wn0, lane, wsm);
+        }
+    } else conv_epilogue(p, acc, m0, n0, wm0, wn0, frow, fh);
 }
 
 template <int BM, int BN, bool SMALLC>
