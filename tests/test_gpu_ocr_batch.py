@@ -58,6 +58,9 @@ def test_run_batch_equals_per_image_run(ocr):
         _same(g, ocr.run_gpu(img))
         n += len(g)
     assert n > 30 and stats["boxes"] >= n and stats["lines"] == n
+    # sub-groups of two images: the detector of sub-group i+1 is queued before the host stages of sub-group i (software pipeline)
+    for a, b in zip(ocr.run_batch(imgs, rec_batch=16, det_batch=2), got):
+        _same(a, b)
     # a device-resident stack gives the same as the list of arrays
     stack = torch.from_numpy(np.stack(imgs[:2])).cuda()
     for a, b in zip(ocr.run_batch(stack), got[:2]):

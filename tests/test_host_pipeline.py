@@ -30,6 +30,29 @@ def test_sort_boxes_known_answers():
     assert all(isinstance(x, np.ndarray) and x.dtype == np.int16 for x in sort_boxes(np.array([_box(1, 1)], np.int16)))
 
 
+def test_sort_boxes_int_fast_path_equals_scalar_semantics():
+    """the int16 fast path (lexsort + plain ints) against the statement of the rule on numpy int16 scalars (reference utility.py:32-50),
+    including values where the int16 |dy| wraps"""
+    import warnings
+    rng = np.random.default_rng(3)
+
+    def by_scalars(b):
+        order = sorted(range(b.shape[0]), key=lambda i: (b[i, 0, 1], b[i, 0, 0]))
+        out = [b[i] for i in order]
+        for i in range(1, len(out)):
+            if abs(out[i][0][1] - out[i - 1][0][1]) < 10 and out[i][0][0] < out[i - 1][0][0]:
+                out[i - 1], out[i] = out[i], out[i - 1]
+        return out
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                                                  # int16 overflow warnings of the scalar form
+        for trial in range(200):
+            hi = (40, 2000, 32767)[trial % 3]
+            b = rng.integers(-hi if trial % 5 == 0 else 0, hi, (int(rng.integers(0, 50)), 4, 2)).astype(np.int16)
+            got, exp = sort_boxes(b), by_scalars(b)
+            assert len(got) == len(exp) and all(np.array_equal(g, e) for g, e in zip(got, exp)), trial
+
+
 def test_load_config_and_dotted_merge():
     cfg = load_config(os.path.join(ROOT, "pytorchocr_amd", "configs", "det", "det_r18_db.yml"))
     assert cfg.Architecture["Backbone"]["layers"] == 18 and cfg["Global"]["debug"] is False
