@@ -7,7 +7,7 @@ f = glob.glob(os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/bt/*/*kernel_trace.cs
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # last forward: find last stem kernel
-idx = [i for i, r in enumerate(rows) if "stem3x3s2_bf16" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "stem3x3s2_bf16" in r["Kernel_Name"] or "stem_dw_bf16" in r["Kernel_Name"]]
 start = idx[-1]
 tot = 0
 for r in rows[start:]:
