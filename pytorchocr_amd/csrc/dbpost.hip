@@ -49,7 +49,7 @@ struct DbpostDims {
 // ------------------------------------------------------------------------------------------ binarize
 // 4 pixels per lane (one 16-B load), nibbles of 8 lanes OR-combined into a 32-bit word.
 __global__ __launch_bounds__(256) void binarize_kernel(const float *__restrict__ maps, unsigned *__restrict__ bits,
-                                                       DbpostDims d, float thresh) {
+                                                       DbpostDims d, float thresh, int *__restrict__ strip_runs) {
     const int img = blockIdx.z, y = blockIdx.y;
     const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
     const float *row = maps + (long)img * d.HW + (long)y * d.W;
@@ -67,6 +67,22 @@ __global__ __launch_bounds__(256) void binarize_kernel(const float *__restrict__
     v |= __shfl_xor(v, 4);
     const int wi = x0 >> 5;
     if ((threadIdx.x & 7) == 0 && wi < d.WW) bits[((long)img * d.H + y) * d.WW + wi] = v;
+    // run starts of both polarities in the bottom strip (a pixel that differs from its left neighbour; column 0 against the background
+    // frame): every component of the strip, foreground or hole, contains at least one
+    if (strip_runs && d.strip_y && y >= d.strip_y) {             // uniform over the block
+        const int lane = threadIdx.x & 63;
+        unsigned prev = __shfl_up(v, 8);                         // the word to the left (same value on the 8 lanes of a word)
+        if (lane < 8) prev = (x0 >= 32 && wi < d.WW && (row[(wi << 5) - 1] > thresh)) ? 0x80000000u : 0u;     // first word of the wave: the pixel itself
+        int c = 0;
+        if ((threadIdx.x & 7) == 0 && wi < d.WW) {
+            const int valid = d.W - (wi << 5);
+            const unsigned mask = valid >= 32 ? 0xffffffffu : ((1u << valid) - 1u);
+            c = __popc((v ^ ((v << 1) | (prev >> 31))) & mask);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+        if (lane == 0 && c) atomicAdd(&strip_runs[img], c);
+    }
 }
 
 __global__ __launch_bounds__(256) void pack_u8_kernel(const uint8_t *__restrict__ bm, unsigned *__restrict__ bits, DbpostDims d) {
@@ -186,9 +202,11 @@ __device__ __forceinline__ WordCtx word_ctx(const unsigned *row, int wi, const D
 // strip) -- and when an image has >= MAX_CAND starts there (speckle / noise maps: tens of thousands of components) pass B,
 // the whole image, is skipped for it.  Clean maps have few components and go through both passes (pass A costs 9 %).
 constexpr int STRIP_ROWS = 64;
-struct CclPass { int y_first; const int *skip_if_full; };        // skip_if_full: per-image start counts of pass A, or null
+struct CclPass { int y_first; const int *skip_if_full; const int *skip_if_few; };   // skip_if_full: per-image start counts of pass A (pass B), skip_if_few: run starts of the strip (pass A), or null
 
-__device__ __forceinline__ bool ccl_skip(const CclPass &ps, int img) { return ps.skip_if_full && ps.skip_if_full[img] >= MAX_CAND; }
+__device__ __forceinline__ bool ccl_skip(const CclPass &ps, int img) {
+    return (ps.skip_if_full && ps.skip_if_full[img] >= MAX_CAND) || (ps.skip_if_few && ps.skip_if_few[img] < MAX_CAND);
+}
 
 // label[s] = s for every run start s (pass B also clears the image's chunk counters)
 __global__ __launch_bounds__(256) void ccl_init_kernel(const unsigned *__restrict__ bits, int *__restrict__ labels,
@@ -1890,6 +1908,7 @@ struct ptocr_dbpost {
     long pool_cap;
     hipEvent_t ev0, ev1;          // device time of the last call's kernels (ptocr_dbpost_last_device_ms)
     int timed;
+    int *strip_runs;              // per image: run starts (both polarities) in the bottom strip, counted by binarize_kernel
 };
 
 extern "C" int ptocr_dbpost_create(ptocr_dbpost_t *out, int max_n, int max_h, int max_w) {
@@ -1909,6 +1928,7 @@ extern "C" int ptocr_dbpost_create(ptocr_dbpost_t *out, int max_n, int max_h, in
     PT_HIP(hipMalloc(&h->chunk_cnt, sizeof(int) * max_n * nch));
     PT_HIP(hipMalloc(&h->totals, sizeof(int) * max_n));
     PT_HIP(hipMalloc(&h->strip_totals, sizeof(int) * max_n));
+    PT_HIP(hipMalloc(&h->strip_runs, sizeof(int) * max_n));
     PT_HIP(hipMalloc(&h->cands, sizeof(Cand) * max_n * MAX_CAND));
     PT_HIP(hipMalloc(&h->acc, sizeof(Acc) * max_n * MAX_CAND));
     PT_HIP(hipMalloc(&h->pool, sizeof(unsigned) * max_n * h->pool_cap));
@@ -1933,6 +1953,7 @@ extern "C" int ptocr_dbpost_destroy(ptocr_dbpost_t h) {
     for (void *b : bufs) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    (void)hipFree(h->strip_runs);
     delete h;
     return 0;
 }
@@ -2010,22 +2031,28 @@ extern "C" int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, co
     PT_HIP(hipMemcpyAsync(h->src_wh, h_src_wh, sizeof(int) * 2 * N, hipMemcpyHostToDevice, s));
     PT_HIP(hipEventRecord(h->ev0, s));
     PT_HIP(hipMemsetAsync(h->flags, 0, sizeof(int) * N, s));
+    const int strip_y = H > 2 * STRIP_ROWS ? H - STRIP_ROWS : 0;      // small maps: one pass over everything
+    d.strip_y = strip_y;
+    // run starts in the strip, counted while binarizing: an upper bound of the strip's components.  Below MAX_CAND the strip pass cannot
+    // be enough and is left out for that image (its four kernels return at once); a caller's own bitmap or the dilation is not counted
+    // (0x7f7f7f7f: the strip pass always runs).
+    const bool counted = !d_bitmap && !use_dilation;
+    PT_HIP(hipMemsetAsync(h->strip_runs, counted ? 0 : 0x7f, sizeof(int) * N, s));
     const dim3 row_grid(cdiv(W, 1024), H, N);
     if (d_bitmap) hipLaunchKernelGGL(pack_u8_kernel, row_grid, dim3(256), 0, s, d_bitmap, h->bits, d);
-    else hipLaunchKernelGGL(binarize_kernel, row_grid, dim3(256), 0, s, d_maps, h->bits, d, thresh);
+    else hipLaunchKernelGGL(binarize_kernel, row_grid, dim3(256), 0, s, d_maps, h->bits, d, thresh, counted ? h->strip_runs : nullptr);
     unsigned *bits = h->bits;
     if (use_dilation) {
         hipLaunchKernelGGL(dilate2x2_kernel, dim3(cdiv(d.WW, 256), H, N), dim3(256), 0, s, h->bits, h->bits2, d);
         bits = h->bits2;
     }
     PT_HIP(hipMemsetAsync(h->chunk_cnt, 0, sizeof(int) * (size_t)N * d.nchunks, s));
-    const int strip_y = H > 2 * STRIP_ROWS ? H - STRIP_ROWS : 0;      // small maps: one pass over everything
-    d.strip_y = strip_y;
-    if (!strip_y) PT_HIP(hipMemsetAsync(h->strip_totals, 0, sizeof(int) * N, s));
+    PT_HIP(hipMemsetAsync(h->strip_totals, 0, sizeof(int) * N, s));      // stays 0 for an image whose strip pass is left out
     for (int pass = strip_y ? 0 : 1; pass < 2; pass++) {
         CclPass ps;
         ps.y_first = pass == 0 ? strip_y : 0;
         ps.skip_if_full = (pass == 1 && strip_y) ? h->strip_totals : nullptr;
+        ps.skip_if_few = pass == 0 ? h->strip_runs : nullptr;
         const int words = (H - ps.y_first) * d.WW;
         const dim3 word_grid(cdiv(words > d.nchunks ? words : d.nchunks, 256), N);
         hipLaunchKernelGGL(ccl_init_kernel, word_grid, dim3(256), 0, s, bits, h->labels, h->chunk_cnt, d, ps);

@@ -115,6 +115,20 @@ def test_noisy_maps_many_tiny_borders():
         _compare(m, [[w, h]], thresh=0.3 + 0.2 * seed, box_thresh=0.5)
 
 
+def test_strip_pass_is_chosen_per_image_and_never_changes_the_result():
+    """The bottom-strip labelling pass is a shortcut for maps with >= 1000 starts in their last 64 rows; it is left out for an image whose
+    strip has fewer than 1000 run starts (counted while binarizing).  Text and noise maps alone and MIXED in one batch; every call must
+    equal the oracle."""
+    text = synth_prob_maps(2, 400, 640, seed=21)
+    noise = uniform01(2 * 400 * 640, 77).reshape(2, 400, 640).astype(np.float32)
+    noise = np.where(np.abs(noise - 0.5) < 2e-3, 0.51, noise).astype(np.float32)
+    wh = [[640, 400], [1280, 800]]
+    for maps, th in ((text, 0.3), (noise, 0.5), (text, 0.3)):
+        _compare(maps, wh, thresh=th)
+    mixed = np.stack([text[0], noise[0], text[1]])                     # thresh 0.5 on the text maps as well: still text-like
+    _compare(mixed, wh + [[640, 400]], thresh=0.5)
+
+
 @pytest.mark.parametrize("seed,ratio", [(1, 1.5), (2, 1.7), (3, 2.0), (4, 0.6)])
 def test_thin_line_components_are_clipper_slivers(seed, ratio):
     """Hundreds of one-pixel-wide strokes per map (the components a noisy map produces): their min-area boxes are thinner than a
