@@ -187,6 +187,10 @@ int ptocr_se_fc_f32(const float *d_partial, const float *d_w1, const float *d_b1
 /* the same gate from transposed weights d_w1t f32[C][S], d_w2t f32[S][C] (every load coalesced; what the bf16 path calls) */
 int ptocr_se_fc_t_f32(const float *d_partial, const float *d_w1t, const float *d_b1, const float *d_w2t, const float *d_b2,
                       float *d_scale, int N, int HW, int C, int S, int nblk, void *stream);
+/* the same gate for wide layers (what the bf16 path calls for C >= 256): eight blocks per image in two launches instead of one block
+ * per image; d_hidden f32[N][S] is the caller's workspace.  Same result up to fp32 summation order. */
+int ptocr_se_fc_split_f32(const float *d_partial, const float *d_w1t, const float *d_b1, const float *d_w2t, const float *d_b2,
+                          float *d_hidden, float *d_scale, int N, int HW, int C, int S, int nblk, void *stream);
 /* stem: conv 3x3 / s2 / p1 of the model input f32[N,3,H,W] -> bf16[N,Ho,Wo,16]; d_w f32[27][16] (row (c*3 + ky)*3 + kx), BN folded */
 int ptocr_stem3x3s2_bf16(const float *d_x, const float *d_w, const float *d_bias, void *d_y, int N, int H, int W, int act, void *stream);
 /* DB head tail for C = 24: ConvT(C,C,2,2)+BN+ReLU -> ConvT(C,1,2,2)+bias -> sigmoid; d_x bf16[N,H,W,ldc] -> d_maps f32[N,4H,4W];

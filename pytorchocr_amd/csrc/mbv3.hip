@@ -154,6 +154,90 @@ __global__ __launch_bounds__(256) void se_fc_t_kernel(const float *__restrict__ 
     }
 }
 
+// Wide layers (C >= 256): one block per image leaves 224 of 256 CUs idle for the 30-50 us the two dependent matrix-vector products
+// take (dependent rounds of L2 loads).  Two kernels of SE_SPLIT blocks per image instead: the first recomputes the pooled vector
+// (cheap, same fixed order) and produces a slice of the hidden units, the second a slice of the gate; inside a block every output
+// is split over K slices (thread = (output, slice)) and the slices are summed in a fixed order.
+constexpr int SE_SPLIT = 8;
+__global__ __launch_bounds__(256) void se_fc1_split_kernel(const float *__restrict__ partial, const float *__restrict__ w1t, const float *__restrict__ b1,
+                                                           float *__restrict__ hidden, int HW, int C, int S, int nblk) {
+    const int n = blockIdx.x, part = blockIdx.y;
+    __shared__ float mean[1024], red[256];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float *pp = partial + (long)n * nblk * C + c;
+        float s = 0.f;
+        int b = 0;
+        for (; b + 7 < nblk; b += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = pp[(long)(b + u) * C];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += v[u];
+        }
+        for (; b < nblk; b++) s += pp[(long)b * C];
+        mean[c] = s / (float)HW;
+    }
+    __syncthreads();
+    const int per = (S + SE_SPLIT - 1) / SE_SPLIT;               // hidden units of this block: [j0, j0 + nj)
+    const int j0 = part * per, nj = min(per, S - j0);
+    if (nj <= 0) return;
+    const int KS = 256 / per;                                    // K slices per output (per <= 32 for S <= 256)
+    const int jl = threadIdx.x % per, ks = threadIdx.x / per;
+    float a = 0.f;
+    if (jl < nj && ks < KS) {
+        float acc[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc[u] = 0.f;
+        int c = ks;
+        for (; c + 7 * KS < C; c += 8 * KS) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc[u] += w1t[(long)(c + u * KS) * S + j0 + jl] * mean[c + u * KS];
+        }
+        for (; c < C; c += KS) acc[0] += w1t[(long)c * S + j0 + jl] * mean[c];
+        a = ((acc[0] + acc[4]) + (acc[1] + acc[5])) + ((acc[2] + acc[6]) + (acc[3] + acc[7]));
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x < nj) {
+        float s = 0.f;
+        for (int k = 0; k < KS; k++) s += red[k * per + threadIdx.x];
+        hidden[(long)n * S + j0 + threadIdx.x] = fmaxf(s + b1[j0 + threadIdx.x], 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void se_fc2_split_kernel(const float *__restrict__ hidden, const float *__restrict__ w2t, const float *__restrict__ b2,
+                                                           float *__restrict__ scale, int C, int S) {
+    const int n = blockIdx.x, part = blockIdx.y;
+    __shared__ float mid[256], red[256];
+    for (int j = threadIdx.x; j < S; j += 256) mid[j] = hidden[(long)n * S + j];
+    __syncthreads();
+    const int per = (C + SE_SPLIT - 1) / SE_SPLIT;               // gate channels of this block (per <= 128 for C <= 1024)
+    const int c0 = part * per, nc = min(per, C - c0);
+    if (nc <= 0) return;
+    const int KS = 256 / per;
+    const int cl = threadIdx.x % per, ks = threadIdx.x / per;
+    float a = 0.f;
+    if (cl < nc && ks < KS) {
+        float acc[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc[u] = 0.f;
+        int j = ks;
+        for (; j + 7 * KS < S; j += 8 * KS) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc[u] += w2t[(long)(j + u * KS) * C + c0 + cl] * mid[j + u * KS];
+        }
+        for (; j < S; j += KS) acc[0] += w2t[(long)j * C + c0 + cl] * mid[j];
+        a = ((acc[0] + acc[4]) + (acc[1] + acc[5])) + ((acc[2] + acc[6]) + (acc[3] + acc[7]));
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x < nc) {
+        float s = 0.f;
+        for (int k = 0; k < KS; k++) s += red[k * per + threadIdx.x];
+        scale[(long)n * C + c0 + threadIdx.x] = fminf(fmaxf(s + b2[c0 + threadIdx.x] + 3.f, 0.f), 6.f) * (1.f / 6.f);       // hardsigmoid
+    }
+}
+
 __global__ __launch_bounds__(256) void se_apply_kernel(float *__restrict__ x, const float *__restrict__ scale, int HW, int C4, long total) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4);
@@ -250,6 +334,16 @@ extern "C" int ptocr_se_fc_t_f32(const float *d_partial, const float *d_w1t, con
              "ptocr_se_fc_t_f32: bad arguments (C <= 1024, S <= 256)");
     hipLaunchKernelGGL(se_fc_t_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, d_partial, d_w1t, d_b1, d_w2t, d_b2, d_scale, HW, C, S, nblk);
     return launch_ok("se_fc_t_kernel");
+}
+
+// the same gate for wide layers, SE_SPLIT blocks per image in two launches; d_hidden: workspace f32[N][S] (the caller's: no state here)
+extern "C" int ptocr_se_fc_split_f32(const float *d_partial, const float *d_w1t, const float *d_b1, const float *d_w2t, const float *d_b2,
+                                     float *d_hidden, float *d_scale, int N, int HW, int C, int S, int nblk, void *stream) {
+    PT_CHECK(d_partial && d_w1t && d_b1 && d_w2t && d_b2 && d_hidden && d_scale && C <= 1024 && S <= 256 && N >= 1 && N <= 65535 && HW >= 1 && nblk >= 1,
+             "ptocr_se_fc_split_f32: bad arguments (C <= 1024, S <= 256)");
+    hipLaunchKernelGGL(se_fc1_split_kernel, dim3(N, SE_SPLIT), dim3(256), 0, (hipStream_t)stream, d_partial, d_w1t, d_b1, d_hidden, HW, C, S, nblk);
+    hipLaunchKernelGGL(se_fc2_split_kernel, dim3(N, SE_SPLIT), dim3(256), 0, (hipStream_t)stream, d_hidden, d_w2t, d_b2, d_scale, C, S);
+    return launch_ok("se_fc_split_kernel");
 }
 
 extern "C" int ptocr_se_fc_f32(const float *d_partial, const float *d_w1, const float *d_b1, const float *d_w2, const float *d_b2,

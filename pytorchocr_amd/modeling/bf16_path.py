@@ -18,6 +18,7 @@ maps out.  Layers of the reference graph and the kernels that run them (csrc/bf1
 Tolerance: bf16 keeps 8 significant bits, so the 1e-4 bar of the fp32 path cannot hold; tests/test_gpu_bf16.py states and checks
 what does (max |p_bf16 - p_fp32| on the probability maps, and the share of pixels whose side of the 0.3 threshold changes)."""
 import ctypes as C
+import os
 
 import torch
 
@@ -105,6 +106,9 @@ class _Se:
         self.w1t, self.w2t = _f(w1p.t().contiguous(), dev), _f(w2p.t().contiguous(), dev)      # [C][S], [S][C]: the gate kernel's coalesced form
 
 
+SE_SPLIT = os.environ.get("PTOCR_SE_SPLIT", "1") != "0"          # 0: one block per image for every SE gate
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -156,6 +160,11 @@ def dwconv(x, dw, want_pool):
 def se_gate(partial, nblk, se, hw):
     n = partial.shape[0]
     scale = torch.empty((n, se.c), dtype=torch.float32, device=partial.device)
+    if se.c >= 256 and SE_SPLIT:                                 # a function of the layer only: an image's gate never depends on its batch
+        hidden = torch.empty((n, se.s), dtype=torch.float32, device=partial.device)
+        _lib.check(_lib.lib().ptocr_se_fc_split_f32(_ptr(partial), _ptr(se.w1t), _ptr(se.b1), _ptr(se.w2t), _ptr(se.b2), _ptr(hidden), _ptr(scale),
+                                                    n, hw, se.c, se.s, nblk, _lib.cur_stream()), "ptocr_se_fc_split_f32")
+        return scale
     _lib.check(_lib.lib().ptocr_se_fc_t_f32(_ptr(partial), _ptr(se.w1t), _ptr(se.b1), _ptr(se.w2t), _ptr(se.b2), _ptr(scale), n, hw, se.c, se.s, nblk,
                                             _lib.cur_stream()), "ptocr_se_fc_t_f32")
     return scale

@@ -138,6 +138,28 @@ def test_stem_kernel_both_forms(hw):
     assert float(((t.float().cpu().double() - ref).abs() / (ref.abs() + 1)).max()) <= 6e-3
 
 
+def test_se_gate_kernels_match_float64():
+    """hardsigmoid(fc2(relu(fc1(mean)))) from the per-block channel sums: the one-block-per-image kernel and the eight-blocks-per-image
+    pair used for wide layers, against float64"""
+    from pytorchocr_amd import _lib
+    from pytorchocr_amd.modeling import bf16_path as bp
+    torch.manual_seed(3)
+    for (n, c, s_, nblk, hw) in ((3, 576, 144, 23, 920), (2, 288, 72, 12, 3680), (5, 1024, 256, 7, 49), (1, 96, 24, 24, 3680)):
+        partial = torch.randn(n, nblk, c) * 3
+        w1, b1, w2, b2 = torch.randn(s_, c) * 0.1, torch.randn(s_) * 0.1, torch.randn(c, s_) * 0.1, torch.randn(c) * 0.1
+        mean = partial.double().sum(1) / hw
+        ref = F.hardsigmoid(F.relu(mean @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double())
+        d = [t.cuda().contiguous() for t in (partial, w1.t(), b1, w2.t(), b2)]
+        for split in (False, True):
+            scale = torch.empty(n, c, device="cuda:0")
+            if split:
+                hid = torch.empty(n, s_, device="cuda:0")
+                _lib.check(_lib.lib().ptocr_se_fc_split_f32(*[bp._ptr(t) for t in d], bp._ptr(hid), bp._ptr(scale), n, hw, c, s_, nblk, _lib.cur_stream()), "split")
+            else:
+                _lib.check(_lib.lib().ptocr_se_fc_t_f32(*[bp._ptr(t) for t in d], bp._ptr(scale), n, hw, c, s_, nblk, _lib.cur_stream()), "single")
+            assert float((scale.cpu().double() - ref).abs().max()) <= 2e-5, (c, split)
+
+
 def test_bf16_maps_against_reference_golden_and_oracle(gold_dir, contract):
     from oracle import model_oracle
     m, sd = _model(contract)
