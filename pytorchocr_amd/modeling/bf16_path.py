@@ -107,6 +107,7 @@ class _Se:
 
 
 SE_SPLIT = os.environ.get("PTOCR_SE_SPLIT", "1") != "0"          # 0: one block per image for every SE gate
+SE_SPLIT_MIN_C = int(os.environ.get("PTOCR_SE_SPLIT_MIN_C", "256"))
 
 
 def _ptr(t):
@@ -160,7 +161,7 @@ def dwconv(x, dw, want_pool):
 def se_gate(partial, nblk, se, hw):
     n = partial.shape[0]
     scale = torch.empty((n, se.c), dtype=torch.float32, device=partial.device)
-    if se.c >= 256 and SE_SPLIT:                                 # a function of the layer only: an image's gate never depends on its batch
+    if se.c >= SE_SPLIT_MIN_C and SE_SPLIT:                                 # a function of the layer only: an image's gate never depends on its batch
         hidden = torch.empty((n, se.s), dtype=torch.float32, device=partial.device)
         _lib.check(_lib.lib().ptocr_se_fc_split_f32(_ptr(partial), _ptr(se.w1t), _ptr(se.b1), _ptr(se.w2t), _ptr(se.b2), _ptr(hidden), _ptr(scale),
                                                     n, hw, se.c, se.s, nblk, _lib.cur_stream()), "ptocr_se_fc_split_f32")
