@@ -1683,7 +1683,8 @@ struct StageArgs {
     const float *maps; const Cand *cands; const int *totals; const Acc *acc; const unsigned *pool;
     Result *results; int *flags; const int *src_wh; F2 *hin; int *hn; float *mini;
     float box_thresh, unclip_ratio; int use_padding_resize;
-    int dbg_skip;      // timing experiments only (PTOCR_DBPOST_DBG_SKIP): phases of the full-size pass to leave out
+    int dbg_skip;      // timing experiments only (PTOCR_DBPOST_DBG_SKIP; results are wrong by design): bits 0-3 phases of the full-size pass,
+                       // 16 unclip without its rectangle, 32 no unclip, 64 unclip without hull + calipers, 128 unclip with the hull only
 };
 
 // ---- stage A kernel: one workgroup per border (12 KB of LDS: fits beside a Winograd workgroup of the next batch's forward)
