@@ -1688,9 +1688,7 @@ struct StageArgs {
 };
 
 // ---- stage A kernel: one workgroup per border (12 KB of LDS: fits beside a Winograd workgroup of the next batch's forward)
-__global__ __launch_bounds__(CT_THREADS, 6) void hull_kernel(StageArgs a, DbpostDims d) {
-    const int img = blockIdx.y, k = blockIdx.x;
-    if (k >= min(a.totals[img], MAX_CAND)) return;
+__device__ __forceinline__ void hull_body(const StageArgs &a, const DbpostDims &d, int img, int k) {
     const int tid = threadIdx.x;
     const long bi = (long)img * MAX_CAND + k;
     Result *res = &a.results[bi];
@@ -1716,9 +1714,7 @@ __global__ __launch_bounds__(CT_THREADS, 6) void hull_kernel(StageArgs a, Dbpost
 
 // ---- stage B kernel: one WAVE per border (3.7 KB of LDS, no other resource: thousands are resident at once, so the stage
 // lasts as long as ONE rectangle).  The rectangle is the reference's sequential float32 code, run by lane 0 on LDS arrays.
-__global__ __launch_bounds__(64) void rect_kernel(StageArgs a, DbpostDims d) {
-    const int img = blockIdx.y, k = blockIdx.x;
-    if (k >= min(a.totals[img], MAX_CAND)) return;
+__device__ __forceinline__ void rect_body(const StageArgs &a, const DbpostDims &d, int img, int k) {
     const long bi = (long)img * MAX_CAND + k;
     Result *res = &a.results[bi];
     if (res->status != ST_PEND_RECT) return;                    // uniform over the wave
@@ -1735,9 +1731,7 @@ __global__ __launch_bounds__(64) void rect_kernel(StageArgs a, DbpostDims d) {
 
 // ---- stage C kernel: BoxScore (db_postprocess.cpp:194-229), one workgroup per border (15.6 KB of LDS: mask planes of 63 488 px;
 // a larger mask goes through them in bands of rows)
-__global__ __launch_bounds__(CT_THREADS, 6) void score_kernel(StageArgs a, DbpostDims d) {
-    const int img = blockIdx.y, k = blockIdx.x;
-    if (k >= min(a.totals[img], MAX_CAND)) return;
+__device__ __forceinline__ void score_body(const StageArgs &a, const DbpostDims &d, int img, int k) {
     const int tid = threadIdx.x;
     const long bi = (long)img * MAX_CAND + k;
     Result *res = &a.results[bi];
@@ -1759,9 +1753,7 @@ __global__ __launch_bounds__(CT_THREADS, 6) void score_kernel(StageArgs a, Dbpos
 
 // ---- stage D kernel: one WAVE per border (3.5 KB of LDS): lane 0 offsets the mini-box (double-precision trigonometry), the
 // wave sorts the offset polygon by rank, lane 0 runs the second rectangle and the final box
-__global__ __launch_bounds__(64, 5) void unclip_kernel(StageArgs a, DbpostDims d) {
-    const int img = blockIdx.y, k = blockIdx.x;
-    if (k >= min(a.totals[img], MAX_CAND)) return;
+__device__ __forceinline__ void unclip_body(const StageArgs &a, const DbpostDims &d, int img, int k) {
     const long bi = (long)img * MAX_CAND + k;
     Result *res = &a.results[bi];
     if (res->status != ST_PEND_UNCLIP) return;                  // uniform over the wave
@@ -1799,6 +1791,23 @@ __global__ __launch_bounds__(64, 5) void unclip_kernel(StageArgs a, DbpostDims d
     else ub = min_area_rect_wave(pts, np, hull, stack, scratch, &sh_hn);
     if (threadIdx.x == 0) res->status = unclip_box(ub, res, a.src_wh[2 * img], a.src_wh[2 * img + 1], a.use_padding_resize, d);
 }
+
+// The stage kernels proper: STAGE_GRID workgroups per image, each walking candidates k, k + STAGE_GRID, ... -- a text-like map has ~150
+// candidates of the 1000 slots, and 32 000 workgroups that read one word and leave cost each stage ~7 us.
+constexpr int STAGE_GRID = 256;
+#define PT_STAGE_KERNEL(NAME, BODY, BOUNDS) \
+    __global__ BOUNDS void NAME(StageArgs a, DbpostDims d) { \
+        const int img = blockIdx.y, num = min(a.totals[img], MAX_CAND); \
+        for (int k = blockIdx.x; k < num; k += gridDim.x) { \
+            BODY(a, d, img, k); \
+            __syncthreads();                                     /* the body's LDS is reused by the next candidate */ \
+        } \
+    }
+PT_STAGE_KERNEL(hull_kernel, hull_body, __launch_bounds__(CT_THREADS, 6))
+PT_STAGE_KERNEL(rect_kernel, rect_body, __launch_bounds__(64))
+PT_STAGE_KERNEL(score_kernel, score_body, __launch_bounds__(CT_THREADS, 6))
+PT_STAGE_KERNEL(unclip_kernel, unclip_body, __launch_bounds__(64, 5))
+#undef PT_STAGE_KERNEL
 
 // ---- full-size pass: a few workgroups of 1024 threads per image walk the borders the small-footprint stages deferred (borders wider
 // than 1024 px, more than 96 hull / offset points: usually none; on noise maps the one giant component) through all four stages:
@@ -2079,10 +2088,10 @@ extern "C" int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, co
     a.results = h->results; a.flags = h->flags; a.src_wh = h->src_wh; a.hin = h->hin; a.hn = h->hn; a.mini = h->mini;
     a.box_thresh = box_thresh; a.unclip_ratio = unclip_ratio; a.use_padding_resize = use_padding_resize;
     a.dbg_skip = getenv("PTOCR_DBPOST_DBG_SKIP") ? atoi(getenv("PTOCR_DBPOST_DBG_SKIP")) : 0;
-    hipLaunchKernelGGL(hull_kernel, dim3(MAX_CAND, N), dim3(CT_THREADS), 0, s, a, d);
-    hipLaunchKernelGGL(rect_kernel, dim3(MAX_CAND, N), dim3(64), 0, s, a, d);
-    hipLaunchKernelGGL(score_kernel, dim3(MAX_CAND, N), dim3(CT_THREADS), 0, s, a, d);
-    hipLaunchKernelGGL(unclip_kernel, dim3(MAX_CAND, N), dim3(64), 0, s, a, d);
+    hipLaunchKernelGGL(hull_kernel, dim3(STAGE_GRID, N), dim3(CT_THREADS), 0, s, a, d);
+    hipLaunchKernelGGL(rect_kernel, dim3(STAGE_GRID, N), dim3(64), 0, s, a, d);
+    hipLaunchKernelGGL(score_kernel, dim3(STAGE_GRID, N), dim3(CT_THREADS), 0, s, a, d);
+    hipLaunchKernelGGL(unclip_kernel, dim3(STAGE_GRID, N), dim3(64), 0, s, a, d);
     hipLaunchKernelGGL(contour_big_kernel, dim3(64, N), dim3(BIG_THREADS), 0, s, a, d);
     hipLaunchKernelGGL(compact_kernel, dim3(N), dim3(1024), 0, s, h->results, h->totals, h->boxes, h->counts, max_boxes);
     if (int e = launch_ok("dbpost kernels")) return e;
