@@ -5,6 +5,7 @@
 hipcc cross-compiles without a GPU.  The .so is git-ignored but travels with the repo snapshot.
 """
 import glob
+import hashlib
 import os
 import subprocess
 import sys
@@ -23,9 +24,20 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def _flags_tag():
+    """Digest of the compile flags: an object built with other flags (a -D knock-out of tools/dbg) is stale."""
+    return hashlib.sha256(" ".join([HIPCC] + FLAGS).encode()).hexdigest()[:16]
+
+
 def _stale(obj, src):
     deps = [src] + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "ptocr_hip.h")]
-    return (not os.path.exists(obj)) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps)
+    if (not os.path.exists(obj)) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps):
+        return True
+    try:
+        with open(obj + ".flags") as f:
+            return f.read().strip() != _flags_tag()
+    except OSError:
+        return True
 
 
 def build(force=False, verbose=True):
@@ -43,6 +55,8 @@ def build(force=False, verbose=True):
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on " + src)
+        with open(os.path.join(objdir, os.path.basename(src) + ".o.flags"), "w") as f:
+            f.write(_flags_tag())
     if procs or not os.path.exists(LIB):
         cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:

@@ -78,9 +78,7 @@ class BaseModel(nn.Module):
             raise RuntimeError("pytorchocr_amd BaseModel.forward: input is on %s; the HIP path has no CPU fallback" % x.device)
         y = dict()
         if self._compute == "bf16":
-            if self.return_all_feats:
-                raise NotImplementedError("return_all_feats is an fp32-path option")
-            return self._bf16_runner().forward(x)
+            return self._bf16_runner().forward(x, want_feats=self.return_all_feats)
         if self.model_type == "det":
             feats = self.backbone.forward_from_nchw(x) if hasattr(self.backbone, "forward_from_nchw") \
                 else self.backbone.forward_nhwc(ops.nchw_to_nhwc(x, 4))

@@ -188,6 +188,7 @@ class Mbv3DbBf16:
         w, b = ops.fold_bn(c1.weight, c1.bias, bb.conv1[1])
         self.stem_w = _f(w.permute(1, 2, 3, 0).reshape(27, 16), dev)
         self.stem_b = _f(b, dev)
+        self.out_channels = list(bb.out_channels)
         self.stages = []
         for stage in bb.stages:
             blocks = []
@@ -219,8 +220,9 @@ class Mbv3DbBf16:
         self.t_b2 = float(hb[6].bias.detach().cpu()[0])
         self.c4 = c4
 
-    def forward(self, x):
-        """x f32[N,3,H,W] (H, W multiples of 32) on the device -> {"maps": f32[N,1,H,W]}"""
+    def forward(self, x, want_feats=False):
+        """x f32[N,3,H,W] (H, W multiples of 32) on the device -> {"maps": f32[N,1,H,W]}; with want_feats also the reference's
+        return_all_feats entries (base_model.py:56-73) as fp32 NCHW copies of the bf16 tensors"""
         x = x.contiguous().float()
         n, _, h, w_ = x.shape
         t = torch.empty((n, (h - 1) // 2 + 1, (w_ - 1) // 2 + 1, 16), dtype=torch.bfloat16, device=x.device)
@@ -255,4 +257,7 @@ class Mbv3DbBf16:
         _lib.check(_lib.lib().ptocr_db_head_tail_bf16(_ptr(hx), _ptr(self.t_w1), _ptr(self.t_b1), _ptr(self.t_w2), C.c_float(self.t_b2), _ptr(maps),
                                                       n, h4, w4, self.c4, hx.shape[3], _lib.cur_stream()), "ptocr_db_head_tail_bf16")
         _count(hx, maps)
+        if want_feats:
+            return {"backbone_out": [f.float().permute(0, 3, 1, 2)[:, :c].contiguous() for f, c in zip(feats, self.out_channels)],
+                    "neck_out": fuse.float().permute(0, 3, 1, 2)[:, :self.fuse_c].contiguous(), "maps": maps}
         return {"maps": maps}

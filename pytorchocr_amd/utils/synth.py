@@ -217,3 +217,47 @@ def synth_scene_images(n, h, w, seed=0):
     noise = (uniform01(n * h * w * 3, seed ^ 0xC0FFEE).reshape(n, h, w, 3) - np.float32(0.5)) * np.float32(8.0)
     img = maps[..., None] * np.float32(255.0) + noise
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def synth_scene_inputs(n, h, w, seed=0):
+    """synth_scene_images as the detector's input tensor f32[n,3,h,w]: BGR -> RGB, /255, ImageNet mean / std
+    (reference pytocr/data/imaug/operators.py:41-112), no resize."""
+    img = synth_scene_images(n, h, w, seed=seed)[..., ::-1].astype(np.float32) / np.float32(255.0)
+    mean = np.array([0.485, 0.456, 0.406], np.float32)
+    std = np.array([0.229, 0.224, 0.225], np.float32)
+    return np.ascontiguousarray(((img - mean) / std).astype(np.float32).transpose(0, 3, 1, 2))
+
+
+def synth_mbv3s_scene_state_dict(ref_shapes, readout, gain=14.0, level=0.45, seed=2022):
+    """A DBNet MobileNetV3-small checkpoint whose probability maps on synth_scene_inputs are TEXT-LIKE and cross both
+    post-process thresholds, with every backbone / neck layer carrying its random synth_state_dict weights (so reduced-precision
+    error of all those layers reaches the map, amplified by `gain`).  `readout` f32[9*C + 1] is a linear read-out of the 3x3
+    neighbourhood of the neck output (C = 96 channels, index c*9 + kh*3 + kw, last entry the intercept) fitted by
+    tools/gen_golden.py on the REFERENCE model's neck features to the scene's brightness (tests/golden/mbv3s_scene_readout.npz).
+    The head carries it: binarize.0 channel 0 = +readout, channel 1 = -readout (ReLU passes z as relu(z) - relu(-z)), BN bias
+    -+(intercept - level), both transposed convs replicate channels 0 / 1, the last one applies +-gain; the other 22 head channels
+    keep their random weights (a few 1e-2 of logit noise).  map ~ sigmoid(gain * (brightness_estimate - level))."""
+    out = synth_state_dict(ref_shapes, seed)
+    c = ref_shapes["head.binarize.0.weight"][0][1]
+    readout = np.asarray(readout, np.float32)
+    assert readout.shape == (9 * c + 1,)
+    wr = readout[:-1].reshape(c, 3, 3)
+    out["head.binarize.0.weight"][0] = wr
+    out["head.binarize.0.weight"][1] = -wr
+    for bn in ("head.binarize.1", "head.binarize.4"):
+        out[bn + ".weight"][:2] = 1.0
+        out[bn + ".running_var"][:2] = 1.0
+        out[bn + ".running_mean"][:2] = 0.0
+        out[bn + ".bias"][:2] = 0.0
+    out["head.binarize.1.bias"][0] = readout[-1] - np.float32(level)
+    out["head.binarize.1.bias"][1] = np.float32(level) - readout[-1]
+    w3 = out["head.binarize.3.weight"]                  # [Cin, Cout, 2, 2]
+    w3[:, :2] = 0.0
+    w3[:2, :] = 0.0
+    w3[0, 0] = 1.0
+    w3[1, 1] = 1.0
+    out["head.binarize.3.bias"][:2] = 0.0
+    out["head.binarize.6.weight"][0] = np.float32(gain)
+    out["head.binarize.6.weight"][1] = np.float32(-gain)
+    out["head.binarize.6.bias"][:] = 0.0
+    return out

@@ -1,11 +1,13 @@
 """bf16 inference path of the MobileNetV3 DB detector (BASELINE.json configs[3]) on the HIP engine (-m gpu).
 
 Tolerance.  north_star's 1e-4 is an fp32 statement; bf16 carries 8 significant bits (relative rounding 2^-9 per stored
-activation and weight), through ~45 layers.  What the bf16 path is held to, against the REFERENCE's own fp32 outputs
-(tests/golden) and the fp32 oracle:  max |p_bf16 - p_fp32| <= 3e-2 on the probability maps, mean <= 3e-3, and at most 0.5 % of the
-pixels on the other side of the 0.3 binarisation threshold (those are the pixels that can move a box vertex; the post-process
-itself is bit-exact on whatever map it is given).  The per-kernel tests compare each bf16 kernel with a float64 evaluation of the
-same bf16-rounded operands (tight: only the accumulation order and the output rounding differ)."""
+activation and weight), through ~45 layers.  The whole-network evidence is taken on the SCENE checkpoint (random backbone / neck,
+a fitted brightness read-out in the head with a logit gain of 14: text-like maps that cross thresh and box_thresh) against outputs of
+the REFERENCE model (tests/golden/det_mbv3s_scene_*.npz): feature and logit errors relative to their scale, map error relative to
+the map's range, threshold flips counted near the threshold, and the boxes of the bf16 maps scored against the boxes of the fp32 maps
+(SCENE_BOUNDS below; a test detunes single layers by 3 % and checks that the bounds notice).  The per-kernel tests compare each
+bf16 kernel with a float64 evaluation of the same bf16-rounded operands (tight: only the accumulation order and the output rounding
+differ)."""
 import os
 
 import numpy as np
@@ -160,8 +162,9 @@ def test_se_gate_kernels_match_float64():
             assert float((scale.cpu().double() - ref).abs().max()) <= 2e-5, (c, split)
 
 
-def test_bf16_maps_against_reference_golden_and_oracle(gold_dir, contract):
-    from oracle import model_oracle
+def test_fp32_and_bf16_maps_on_the_random_checkpoint(gold_dir, contract):
+    """the all-random synthetic checkpoint: its maps span only 0.45..0.51 (nothing near a threshold), so this is a smoke check of
+    the two paths against the reference golden, not the bf16 parity evidence -- that is the scene checkpoint below"""
     m, sd = _model(contract)
     g = np.load(os.path.join(gold_dir, "det_mbv3s_db_1x3x64x96.npz"))
     x = torch.from_numpy(synth_images(1, 3, 64, 96, seed=int(g["seed"]))).cuda()
@@ -170,34 +173,165 @@ def test_bf16_maps_against_reference_golden_and_oracle(gold_dir, contract):
         m.set_compute_dtype("bf16")
         p16 = m(x)["maps"].cpu().numpy()
     assert p16.dtype == np.float32 and p16.shape == g["maps"].shape
-    assert np.abs(p32 - g["maps"]).max() <= 1e-4                    # the fp32 path still meets its own bar
-    d = np.abs(p16 - g["maps"])
-    assert d.max() <= 3e-2 and d.mean() <= 3e-3, (d.max(), d.mean())
-    xs = synth_images(2, 3, 224, 320, seed=31)
+    assert np.abs(p32 - g["maps"]).max() <= 1e-4                    # the fp32 path meets the fp32 bar
+    rng = float(g["maps"].max() - g["maps"].min())
+    assert np.abs(p16 - g["maps"]).max() <= 0.1 * rng, (np.abs(p16 - g["maps"]).max(), rng)      # relative to what the map does
+
+
+# ---- configs[3] parity evidence: the scene checkpoint (utils/synth.py: synth_mbv3s_scene_state_dict).  Every backbone / neck layer
+# carries random weights, the head reads the scene's brightness out of the neck features and applies a gain of 14, so the maps
+# are text-like, cross 0.3 and 0.5, and the error of every bf16 layer reaches them amplified.  Golden = outputs of the
+# REFERENCE model (tools/gen_golden.py --mbv3s-scene-only).
+
+def _scene_model(contract, gold_dir):
+    from pytorchocr_amd.modeling.architectures import build_model
+    from pytorchocr_amd.utils.synth import synth_mbv3s_scene_state_dict
+    r = np.load(os.path.join(gold_dir, "mbv3s_scene_readout.npz"))
+    sd = synth_mbv3s_scene_state_dict(contract["det_mbv3s_db"], r["readout"], float(r["gain"]), float(r["level"]))
+    m = build_model(dict(MBV3S))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return m.to("cuda:0").eval(), sd
+
+
+def _rel_rms(a, b):
+    return float(np.sqrt(((a.astype(np.float64) - b) ** 2).mean()) / np.sqrt((b.astype(np.float64) ** 2).mean()))
+
+
+def _scene_metrics(m, g):
+    """bf16 forward of the golden's scene image against the reference's outputs"""
+    from pytorchocr_amd.utils.synth import synth_scene_inputs
+    x = torch.from_numpy(synth_scene_inputs(1, 224, 320, seed=int(g["seed"]))).cuda()
+    m.return_all_feats = True
+    try:
+        with torch.no_grad():
+            y = m(x)
+    finally:
+        m.return_all_feats = False
+    p = y["maps"].cpu().numpy().astype(np.float64)
+    ref, z_ref = g["maps"].astype(np.float64), g["logits"].astype(np.float64)
+    open_ = np.abs(z_ref) < 5.0                                  # pixels whose sigmoid is not saturated: the logit is recoverable from p
+    z = np.log(p[open_] / (1.0 - p[open_]))
+    band = np.abs(ref - 0.3) < 0.1
+    flipped = (p > 0.3) != (ref > 0.3)
+    return {
+        "neck_rel_rms": _rel_rms(y["neck_out"].cpu().numpy()[:, :, ::4, ::4], g["neck_sub"]),
+        "c2_rel_rms": _rel_rms(y["backbone_out"][0].cpu().numpy()[:, :, ::4, ::4], g["c2_sub"]),
+        "c5_rel_rms": _rel_rms(y["backbone_out"][3].cpu().numpy(), g["c5"]),
+        "logit_rms": float(np.sqrt(((z - z_ref[open_]) ** 2).mean())), "logit_max": float(np.abs(z - z_ref[open_]).max()),
+        "logit_span": float(z_ref.max() - z_ref.min()),
+        "map_max": float(np.abs(p - ref).max()), "map_mean": float(np.abs(p - ref).mean()), "map_range": float(ref.max() - ref.min()),
+        "flips_all": float(flipped.mean()), "flips_in_band": float(flipped[band].mean()), "band_share": float(band.mean()),
+        "flips_outside_band": int(flipped[~band].sum()),
+        "above_03": float((ref > 0.3).mean()), "above_05": float((ref > 0.5).mean()),
+    }
+
+
+# Stated tolerance of the bf16 path (8 significant bits per stored activation / weight, ~45 layers, logit gain 14); in brackets
+# what MI355X gave in round 3 (gpurun_out/r3_bf16.log -> DESIGN 3.5): relative RMS error of the features [neck 5.1e-3, C2 3.1e-3, C5 3.1e-3];
+# logit error over the unsaturated pixels as a share of the logit span of 19 [RMS 0.20 %, max 0.64 %]; map error of a map that spans
+# 0..1 [max 0.022, mean 7.8e-4]; pixels on the other side of thresh [0.035 % of all, 2.9 % of those within 0.1 of it, none outside].
+SCENE_BOUNDS = {"neck_rel_rms": 1e-2, "c2_rel_rms": 8e-3, "c5_rel_rms": 8e-3, "logit_rms_share": 4e-3, "logit_max_share": 1.5e-2,
+                "map_max": 5e-2, "map_mean": 2e-3, "flips_all": 1e-3, "flips_in_band": 6e-2}
+
+
+def _scene_violations(q):
+    v = []
+    for k in ("neck_rel_rms", "c2_rel_rms", "c5_rel_rms", "map_max", "map_mean", "flips_all", "flips_in_band"):
+        if q[k] > SCENE_BOUNDS[k]:
+            v.append((k, q[k]))
+    if q["logit_rms"] > SCENE_BOUNDS["logit_rms_share"] * q["logit_span"]:
+        v.append(("logit_rms", q["logit_rms"]))
+    if q["logit_max"] > SCENE_BOUNDS["logit_max_share"] * q["logit_span"]:
+        v.append(("logit_max", q["logit_max"]))
+    if q["flips_outside_band"]:
+        v.append(("flips_outside_band", q["flips_outside_band"]))
+    return v
+
+
+def test_bf16_scene_checkpoint_against_the_reference_golden(gold_dir, contract):
+    from pytorchocr_amd.utils.synth import synth_scene_inputs
+    m, sd = _scene_model(contract, gold_dir)
+    g = np.load(os.path.join(gold_dir, "det_mbv3s_scene_1x3x224x320.npz"))
+    x = torch.from_numpy(synth_scene_inputs(1, 224, 320, seed=int(g["seed"]))).cuda()
     with torch.no_grad():
-        p16 = m(torch.from_numpy(xs).cuda())["maps"].cpu().numpy()
-    ref = model_oracle.dbnet_forward(sd, torch.from_numpy(xs))["maps"].numpy()
-    d = np.abs(p16 - ref)
-    flips = ((p16 > 0.3) != (ref > 0.3)).mean()
-    assert d.max() <= 3e-2 and d.mean() <= 3e-3 and flips <= 5e-3, (d.max(), d.mean(), flips)
-    m.set_compute_dtype("f32")
+        p32 = m(x)["maps"].cpu().numpy()
+    assert np.abs(p32 - g["maps"]).max() <= 1e-4                    # fp32 HIP path vs the reference's own output, gain 14 included
+    m.set_compute_dtype("bf16")
+    q = _scene_metrics(m, g)
+    print("bf16 scene metrics:", q)
+    # the test means something only on a map that lives on both sides of the thresholds
+    assert 0.2 <= q["above_03"] <= 0.8 and 0.2 <= q["above_05"] <= 0.8 and q["map_range"] > 0.99 and q["band_share"] > 0.01, q
+    assert not _scene_violations(q), (_scene_violations(q), q)
+
+
+def test_bf16_scene_bounds_catch_a_detuned_layer(gold_dir, contract):
+    """the bounds above are not vacuous: one layer whose packed bf16 weights carry a 3 % error (about what dropping two mantissa bits
+    of one kernel's operands would do) breaks them -- for a backbone layer, a lateral and a smoothing conv in turn"""
+    m, sd = _scene_model(contract, gold_dir)
+    g = np.load(os.path.join(gold_dir, "det_mbv3s_scene_1x3x224x320.npz"))
+    m.set_compute_dtype("bf16")
+    assert not _scene_violations(_scene_metrics(m, g))
+    r = m._bf16_runner()
+    for name, holder in (("stage1 expand", r.stages[1][0]["ex"]), ("lateral in3", r.lat["in3"]), ("smooth out2", r.smooth["out2"])):
+        keep = holder.w.clone()
+        holder.w.copy_((keep.float() * 1.03).to(torch.bfloat16))
+        v = _scene_violations(_scene_metrics(m, g))
+        holder.w.copy_(keep)
+        assert v, "a 3 %% weight error in %s went unnoticed" % name
+    assert not _scene_violations(_scene_metrics(m, g))
+
+
+def _boxes(post, maps, h, w):
+    return post({"maps": maps}, np.array([[h, w, 1.0, 1.0]] * maps.shape[0]))
+
+
+def test_bf16_boxes_against_fp32_boxes_on_scene_images(gold_dir, contract):
+    """736x1280 (configs[3] geometry), 4 scene images (~140 text bars each): boxes of the bf16 maps scored against the boxes of the
+    fp32 maps with the reference's ICDAR IoU protocol (metrics/DetMetric, IoU >= 0.5), and vertex by vertex"""
+    from pytorchocr_amd.metrics import DetMetric
+    from pytorchocr_amd.postprocess import build_post_process
+    from pytorchocr_amd.utils.synth import synth_scene_inputs
+    m, sd = _scene_model(contract, gold_dir)
+    post = build_post_process(dict(name="DBPostProcess", thresh=0.3, box_thresh=0.5, unclip_ratio=1.7, cpp_speedup=True), {})
+    n, h, w = 4, 736, 1280
+    x = torch.from_numpy(synth_scene_inputs(n, h, w, seed=40)).cuda()
     with torch.no_grad():
-        assert np.abs(m(torch.from_numpy(xs).cuda())["maps"].cpu().numpy() - ref).max() <= 1e-4
+        p32 = m(x)["maps"]
+        b32 = _boxes(post, p32, h, w)
+        m.set_compute_dtype("bf16")
+        p16 = m(x)["maps"]
+        b16 = _boxes(post, p16, h, w)
+    d = (p16 - p32).abs()
+    flips = ((p16 > 0.3) != (p32 > 0.3)).float().mean().item()
+    assert d.max().item() <= 8e-2 and d.mean().item() <= 2e-3 and flips <= 3e-3, (d.max().item(), d.mean().item(), flips)
+    k32, k16 = [len(b["points"]) for b in b32], [len(b["points"]) for b in b16]
+    assert min(k32) >= 100, k32
+    metric = DetMetric()
+    metric(b16, [None, None, [list(b["points"].astype(np.float64)) for b in b32], [[False] * k for k in k32]])
+    res = metric.get_metric()
+    shifts, same = [], 0
+    for a, b in zip(b32, b16):                                     # nearest fp32 box of every bf16 box, by centre
+        ca, cb = a["points"].astype(np.float64).mean(1), b["points"].astype(np.float64).mean(1)
+        j = np.abs(cb[:, None, :] - ca[None, :, :]).sum(2).argmin(1)
+        dv = np.abs(b["points"].astype(np.int32) - a["points"].astype(np.int32)[j]).reshape(len(cb), -1).max(1)
+        shifts.append(dv)
+        same += int((dv == 0).sum())
+    shifts = np.concatenate(shifts)
+    print("bf16 vs fp32 boxes: counts %s / %s, hmean %.4f, identical %d of %d, vertex shift p50 %d p99 %d max %d" %
+          (k16, k32, res["hmean"], same, len(shifts), np.percentile(shifts, 50), np.percentile(shifts, 99), shifts.max()))
+    assert res["hmean"] >= 0.98 and res["precision"] >= 0.98 and res["recall"] >= 0.98, res
+    assert abs(sum(k16) - sum(k32)) <= 0.02 * sum(k32)
+    assert np.percentile(shifts, 90) <= 2, np.percentile(shifts, [50, 90, 99])
 
 
 def test_bf16_config3_size_properties(contract):
-    """736x1280 (BASELINE configs[3] geometry): one image against the fp32 oracle, then batch 32 against itself -- the maps of an
-    image do not depend on the batch it travels in, and two runs give the same bits"""
-    from oracle import model_oracle
+    """736x1280 (BASELINE configs[3] geometry), batch 32: the maps of an image do not depend on the batch it travels in, and two runs
+    give the same bits"""
     m, sd = _model(contract)
     m.set_compute_dtype("bf16")
     base = synth_images(2, 3, 736, 1280, seed=9)
     with torch.no_grad():
         one = m(torch.from_numpy(base[:1]).cuda())["maps"]
-        ref = model_oracle.dbnet_forward(sd, torch.from_numpy(base[:1]))["maps"].numpy()
-        d = np.abs(one.cpu().numpy() - ref)
-        flips = ((one.cpu().numpy() > 0.3) != (ref > 0.3)).mean()
-        assert d.max() <= 3e-2 and d.mean() <= 3e-3 and flips <= 5e-3, (d.max(), d.mean(), flips)
         xb = torch.from_numpy(base).cuda().repeat(16, 1, 1, 1)
         a = m(xb)["maps"]
         b = m(xb)["maps"]
