@@ -12,7 +12,9 @@ the RCCL broadcast of the weights from rank 0 before the timed region.  Rank 0 p
 
 The second half of BASELINE.json's metric (CRNN text-lines/sec, configs[2]: batch 512 of 32x320 crops) is timed in the same
 run with the same K / W and travels in the same line under "crnn" (--workload crnn prints it as the top-level line instead;
---workload ocr times configs[4], the run_ocr pipeline).
+--workload ocr times configs[4], the run_ocr pipeline).  The default line also carries "mbv3s_bf16" (configs[3]: the bf16
+MobileNetV3-small detector, 32 images per GPU) and "ocr" (configs[4], a few steps of the 64-image run_ocr batch), each with its
+own roofline and cpu_baseline, so that the driver's one run times every BASELINE config that fits the box.
 
 `value` is wall clock over exactly K steps (barrier + synchronize on both sides, max over ranks); `ms_per_step_median` is the
 median over the K steps of HIP-event step times on the launch stream.
@@ -176,6 +178,90 @@ def crnn_cpu_baseline(n_lines):
                       % (done, dt / done * 1e3)}
 
 
+def parallelism(what, world):
+    """config.parallelism: how the work is split, the torch.distributed backend actually in use and its world size"""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        be = "%s (%s), dist world %d" % (dist.get_backend(), "RCCL over xGMI" if dist.get_backend() == "nccl" else "rehearsal backend",
+                                         dist.get_world_size())
+    else:
+        be = "single process, no process group"
+    return "%s x%d; %s; weight broadcast from rank 0 is the only collective" % (what, world, be)
+
+
+def mbv3s_cpu_baseline(n_img, H, W):
+    """configs[3] beside the CPU: the oracle's MobileNetV3-small DB forward in fp32 (the reference has no reduced-precision mode) +
+    the C post-process, batch 1 per image like infer_det.py"""
+    import torch
+    from oracle import dbpost, model_oracle
+    from pytorchocr_amd.utils.synth import synth_images, synth_prob_maps, synth_state_dict
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    sd = {k: torch.from_numpy(v) for k, v in synth_state_dict(load_contract("det_mbv3s_db")).items()}
+    x = torch.from_numpy(synth_images(1, 3, H, W, seed=2022))
+    stress = synth_prob_maps(1, H, W, seed=2022)[0]
+    model_oracle.dbnet_forward(sd, x[:, :, :64, :64])
+    t_model = t_post = 0.0
+    for _ in range(n_img):
+        t0 = time.perf_counter()
+        maps = model_oracle.dbnet_forward(sd, x)["maps"].numpy()
+        t1 = time.perf_counter()
+        for m in (maps[0, 0], stress):
+            dbpost.boxes_from_bitmap(m, dbpost.binarize(m, 0.3), 0.5, 1.7, W, H)
+        t2 = time.perf_counter()
+        t_model += t1 - t0
+        t_post += (t2 - t1) / 2
+    total = t_model + t_post
+    return {"value": round(n_img / total, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d images %dx%d, batch 1 each: torch-CPU fp32 MobileNetV3-small DB forward %.3f s/img + C post-process %.4f s/img "
+                      "(single thread)" % (n_img, H, W, t_model / n_img, t_post / n_img)}
+
+
+def ocr_cpu_baseline(n_img):
+    """configs[4] beside the CPU, image by image and box by box as run_ocr.py:167-231 does: host resize + normalise, the oracle's
+    DBNet++ r18 forward, the C post-process, sort_boxes, per box perspective crop -> gray -> resize/pad -> batch-1 CRNN forward ->
+    CTC decode.  (Resize and crops use the product's vectorised HOST operators -- the reference's are OpenCV calls; the oracle's
+    per-pixel Python restatements of them are checkers, far too slow to stand for a CPU path.)"""
+    import numpy as np
+    import torch
+    from oracle import ctc_oracle, dbpost, model_oracle
+    from pytorchocr_amd.data.imaug import bgr_to_gray, resize_bilinear
+    from pytorchocr_amd.utils.synth import synth_brightness_detector_state_dict, synth_scene_images, synth_state_dict
+    from pytorchocr_amd.utils.utility import sort_boxes
+    from pytorchocr_amd.utils.warp import get_part_img
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    det_sd = {k: torch.from_numpy(v) for k, v in synth_brightness_detector_state_dict(load_contract("detpp_r18_db"), use_asf=True).items()}
+    rec_sd = {k: torch.from_numpy(v) for k, v in synth_state_dict(load_contract("rec_vgg_bilstm_ctc")).items()}
+    chars = ctc_oracle.load_characters(os.path.join(ROOT, "pytorchocr_amd", "utils", "char_dict_6623.txt"))
+    imgs = synth_scene_images(n_img, 960, 1280, seed=100)
+    mean, std = np.array([0.485, 0.456, 0.406], np.float32), np.array([0.229, 0.224, 0.225], np.float32)
+    model_oracle.crnn_forward(rec_sd, torch.zeros(1, 1, 32, 320))
+    lines = 0
+    t0 = time.perf_counter()
+    for img in imgs:
+        rs = resize_bilinear(img[:, :, ::-1], (992, 736)).astype(np.float32) / 255.0
+        x = torch.from_numpy(np.ascontiguousarray(((rs - mean) / std).transpose(2, 0, 1)[None], np.float32))
+        pm = model_oracle.dbnet_r18_forward(det_sd, x)["maps"].numpy()[0, 0]
+        boxes = dbpost.boxes_from_bitmap(pm, dbpost.binarize(pm, 0.3), 0.5, 1.7, 1280, 960)
+        boxes = sort_boxes(boxes.astype(np.int16)) if len(boxes) else []
+        for box in boxes:
+            part = get_part_img(img, np.asarray(box))
+            if part.shape[0] < 2 or part.shape[1] < 2:
+                continue
+            if part.shape[0] >= 1.5 * part.shape[1]:
+                part = np.rot90(part, 1)
+            g = bgr_to_gray(np.ascontiguousarray(part))
+            rw = min(320, int(np.ceil(32 * g.shape[1] / float(g.shape[0]))))
+            r = resize_bilinear(g, (max(rw, 1), 32)).astype(np.float32) / 255.0
+            pad = np.zeros((1, 1, 32, 320), np.float32)
+            pad[0, 0, :, :r.shape[1]] = (r - 0.5) / 0.5
+            ctc_oracle.ctc_label_decode(model_oracle.crnn_forward(rec_sd, torch.from_numpy(pad)).numpy(), chars)
+            lines += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(n_img / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d source images 1280x960 (%d text lines), image by image, batch-1 CRNN per box as run_ocr.py:187-229: torch-CPU fp32 "
+                      "DB++ r18 + C post-process + host crops + torch-CPU CRNN + CTC decode, %.2f s/img" % (n_img, lines, dt / max(n_img, 1))}
+
+
 def _sync_all(world):
     import torch
     torch.cuda.synchronize()
@@ -235,10 +321,22 @@ def _wino_roofline(wino_ms, wino_flops, n_wino, steps, what):
     n4 = wino_flops["n4"]
     return {"bound": "mfma", "achieved": round(ex, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ex / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "traffic_source": "profiles/conv_traffic.json / crnn_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                              "(2 * FETCH_SIZE + WRITE_SIZE per launch); copied from the committed profile, NOT measured in this run",
             "kernel": "conv_wino4_kernel F(4x4,3x3) + conv_wino_kernel F(2x2,3x3) (%s; %d + %d launches per step, %.3f ms avg launch, HIP "
                       "events on the launch stream); achieved = executed MFMA FLOPs (direct-convolution FLOPs / 4 resp. / 2.25) of "
                       "those launches / their time" % (what, n4 // max(steps, 1), (n_wino - n4) // max(steps, 1), wino_ms / max(n_wino, 1)),
             "algorithmic_tflops": round(alg, 2), "algorithmic_over_peak": round(alg / PEAK_F32_MFMA_TFLOPS, 4)}
+
+
+def _ocr_roofline(prof, labels, steps):
+    """run_ocr's dominant kernel is the same Winograd kernel (DB++ r18 and the CRNN's VGG stack): executed MFMA FLOPs of its launches
+    over their HIP-event durations, like the det line"""
+    conv_ms, n_launch, wino_ms, wino_flops, n_wino = _conv_profile(prof, labels)
+    roof = _wino_roofline(wino_ms, wino_flops, n_wino, steps, "3x3/s1 layers of DBNet++ r18 and of the CRNN's VGG stack")
+    roof["traffic"], roof["traffic_source"] = None, None
+    roof["all_conv"] = {"launches_per_step": n_launch // max(steps, 1), "ms_per_step": round(conv_ms / max(steps, 1), 3)}
+    return roof
 
 
 def run_det(args, rank, local, world, device):
@@ -351,18 +449,26 @@ def run_det(args, rank, local, world, device):
             "bound": "hbm", "achieved": round(post_bytes / (best * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
             "frac": round(post_bytes / (best * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
             "traffic": (_profile_json("post_traffic.json") or {}).get("hbm_bytes_per_call"),
+            "traffic_source": "profiles/post_traffic.json (rocprofv3 --pmc passes of tools/bench_post.py; per_kernel too): copied from the "
+                              "committed profile, NOT measured in this run",
             "stage": "DB post-process of %d maps %dx%d (%s maps): %d B/pixel accounting (SURVEY 8d) = %.1f MB per call / median device "
                      "time of the call's kernels alone on the chip (HIP events on its stream)" % (B, H, W, pk, POST_BYTES_PER_PIXEL, post_bytes / 1e6),
             "ms_per_call_alone": round(ms_alone, 4) if ms_alone else None,
             "ms_per_call_overlapped": {t: round(median(v), 4) for t, v in by_tag.items()},
             "per_kernel": (_profile_json("post_traffic.json") or {}).get("per_kernel"),
         }
-    cpu = det_cpu_baseline(args.cpu_images, H, W) if world == 1 and args.cpu_images > 0 and not bf16 else None
+    # rank 0 only, after the timed region (the other ranks wait at the next barrier); with several ranks on the host the sample is halved
+    n_cpu = args.cpu_images if world == 1 else max(1, args.cpu_images // 2)
+    cpu = None
+    if args.cpu_images > 0:
+        cpu = mbv3s_cpu_baseline(n_cpu, H, W) if args.det_model == "mbv3s" else (det_cpu_baseline(n_cpu, H, W) if args.det_model == "r18" else None)
     if bf16:
         fms = median([a.elapsed_time(b) for a, b in fwd_events])
         gbps = fwd_bytes / (fms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
                 "traffic": (_profile_json("mbv3s_bf16_traffic.json") or {}).get("hbm_bytes_per_forward"),
+                "traffic_source": "profiles/mbv3s_bf16_traffic.json (rocprofv3 --pmc passes of this command with --det-model mbv3s --dtype bf16): "
+                                  "copied from the committed profile, NOT measured in this run",
                 "kernel": "whole bf16 forward (47 launches: stem, 1x1 MFMA convs, depthwise + SE pool, SE gate, 3x3 MFMA convs, head tail): "
                           "bytes every launch reads + writes once (activations, weights; %.1f MB per forward of %d images) / median forward time "
                           "%.3f ms (HIP events on the launch stream, post-process of the previous batch overlapping)" % (fwd_bytes / 1e6, B, fms),
@@ -385,7 +491,7 @@ def run_det(args, rank, local, world, device):
                                                        "configs[3]: batch 256 = 32 per GPU x 8" if bf16 else "configs[1]"),
                    "global_batch": world * B, "post_input": args.post_input, "post_overlap": bool(args.overlap),
                    "boxes_per_image": {t: round(v / (B * args.steps), 1) for t, v in nbox.items()},
-                   "parallelism": "image-sharded x%d, RCCL weight broadcast only" % world},
+                   "parallelism": parallelism("image-sharded", world)},
         "roofline": roof, "roofline_post": roofline_post, "cpu_baseline": cpu,
     }
 
@@ -457,9 +563,9 @@ def run_crnn(args, rank, local, world, device):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "CRNN vgg_v1_x1.0 + CTC greedy, batch %d synthetic 32x320 gray crops per GPU (BASELINE.json configs[2])" % B,
                    "global_batch": world * B, "decode_overlap": bool(args.overlap), "chars_per_line": round(nchar / (B * args.steps), 1),
-                   "parallelism": "line-sharded x%d" % world},
+                   "parallelism": parallelism("line-sharded", world)},
         "roofline": roof,
-        "cpu_baseline": crnn_cpu_baseline(args.cpu_lines) if world == 1 and args.cpu_lines > 0 else None,
+        "cpu_baseline": crnn_cpu_baseline(args.cpu_lines if world == 1 else max(16, args.cpu_lines // 2)) if args.cpu_lines > 0 else None,
     }
 
 
@@ -512,6 +618,8 @@ def main():
                     help="bf16 = BASELINE configs[3] (with --det-model mbv3s): bf16 activations and weights, fp32 accumulation, fp32 maps")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false",
                     help="run the post-process synchronously after each forward instead of overlapping it with the next batch")
+    ap.add_argument("--no-embed", dest="embed", action="store_false",
+                    help="leave the configs[3] (mbv3s_bf16) and configs[4] (ocr) sub-lines out of the default det line")
     ap.add_argument("--cpu-images", type=int, default=8, help="images in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-lines", type=int, default=256, help="text lines in the CRNN CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
@@ -557,11 +665,29 @@ def main():
             crnn = run_crnn(a2, rank, local, world, device)
             if rank == 0:
                 line["crnn"] = crnn
+        if args.embed and args.det_model == "r18" and args.dtype == "f32":
+            import copy
+            a3 = copy.copy(args)                                     # BASELINE configs[3]: bf16 MobileNetV3-small detector, 32 images per GPU
+            a3.det_model, a3.dtype, a3.warmup, a3.cpu_images = "mbv3s", "bf16", min(args.warmup, 10), min(args.cpu_images, 4)
+            torch.cuda.empty_cache()
+            sub = run_det(a3, rank, local, world, device)
+            if rank == 0:
+                line["mbv3s_bf16"] = sub
+            a4 = copy.copy(args)                                     # BASELINE configs[4]: run_ocr over 64 source images, a few steps
+            a4.batch, a4.steps, a4.warmup = 0, max(2, min(5, args.steps)), 2
+            torch.cuda.empty_cache()
+            from pytorchocr_amd.deploy.bench_ocr import run_ocr_bench
+            sub = run_ocr_bench(a4, rank, local, world, device, roofline_fn=_ocr_roofline,
+                                cpu_fn=(lambda: ocr_cpu_baseline(1)) if args.cpu_images > 0 else None, parallelism_fn=parallelism)
+            if rank == 0:
+                line["ocr"] = sub
     elif args.workload == "crnn":
         line = run_crnn(args, rank, local, world, device)
     else:
         from pytorchocr_amd.deploy.bench_ocr import run_ocr_bench
-        line = run_ocr_bench(args, rank, local, world, device)
+        line = run_ocr_bench(args, rank, local, world, device, roofline_fn=_ocr_roofline,
+                             cpu_fn=(lambda: ocr_cpu_baseline(max(1, min(2, args.cpu_images)))) if args.cpu_images > 0 else None,
+                             parallelism_fn=parallelism)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

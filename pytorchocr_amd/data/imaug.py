@@ -2,13 +2,32 @@
 (`DecodeImage` :14-38, `ToTensor` :41-72, `Normalize` :75-112, `KeepKeys` :115-124, `DetResizeForTest` :155-252) and
 rec_img_aug.py (`ClsResizeImg` :29-37, `RecResizeImg` :40-53, `resize_norm_img` :108-134).
 
-cv2 is not a dependency here: `resize_bilinear` restates cv2.resize(INTER_LINEAR) for uint8 images in its
-fixed-point form (11-bit coefficients, half-pixel centres).  UNPINNED against OpenCV (absent from the image).
+cv2 is not a dependency here: `resize_bilinear` / `bgr_to_gray` restate cv2.resize(INTER_LINEAR) and cv2.cvtColor(BGR2GRAY) for uint8
+images in OpenCV's own fixed-point arithmetic (resize.cpp: 11-bit coefficient tables, `HResizeLinear`, the truncating u8
+`VResizeLinear`, the 2x2 area re-route; color_rgb: 14-bit B2Y / G2Y / R2Y of the pinned opencv-python 4.1.2.30).  Held bit-exact to
+oracle/cv2_oracle.py by tests/test_oracle_cv2.py; UNPINNED against OpenCV itself (absent from the image).
 """
 import math
 
 import numpy as np
 import torch
+
+
+def _resize_tables(dn, sn, clamp):
+    """resize.cpp: per destination index the source offset and the two 11-bit coefficients; x offsets are clamped with the fraction
+    zeroed, y offsets are not (the rows are clipped when they are fetched)"""
+    scale = 1.0 / (float(dn) / float(sn))                                                # hal::resize: scale = 1. / inv_scale
+    f = ((np.arange(dn, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)       # fx = (float)((dx + 0.5) * scale_x - 0.5)
+    s0 = np.floor(f).astype(np.int64)
+    fr = (f - s0.astype(np.float32)).astype(np.float32)
+    if clamp:
+        lo = s0 < 0
+        fr[lo] = 0
+        s0[lo] = 0
+        hi = s0 >= sn - 1
+        fr[hi] = 0
+        s0[hi] = sn - 1
+    return s0, fr
 
 
 def resize_bilinear(img, dsize):
@@ -18,35 +37,25 @@ def resize_bilinear(img, dsize):
     sh, sw = src.shape[:2]
     if (sh, sw) == (dh, dw):
         return src.copy()
-
-    def coeffs(dn, sn):
-        scale = sn / float(dn)
-        f = ((np.arange(dn, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)    # cv2: fx = (float)((dx+0.5)*scale_x - 0.5)
-        s0 = np.floor(f).astype(np.int64)
-        fr = (f - s0.astype(np.float32)).astype(np.float32)
-        lo = s0 < 0
-        fr[lo] = 0
-        s0[lo] = 0
-        hi = s0 >= sn - 1
-        fr[hi] = 0
-        s0[hi] = sn - 1
-        s1 = np.minimum(s0 + 1, sn - 1)
-        return s0, s1, fr
-
-    x0, x1, fx = coeffs(dw, sw)
-    y0, y1, fy = coeffs(dh, sh)
+    x0, fx = _resize_tables(dw, sw, True)
+    x1 = np.minimum(x0 + 1, sw - 1)
+    ys, fy = _resize_tables(dh, sh, False)
+    y0, y1 = np.clip(ys, 0, sh - 1), np.clip(ys + 1, 0, sh - 1)
     if src.dtype == np.uint8:
-        ONE = 2048
-        ax1 = np.rint(fx * np.float32(ONE)).astype(np.int64)           # saturate_cast<short>(fx * INTER_RESIZE_COEF_SCALE)
-        ax0 = ONE - ax1
-        by1 = np.rint(fy * np.float32(ONE)).astype(np.int64)
-        by0 = ONE - by1
         s = src.astype(np.int64)
+        if sw == 2 * dw and sh == 2 * dh:              # exact 2x2 down-scale: OpenCV runs INTER_LINEAR as INTER_AREA (fast)
+            return ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+        ONE = np.float32(2048)
+        ax0 = np.clip(np.rint((np.float32(1) - fx) * ONE), -32768, 32767).astype(np.int64)   # saturate_cast<short>((1.f - fx) * 2048)
+        ax1 = np.clip(np.rint(fx * ONE), -32768, 32767).astype(np.int64)
+        by0 = np.clip(np.rint((np.float32(1) - fy) * ONE), -32768, 32767).astype(np.int64)
+        by1 = np.clip(np.rint(fy * ONE), -32768, 32767).astype(np.int64)
         shp = (1, dw) + (1,) * (s.ndim - 2)
-        rows = s[:, x0] * ax0.reshape(shp) + s[:, x1] * ax1.reshape(shp)            # horizontal pass, scale 2^11
+        rows = s[:, x0] * ax0.reshape(shp) + s[:, x1] * ax1.reshape(shp)                # HResizeLinear, scale 2^11
         shp = (dh, 1) + (1,) * (s.ndim - 2)
-        out = (rows[y0] * by0.reshape(shp) + rows[y1] * by1.reshape(shp) + (1 << 21)) >> 22
-        return np.clip(out, 0, 255).astype(np.uint8)
+        # VResizeLinear<uchar, ...>: two truncating 16-bit products, then (+ 2) >> 2
+        out = (((by0.reshape(shp) * (rows[y0] >> 4)) >> 16) + ((by1.reshape(shp) * (rows[y1] >> 4)) >> 16) + 2) >> 2
+        return (out & 255).astype(np.uint8)
     s = src.astype(np.float32)
     shp = (1, dw) + (1,) * (s.ndim - 2)
     rows = s[:, x0] * (1 - fx).reshape(shp) + s[:, x1] * fx.reshape(shp)
@@ -55,9 +64,9 @@ def resize_bilinear(img, dsize):
 
 
 def bgr_to_gray(img):
-    """cv2.cvtColor(img, COLOR_BGR2GRAY) for uint8: fixed-point 0.114 B + 0.587 G + 0.299 R (15-bit coefficients)."""
+    """cv2.cvtColor(img, COLOR_BGR2GRAY) for uint8: CV_DESCALE(B * 1868 + G * 9617 + R * 4899, 14) (opencv-python 4.1.2.30)."""
     b, g, r = (img[..., i].astype(np.int64) for i in range(3))
-    return ((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15).astype(np.uint8)
+    return ((b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14).astype(np.uint8)
 
 
 class DecodeImage(object):

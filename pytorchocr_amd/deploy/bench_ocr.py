@@ -37,7 +37,10 @@ def make_ocrer(device_index, rank=0, world=1):
     return ocr
 
 
-def run_ocr_bench(args, rank, local, world, device):
+def run_ocr_bench(args, rank, local, world, device, roofline_fn=None, cpu_fn=None, parallelism_fn=None):
+    """roofline_fn(prof, labels, steps) -> the line's roofline from the HIP-event durations of the conv launches of the timed region
+    (bench.py's accounting: executed MFMA FLOPs per launch); cpu_fn() -> the cpu_baseline object (rank 0, after the timed region)"""
+    from ..modeling import ops
     from ..parallel import shard_range
     from ..utils.synth import synth_scene_images
     total = args.batch or 64
@@ -56,6 +59,8 @@ def run_ocr_bench(args, rank, local, world, device):
         dist.barrier()
         torch.cuda.synchronize()
     step_ms = []
+    ops.PROFILE = [] if rank == 0 and roofline_fn is not None else None
+    ops.PROFILE_LABELS = [] if rank == 0 and roofline_fn is not None else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         t1 = time.perf_counter()
@@ -66,6 +71,8 @@ def run_ocr_bench(args, rank, local, world, device):
         dist.barrier()
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    prof, labels = ops.PROFILE, ops.PROFILE_LABELS
+    ops.PROFILE = ops.PROFILE_LABELS = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -84,13 +91,8 @@ def run_ocr_bench(args, rank, local, world, device):
                                "perspective crops -> CRNN in 512-line chunks -> CTC decode; %d images total (BASELINE.json configs[4])" % total,
                    "global_batch": total, "images_per_gpu": n_local, "boxes_per_image": round(boxes_img, 1),
                    "lines_per_sec": round(stats.get("lines", 0) * world / dt, 1),
-                   "parallelism": "image-sharded x%d, RCCL weight broadcast only" % world},
-        "roofline": {"bound": "mfma", "achieved": round((101.98 * n_local + 4.98 * stats.get("lines", 0) / max(args.steps, 1)) * 1e9 * args.steps
-                                                       / dt / 1e12 / 2.25, 2),
-                     "peak": 157.3, "unit": "TFLOP/s",
-                     "frac": round((101.98 * n_local + 4.98 * stats.get("lines", 0) / max(args.steps, 1)) * 1e9 * args.steps / dt / 1e12 / 2.25 / 157.3, 4),
-                     "traffic": None,
-                     "kernel": "whole pipeline: algorithmic FLOPs (101.98 GFLOP/image DB++ @736x992 + 4.98 GFLOP/line CRNN, SURVEY 8d) / 2.25 "
-                               "(lower bound of the executed MFMA rate: 85 % of the FLOPs run as Winograd) / wall time, host stages included"},
-        "cpu_baseline": None,
+                   "parallelism": parallelism_fn("image-sharded", world) if parallelism_fn else "image-sharded x%d" % world},
+        "roofline": roofline_fn(prof, labels, args.steps) if roofline_fn is not None else None,
+        "whole_pipeline_algorithmic_tflops": round((101.98 * n_local * args.steps + 4.98 * stats.get("lines", 0)) * 1e9 / dt / 1e12, 2),
+        "cpu_baseline": cpu_fn() if cpu_fn is not None else None,
     }
