@@ -7,11 +7,11 @@ import numpy as np, torch
 from pytorchocr_amd.postprocess import build_post_process
 from pytorchocr_amd.utils.synth import synth_prob_maps
 
-B, H, W = 32, 736, 1280
+B, H, W = (int(sys.argv[2]) if len(sys.argv) > 2 else 32), 736, 1280
 dev = torch.device("cuda:0")
 post = build_post_process(dict(name="DBPostProcess", thresh=0.3, box_thresh=0.5, max_candidates=1000, unclip_ratio=1.7,
                                score_mode="poly", cpp_speedup=True, out_polygon=False), dict(use_gpu=True))
-maps = torch.from_numpy(synth_prob_maps(4, H, W, seed=7)).to(dev).repeat(B // 4, 1, 1)[:, None].contiguous()
+maps = torch.from_numpy(synth_prob_maps(min(4, B), H, W, seed=7)).to(dev).repeat(max(B // 4, 1), 1, 1)[:B, None].contiguous()
 shape_list = np.array([[H, W, 1.0, 1.0]] * B)
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 for _ in range(2):
