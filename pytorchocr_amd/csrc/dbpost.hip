@@ -1792,7 +1792,11 @@ __device__ void score_mask(const unsigned *st, int n, int xmin, int ymin, int bw
         const int rows = min(R, bh - r0);
         for (int i = tid; i < rows * pw; i += nt) { border[i] = 0; toggle[i] = 0; }
         __syncthreads();
-        for (int i = tid; i < n; i += nt) {
+        for (int i0 = 0; i0 < n; i0 += 8 * nt)
+#pragma unroll
+        for (int u8 = 0; u8 < 8; u8++) {                        // (the compiler hoists the eight loads of a round: independent addresses, no store between them)
+            const int i = i0 + u8 * nt + tid;
+            if (i >= n) continue;
             const unsigned sv = st[i];
             const int so = st_out(sv);
             const int x0 = st_x(sv) - xmin, y0 = st_y(sv) - ymin - r0;                 // row relative to the band
@@ -1903,12 +1907,18 @@ __device__ int hull_candidates(const unsigned *st, int n, int xmin, int bw, unsi
     for (int i = tid; i < bw; i += NT) { col_lo[i] = 0x7fffffff; col_hi[i] = -0x7fffffff; }
     if (tid == 0) *sh_n = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += NT) {
-        const unsigned s = st[i];
-        if (st_out(s) == (st_in(s) ^ 4)) continue;             // the chain runs straight through: not a contour point, not a hull vertex
-        const int x = st_x(s) - xmin, y = st_y(s);
-        atomicMin(&col_lo[x], y);
-        atomicMax(&col_hi[x], y);
+    for (int i0 = 0; i0 < n; i0 += 8 * NT) {                    // eight loads in flight per lane: a lone wave pays the memory latency once per round
+        unsigned sv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = i0 + u * NT + tid; sv[u] = i < n ? st[i] : 0u; }     // 0: s_out == s_in ^ 4 is false for it, but ...
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const unsigned s = sv[u];
+            if (i0 + u * NT + tid >= n || st_out(s) == (st_in(s) ^ 4)) continue;   // the chain runs straight through: not a contour point, not a hull vertex
+            const int x = st_x(s) - xmin, y = st_y(s);
+            atomicMin(&col_lo[x], y);
+            atomicMax(&col_hi[x], y);
+        }
     }
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
@@ -1948,6 +1958,96 @@ __device__ int hull_candidates(const unsigned *st, int n, int xmin, int bw, unsi
         for (int r = 0; r < ROUNDS; r++)
             if (v_pos[r] >= 0) { col_lo[v_pos[r]] = v_lo[r]; col_hi[v_pos[r]] = v_hi[r]; col_x[v_pos[r]] = r * NT + tid; }
         __syncthreads();
+    }
+    if (NT == 64) {
+        // One wave: the strict hull vertices of the two x-monotone chains (column minima / column maxima) by PRUNING instead of the chord
+        // tests below (O(m^2) per chain: a 900-pixel-wide merged blob with a ragged edge kept its wave busy for 70 k cycles while the other
+        // borders of the kernel had long finished).  A point that is not strictly outside the segment between its two current
+        // neighbours lies inside the hull of the set and goes; all such points go at once (their neighbours, removed or not, belong
+        // to the set); when a round removes nothing every consecutive triple is strictly convex, i.e. the chain is the hull chain.
+        // Same survivors as the chord tests, in a handful of rounds of m / 64 steps.
+        __shared__ unsigned long long keep_bits[MW / 64];
+        for (int i = tid; i < m_cols; i += 64) {                 // pack (x, y): 11 + 15 bits
+            const int x = col_x[i];
+            col_lo[i] = x | (col_lo[i] << 11);
+            col_hi[i] = x | (col_hi[i] << 11);
+        }
+        __syncthreads();
+        int len[2];
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++) {
+            int *P = ch ? col_hi : col_lo;
+            int L = m_cols;
+            for (;;) {
+                for (int r = 0; r * 64 < L; r++) {               // who stays (reads only)
+                    const int i = r * 64 + tid;
+                    bool keep = false;
+                    if (i < L) {
+                        keep = true;
+                        if (i > 0 && i < L - 1) {
+                            const int a = P[i - 1], b = P[i + 1], q = P[i];
+                            const long long cr = cross3(a & 0x7ff, a >> 11, b & 0x7ff, b >> 11, q & 0x7ff, q >> 11);
+                            keep = ch ? cr > 0 : cr < 0;         // strictly below (max-y chain) / above (min-y chain) the chord of its neighbours
+                        }
+                    }
+                    const unsigned long long bal = __ballot(keep);
+                    if (tid == 0) keep_bits[r] = bal;
+                }
+                __syncthreads();
+                int newL = 0;
+                for (int r = 0; r * 64 < L; r++) {               // compaction in place, a chunk at a time
+                    const int i = r * 64 + tid;
+                    const unsigned long long bal = keep_bits[r];
+                    const bool keep = (bal >> tid) & 1ull;
+                    const int v = keep ? P[i] : 0;
+                    const int pos = newL + __popcll(bal & ((1ull << tid) - 1));
+                    __syncthreads();
+                    if (keep) P[pos] = v;
+                    newL += __popcll(bal);
+                }
+                __syncthreads();
+                if (newL == L) break;
+                L = newL;
+            }
+            len[ch] = L;
+        }
+        // merge in (x, y) order: at equal x the column minimum first; a column whose minimum and maximum are one point is emitted once
+        const int L0 = len[0], L1 = len[1];
+        auto lower = [&](const int *P, int L, int x) { int lo = 0, hi = L; while (lo < hi) { const int m = (lo + hi) >> 1; if ((P[m] & 0x7ff) < x) lo = m + 1; else hi = m; } return lo; };
+        int dup_before = 0, total_dup = 0;                      // duplicates among the max-chain entries (running count per chunk)
+        for (int r = 0; r * 64 < L0; r++) {
+            const int j = r * 64 + tid;
+            if (j < L0) {
+                const int v = col_lo[j], x = v & 0x7ff;
+                const int k = lower(col_hi, L1, x);
+                // entries of the other chain that come before: those with smaller x, minus the duplicates among them
+                int d = 0;
+                for (int t = 0; t < k; t++) { const int u = col_hi[t]; const int kk = lower(col_lo, L0, u & 0x7ff); d += (kk < L0 && col_lo[kk] == u) ? 1 : 0; }
+                const int pos = j + k - d;
+                if (pos < cap) { out[pos].x = (float)(x + xmin); out[pos].y = (float)(v >> 11); }
+            }
+        }
+        for (int r = 0; r * 64 < L1; r++) {
+            const int j = r * 64 + tid;
+            bool dup = false;
+            int v = 0, x = 0, kle = 0;
+            if (j < L1) {
+                v = col_hi[j]; x = v & 0x7ff;
+                const int k = lower(col_lo, L0, x);
+                dup = k < L0 && col_lo[k] == v;
+                kle = k + ((k < L0 && (col_lo[k] & 0x7ff) == x) ? 1 : 0);      // min-chain entries with x' <= x
+            }
+            const unsigned long long bal = __ballot(dup);
+            const int d = dup_before + __popcll(bal & ((1ull << tid) - 1));
+            if (j < L1 && !dup) {
+                const int pos = kle + j - d;
+                if (pos < cap) { out[pos].x = (float)(x + xmin); out[pos].y = (float)(v >> 11); }
+            }
+            dup_before += __popcll(bal);
+        }
+        total_dup = dup_before;
+        __syncthreads();
+        return L0 + L1 - total_dup;
     }
     for (int base = 0; base < m_cols; base += NT) {
         const int i = base + tid;
@@ -2193,8 +2293,9 @@ PT_STAGE_KERNEL(unclip_kernel, unclip_body, __launch_bounds__(64))
 // is not filtered out before -- the BoxScore mask and its masked mean (the reference scores only borders whose rectangle passes the
 // size filter; scoring the few others as well costs less than a kernel boundary between the two passes over the states), and the
 // border joins its image's list.  Kernel 2, four lanes per border: rectangle, filters, unclip, second rectangle, final box.
+constexpr int WAVE_NT = 64;                // threads per border in kernel 1 (128: 87 us against 78 -- the largest mask sets the time either way)
 constexpr int W_MW = 1024;                // border width a wave takes (wider: the full-size pass)
-constexpr int W_PLANE = 768;              // mask plane words per wave (a larger mask goes through them in bands of rows)
+constexpr int W_PLANE = 1536;             // mask plane words per wave (a larger mask goes through them in bands of rows)
 __device__ __forceinline__ void border_wave_body(const StageArgs &a, const DbpostDims &d, int img, int k) {
     const int tid = threadIdx.x;
     const long bi = (long)img * MAX_CAND + k;
@@ -2207,15 +2308,15 @@ __device__ __forceinline__ void border_wave_body(const StageArgs &a, const Dbpos
     if (bw > W_MW) { if (tid == 0) { res->status = ST_DEFER; atomicOr(&a.flags[img], 8); } return; }
     constexpr int ARENA = 3 * W_MW > 2 * W_PLANE ? 3 * W_MW : 2 * W_PLANE;
     __shared__ __attribute__((aligned(16))) unsigned arena[ARENA];             // column tables, then the two mask planes
-    __shared__ int wave_cnt[1];
+    __shared__ int wave_cnt[WAVE_NT / 64];
     __shared__ int sh_n;
-    __shared__ double red_d[1];
-    __shared__ int red_i[1];
+    __shared__ double red_d[WAVE_NT / 64];
+    __shared__ int red_i[WAVE_NT / 64];
     __shared__ double sh_tie;
     const unsigned *st = a.pool + (long)img * d.pool_cap + ac.off;
     long long *ts = a.stamps ? a.stamps + ((long)img * MAX_CAND + k) * 16 + 12 : nullptr;   // slots 12..14 of the border's record
     stamp(ts, 0);
-    const int n = hull_candidates<W_MW, 64>(st, ac.nstates, ac.xmin, bw, arena, a.hin + bi * S_MH, Q_PTS, wave_cnt, &sh_n);
+    const int n = hull_candidates<W_MW, WAVE_NT>(st, ac.nstates, ac.xmin, bw, arena, a.hin + bi * S_MH, Q_PTS, wave_cnt, &sh_n);
     stamp(ts, 1);
     if (n > Q_PTS) { if (tid == 0) { res->status = ST_DEFER; atomicOr(&a.flags[img], 8); } return; }
     if (tid == 0) a.tie[bi] = 0;
@@ -2231,7 +2332,7 @@ __device__ __forceinline__ void border_wave_body(const StageArgs &a, const Dbpos
     }
 }
 
-__global__ __launch_bounds__(64) void border_wave_kernel(StageArgs a, DbpostDims d) {
+__global__ __launch_bounds__(WAVE_NT) void border_wave_kernel(StageArgs a, DbpostDims d) {
     const int img = blockIdx.y, num = min(a.totals[img], MAX_CAND);
     for (int k = blockIdx.x; k < num; k += gridDim.x) {
         border_wave_body(a, d, img, k);
@@ -2643,7 +2744,7 @@ static void run_chain(ptocr_dbpost *h, const float *d_maps, const uint8_t *d_bit
         hipLaunchKernelGGL(score_kernel, dim3(STAGE_GRID, N), dim3(CT_THREADS), 0, s, a, d);
         hipLaunchKernelGGL(unclip_kernel, dim3(STAGE_GRID, N), dim3(64), 0, s, a, d);
     } else {
-        hipLaunchKernelGGL(border_wave_kernel, dim3(STAGE_GRID, N), dim3(64), 0, s, a, d);
+        hipLaunchKernelGGL(border_wave_kernel, dim3(STAGE_GRID, N), dim3(WAVE_NT), 0, s, a, d);
         hipLaunchKernelGGL(border_quad_kernel, dim3(cdiv(MAX_CAND, 16), N), dim3(64), 0, s, a, d);
     }
     hipLaunchKernelGGL(contour_big_kernel, dim3(64, N), dim3(BIG_THREADS), 0, s, a, d);
