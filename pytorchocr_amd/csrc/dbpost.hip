@@ -2558,6 +2558,8 @@ struct ptocr_dbpost {
     hipEvent_t ev_fork, ev_join[DBPOST_STREAMS];
     int timed;
     int *strip_runs;              // per image: run starts (both polarities) in the bottom strip, counted by binarize_kernel
+    int strip_hint;               // run the bottom-strip labelling pass in the next call (see run_chain)
+    int *h_strip;                 // pinned: the strip's run-start counts of the last call
     int *zeroed;                  // ONE block cleared per call: flags | strip_totals | strip_runs | list_n (max_n ints each)
     long long *stamps;            // PTOCR_DBPOST_STAMPS=1: phase time stamps of the stage kernels (max_n * MAX_CAND * 16)
     int *list; int *tie;          // two-kernel stage form: candidates pending their rectangle per image; score tie marker per border
@@ -2580,6 +2582,8 @@ extern "C" int ptocr_dbpost_create(ptocr_dbpost_t *out, int max_n, int max_h, in
     PT_HIP(hipMalloc(&h->chunk_cnt, sizeof(int) * max_n * nch));
     PT_HIP(hipMalloc(&h->totals, sizeof(int) * max_n));
     PT_HIP(hipMalloc(&h->zeroed, sizeof(int) * 4 * max_n));
+    PT_HIP(hipHostMalloc(&h->h_strip, sizeof(int) * max_n));
+    h->strip_hint = 1;
     h->flags = h->zeroed; h->strip_totals = h->zeroed + max_n; h->strip_runs = h->zeroed + 2 * max_n;
     if (getenv("PTOCR_DBPOST_STAMPS")) {
         PT_HIP(hipMalloc(&h->stamps, sizeof(long long) * 16 * (size_t)max_n * MAX_CAND));
@@ -2615,6 +2619,7 @@ extern "C" int ptocr_dbpost_destroy(ptocr_dbpost_t h) {
     for (void *b : bufs) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->h_strip) (void)hipHostFree(h->h_strip);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (int p = 0; p < DBPOST_STREAMS; p++) {
         if (h->ev_join[p]) (void)hipEventDestroy(h->ev_join[p]);
@@ -2697,15 +2702,24 @@ static void run_chain(ptocr_dbpost *h, const float *d_maps, const uint8_t *d_bit
     Cand *w_cands = h->cands + (long)i0 * MAX_CAND;
     Acc *w_acc = h->acc + (long)i0 * MAX_CAND;
     unsigned *w_pool = h->pool + i0 * h->pool_cap;
-    const int strip_y = H > 2 * STRIP_ROWS ? H - STRIP_ROWS : 0;      // small maps: one pass over everything
+    // The strip pass pays on noise maps only (an image whose bottom 64 rows hold >= 1000 run starts); on text-like maps its four
+    // launches do nothing and cost ~20 us.  So it is launched when the PREVIOUS call on this workspace met such an image (or could
+    // not count: caller's bitmap, dilation); the labels are the same either way, a first noise batch just takes the slower route once.
+    // (Also tried: the 5-us single-block kernels -- chunk suffix sums, pool offsets, box compaction -- as "last block of the image"
+    // tails of their predecessors: the ticket atomics and the lone tail block cost more than the launches saved, 0.504 against 0.490 ms.)
+    const bool counted = !d_bitmap && !use_dilation;
+    const int strip_y = (H > 2 * STRIP_ROWS && (h->strip_hint || !counted)) ? H - STRIP_ROWS : 0;      // small maps: one pass over everything
     d.strip_y = strip_y;
     // run starts in the strip, counted while binarizing: an upper bound of the strip's components.  Below MAX_CAND the strip pass cannot
     // be enough and is left out for that image (its four kernels return at once); a caller's own bitmap or the dilation is not counted
     // (no count: the strip pass always runs).
-    const bool counted = !d_bitmap && !use_dilation;
     const dim3 row_grid(cdiv(W, 1024), H, N);
     if (d_bitmap) hipLaunchKernelGGL(pack_u8_kernel, row_grid, dim3(256), 0, s, d_bitmap, w_bits, d);
-    else hipLaunchKernelGGL(binarize_kernel, row_grid, dim3(256), 0, s, d_maps, w_bits, d, thresh, counted ? w_strip_runs : nullptr);
+    else {
+        DbpostDims dc = d;                                       // the count is taken whether or not the strip pass runs this time
+        dc.strip_y = H > 2 * STRIP_ROWS ? H - STRIP_ROWS : 0;
+        hipLaunchKernelGGL(binarize_kernel, row_grid, dim3(256), 0, s, d_maps, w_bits, dc, thresh, counted ? w_strip_runs : nullptr);
+    }
     unsigned *bits = w_bits;
     if (use_dilation) {
         hipLaunchKernelGGL(dilate2x2_kernel, dim3(cdiv(d.WW, 256), H, N), dim3(256), 0, s, w_bits, w_bits2, d);
@@ -2796,9 +2810,14 @@ extern "C" int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, co
     h->timed = 1;
     PT_HIP(hipMemcpyAsync(h_counts, h->counts, sizeof(int) * N, hipMemcpyDeviceToHost, s));
     PT_HIP(hipMemcpyAsync(h_flags, h->flags, sizeof(int) * N, hipMemcpyDeviceToHost, s));
+    PT_HIP(hipMemcpyAsync(h->h_strip, h->strip_runs, sizeof(int) * N, hipMemcpyDeviceToHost, s));
     PT_HIP(hipMemcpyAsync(h_boxes, h->boxes, sizeof(short) * 8 * (size_t)N * max_boxes, hipMemcpyDeviceToHost, s));
     PT_HIP(hipStreamSynchronize(s));
     for (int i = 0; i < N; i++) h_flags[i] &= 7;           // bit 3 is internal (deferred borders)
+    if (!d_bitmap && !use_dilation) {
+        h->strip_hint = 0;
+        for (int i = 0; i < N; i++) h->strip_hint |= h->h_strip[i] >= MAX_CAND;
+    }
     for (int i = 0; i < N; i++)
         if (h_flags[i] & 4) return fail("ptocr_db_postprocess: internal capacity exceeded on image %d (state pool %ld entries or hull "
                                         "candidates %d)", i, h->pool_cap, MAXHULL);
