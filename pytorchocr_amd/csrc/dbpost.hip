@@ -208,7 +208,7 @@ __device__ __forceinline__ WordCtx word_ctx(const unsigned *row, int wi, const D
 // strip) -- and when an image has >= MAX_CAND starts there (speckle / noise maps: tens of thousands of components) pass B,
 // the whole image, is skipped for it.  Clean maps have few components and go through both passes (pass A costs 9 %).
 constexpr int STRIP_ROWS = 64;
-struct CclPass { int y_first; const int *skip_if_full; const int *skip_if_few; };   // skip_if_full: per-image start counts of pass A (pass B), skip_if_few: run starts of the strip (pass A), or null
+struct CclPass { int y_first; const int *skip_if_full; const int *skip_if_few; int dbg; };   // skip_if_full: per-image start counts of pass A (pass B), skip_if_few: run starts of the strip (pass A), or null
 
 __device__ __forceinline__ bool ccl_skip(const CclPass &ps, int img) {
     return (ps.skip_if_full && ps.skip_if_full[img] >= MAX_CAND) || (ps.skip_if_few && ps.skip_if_few[img] < MAX_CAND);
@@ -238,12 +238,18 @@ __global__ __launch_bounds__(256) void ccl_init_kernel(const unsigned *__restric
 // on bit masks): vertical links where one of the two runs starts; for foreground (8-connected) the NW link at a run
 // start and the NE link at a run end, when the pixel straight above is background; background is 4-connected and every
 // background run touching the image border is united with the virtual FRAME root.
+template <int TPW>                                              // threads per word: 4 on noise maps, 1 otherwise (see below)
 __global__ __launch_bounds__(256) void ccl_merge_kernel(const unsigned *__restrict__ bits, int *__restrict__ labels, DbpostDims d,
                                                         CclPass ps) {
     const int img = blockIdx.y;
     if (ccl_skip(ps, img)) return;
-    const int idx = (blockIdx.x * 256 + threadIdx.x) >> 2;       // four threads per word, one byte of its boundary masks each:
-    const unsigned part = 0xffu << (8 * (threadIdx.x & 3));     // speckle maps put ~10 unions into a word, each a chain of atomics
+    int dummy = 0;
+#define MU(l, x, y) do { if (ps.dbg & 1) dummy += (x) ^ (y); else if (ps.dbg & 2) dummy += uf_find(l, x) ^ uf_find(l, y); else uf_union(l, x, y); } while (0)
+    // speckle maps put ~10 unions into a word, each a chain of atomics: four threads per word there, one byte of its boundary masks
+    // each.  A text-like map has a union in one word of ten, and walking its 30 000 words with 120 000 threads was half of the
+    // kernel's time (38 of 79 us with every union compiled out): one thread per word there.
+    const int idx = TPW == 4 ? (blockIdx.x * 256 + threadIdx.x) >> 2 : blockIdx.x * 256 + threadIdx.x;
+    const unsigned part = TPW == 4 ? 0xffu << (8 * (threadIdx.x & 3)) : 0xffffffffu;
     if (idx >= (d.H - ps.y_first) * d.WW) return;
     const int y = ps.y_first + idx / d.WW, wi = idx % d.WW;
     const bool cut = y == ps.y_first && y > 0;                    // first row of the strip: links upwards end in FRAME
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(256) void ccl_merge_kernel(const unsigned *__restri
         while (f) {
             const int i = __ffs(f) - 1;
             f &= f - 1;
-            uf_union(lab, rs_cur(i), FRAME);
+            MU(lab, rs_cur(i), FRAME);
         }
     }
     if (y == 0) return;
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(256) void ccl_merge_kernel(const unsigned *__restri
     while (v) {
         const int i = __ffs(v) - 1;
         v &= v - 1;
-        uf_union(lab, rs_cur(i), cut ? FRAME : ((u.starts >> i) & 1u ? ubase + i : rs_up(x0 + i)));
+        MU(lab, rs_cur(i), cut ? FRAME : ((u.starts >> i) & 1u ? ubase + i : rs_up(x0 + i)));
     }
     // foreground with background straight above: diagonal links
     const unsigned fgbg = c.w & ~u.w & c.valid;
@@ -284,15 +290,17 @@ __global__ __launch_bounds__(256) void ccl_merge_kernel(const unsigned *__restri
     while (nw) {
         const int i = __ffs(nw) - 1;
         nw &= nw - 1;
-        uf_union(lab, base + i, cut ? FRAME : rs_up(x0 + i - 1));
+        MU(lab, base + i, cut ? FRAME : rs_up(x0 + i - 1));
     }
     const unsigned unext = (wi + 1 < d.WW) ? (up[wi + 1] & 1u) : 0u;
     unsigned ne = fgbg & c.ends & ((u.w >> 1) | (unext << 31)) & part;     // pix(up, x+1) set (bits beyond W are clear)
     while (ne) {
         const int i = __ffs(ne) - 1;
         ne &= ne - 1;
-        uf_union(lab, rs_cur(i), cut ? FRAME : ubase + i + 1);      // up(x) = 0, up(x+1) = 1: a run start
+        MU(lab, rs_cur(i), cut ? FRAME : ubase + i + 1);      // up(x) = 0, up(x+1) = 1: a run start
     }
+    if ((ps.dbg & 3) && dummy == 0x7fffffff) lab[0] = dummy;
+#undef MU
 }
 
 // label[s] = root for every run start s; word_lab[word] = root of the run that covers bit 0 of the word (so that the root of
@@ -2727,13 +2735,15 @@ static void run_chain(ptocr_dbpost *h, const float *d_maps, const uint8_t *d_bit
     }
     for (int pass = strip_y ? 0 : 1; pass < 2; pass++) {
         CclPass ps;
+        ps.dbg = getenv("PTOCR_DBPOST_DBG_SKIP") ? (atoi(getenv("PTOCR_DBPOST_DBG_SKIP")) >> 13) & 3 : 0;      // 8192: merge without unions, 16384: finds only
         ps.y_first = pass == 0 ? strip_y : 0;
         ps.skip_if_full = (pass == 1 && strip_y) ? w_strip_totals : nullptr;
         ps.skip_if_few = (pass == 0 && counted) ? w_strip_runs : nullptr;
         const int words = (H - ps.y_first) * d.WW;
         const dim3 word_grid(cdiv(words > d.nchunks ? words : d.nchunks, 256), N);
         hipLaunchKernelGGL(ccl_init_kernel, word_grid, dim3(256), 0, s, bits, w_labels, w_chunk, d, ps);
-        hipLaunchKernelGGL(ccl_merge_kernel, dim3(cdiv(4 * words, 256), N), dim3(256), 0, s, bits, w_labels, d, ps);
+        if (h->strip_hint || !counted) hipLaunchKernelGGL(ccl_merge_kernel<4>, dim3(cdiv(4 * words, 256), N), dim3(256), 0, s, bits, w_labels, d, ps);
+        else hipLaunchKernelGGL(ccl_merge_kernel<1>, dim3(cdiv(words, 256), N), dim3(256), 0, s, bits, w_labels, d, ps);
         hipLaunchKernelGGL(ccl_flatten_kernel, word_grid, dim3(256), 0, s, bits, w_labels, w_word_lab, w_chunk, d, ps);
         hipLaunchKernelGGL(chunk_suffix_kernel, dim3(N), dim3(1024), 0, s, w_chunk, w_totals, d, ps, w_strip_totals);
     }
