@@ -18,15 +18,17 @@ constexpr int HT_LD = HT_C + 4;          // LDS row stride (floats)
 constexpr int HT_PIX = 128;              // pixels per tile (4 waves x 32)
 
 // w1: f32[256][64] (row (a*2+b)*64 + co, BN folded), b1: f32[256]; w2: f32[4][64] (a'*2+b'), b2 scalar
-// Persistent workgroups (one per CU): the 256 x 64 weights are staged in LDS once, the 128-pixel input tiles are double-
-// buffered in LDS and tile i+1 is fetched into registers while tile i computes (a synchronous load per tile cost 25 %).
-__global__ __launch_bounds__(256, 1) void db_head_tail_kernel(const float *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1,
+// Persistent workgroups, TWO per CU: the 256 x 64 weights sit in LDS (70 KB per workgroup), the pixels do not pass through LDS
+// at all -- with B = pixels a lane's operand of a k step is one of four consecutive channels of ITS pixel, so the lane reads its
+// 64 channels straight from global memory (eight 16-byte loads, the next tile's while this one computes).  With one wave per SIMD
+// (round 2: input tiles double-buffered in LDS, 139 KB) the ~6 k cycles of epilogue per tile -- bias, ReLU, the second contraction,
+// sigmoid -- ran with the matrix pipe idle (56 % busy); with two, one workgroup's epilogue runs under the other's MFMAs.
+__global__ __launch_bounds__(256, 2) void db_head_tail_kernel(const float *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1,
                                                               const float *__restrict__ w2, float b2, float *__restrict__ maps, int H, int W, long npix,
                                                               int ntiles, long x_bytes) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *ws = smem;                                        // [256 col][HT_LD]
-    float *xsb = ws + 256 * HT_LD;                           // [2][HT_PIX pixel][HT_LD]
-    float *w2s = xsb + 2 * HT_PIX * HT_LD;                   // [4][64]
+    float *w2s = ws + 256 * HT_LD;                           // [4][64]
     float *b1s = w2s + 4 * HT_C;                             // [256]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, (int)x_bytes, 0x00020000);
@@ -37,96 +39,86 @@ __global__ __launch_bounds__(256, 1) void db_head_tail_kernel(const float *__res
     w2s[tid] = w2[tid];
     b1s[tid] = b1[tid];
     const int j = lane & 31, h = lane >> 5;                  // pixel within the wave's 32, k half
-    f32x4 xreg[8];
-    auto gload = [&](int tile) {                             // beyond npix: out of range -> zeros
+    f32x4 xcur[8], xnext[8];                                 // B operand: pixel j, k = 8 kk + 4 h + t
+    auto gload = [&](int tile, f32x4 *dst) {                 // beyond npix: out of range -> zeros
+        const long m = (long)tile * HT_PIX + wave * 32 + j;
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int f = tid + 256 * r;
-            const long m = (long)tile * HT_PIX + (f >> 4);
-            xreg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (unsigned)(m * (HT_C * 4) + (f & 15) * 16), 0, 0));
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int f = tid + 256 * r;
-            *reinterpret_cast<f32x4 *>(xsb + buf * HT_PIX * HT_LD + (f >> 4) * HT_LD + (f & 15) * 4) = xreg[r];
-        }
+        for (int kk = 0; kk < 8; kk++)
+            dst[kk] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (unsigned)(m * (HT_C * 4) + (kk * 8 + 4 * h) * 4), 0, 0));
     };
     int tile = blockIdx.x;                                   // host launches gridDim.x <= ntiles
-    gload(tile);
-    lstore(0);
+    gload(tile, xcur);
     __syncthreads();
-  for (int it = 0;; it++) {
-    const int buf = it & 1;
+  for (;;) {
     const int next = tile + (int)gridDim.x;
     const bool has_next = next < ntiles;
-    if (has_next) gload(next);                               // in flight during this tile's MFMAs
+    if (has_next) gload(next, xnext);                        // in flight during this tile's MFMAs
     const long p0 = (long)tile * HT_PIX;
-    const float *xs = xsb + buf * HT_PIX * HT_LD;
-
-    const float *bx = xs + (wave * 32 + j) * HT_LD + 4 * h;  // B operand: pixel j, k = 8kk + 4h + t
-    float outv[4][4];                                        // [ab][a'b'] partial sums of this lane
-#pragma unroll
-    for (int g = 0; g < 4; g++)
-#pragma unroll
-        for (int o = 0; o < 4; o++) outv[g][o] = 0.f;
-
-#pragma unroll
-    for (int g = 0; g < 4; g++) {                            // (a, b) group: 64 mid channels = two 32-row tiles
-        f32x16 acc0, acc1;
-#pragma unroll
-        for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
-        const float *aw0 = ws + (g * 64 + j) * HT_LD + 4 * h;        // A operand: row (co) j of tile 0
-        const float *aw1 = aw0 + 32 * HT_LD;
-#pragma unroll
-        for (int kk = 0; kk < HT_C / 8; kk++) {
-            const f32x4 b = *reinterpret_cast<const f32x4 *>(bx + kk * 8);
-            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(aw0 + kk * 8);
-            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(aw1 + kk * 8);
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b[t], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b[t], acc1, 0, 0, 0);
-            }
-        }
-        // D[row = co][col = pixel j]: register r holds co = (r&3) + 8*(r>>2) + 4*h (+32 for tile 1)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int co0 = (r & 3) + 8 * (r >> 2) + 4 * h, co1 = co0 + 32;
-            const float m0 = fmaxf(acc0[r] + b1s[g * 64 + co0], 0.f);
-            const float m1 = fmaxf(acc1[r] + b1s[g * 64 + co1], 0.f);
-#pragma unroll
-            for (int o = 0; o < 4; o++) outv[g][o] += m0 * w2s[o * HT_C + co0] + m1 * w2s[o * HT_C + co1];
-        }
-    }
-    // the other half of the mid channels lives in lane ^ 32
-#pragma unroll
-    for (int g = 0; g < 4; g++)
-#pragma unroll
-        for (int o = 0; o < 4; o++) outv[g][o] += __shfl_xor(outv[g][o], 32);
     const long pix = p0 + wave * 32 + j;
-    if (h == 0 && pix < npix) {
+    const bool store = h == 0 && pix < npix;
+    float *o = maps;
+    if (store) {
         const long n = pix / ((long)H * W);
         const int rem = (int)(pix - n * (long)H * W);
         const int y = rem / W, xx = rem - y * W;
-        float *o = maps + (n * 4 * H + 4 * y) * (long)(4 * W) + 4 * xx;
-        // output pixel (4y + 2a + a', 4x + 2b + b')
+        o = maps + (n * 4 * H + 4 * y) * (long)(4 * W) + 4 * xx;
+    }
+    // (a, b) groups two at a time -- the pair (a, 0), (a, 1) fills two output rows; the loop over a stays rolled: at two waves per SIMD
+    // the register budget is 256, and four unrolled groups spilled 1.8 KB per lane
+#pragma unroll 1
+    for (int a = 0; a < 2; a++) {
+        float outv[2][4];                                    // [b][a'b'] partial sums of this lane
 #pragma unroll
-        for (int a = 0; a < 2; a++)
+        for (int bb = 0; bb < 2; bb++) {
+            const int g = a * 2 + bb;
+            asm volatile("" ::: "memory");                      // the epilogue's 192 LDS operands are read here, per group: hoisted out of the tile loop they spill
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
+            const float *aw0 = ws + (g * 64 + j) * HT_LD + 4 * h;    // A operand: row (co) j of tile 0
+            const float *aw1 = aw0 + 32 * HT_LD;
+#pragma unroll
+            for (int kk = 0; kk < HT_C / 8; kk++) {
+                const f32x4 b = xcur[kk];
+                const f32x4 a0 = *reinterpret_cast<const f32x4 *>(aw0 + kk * 8);
+                const f32x4 a1 = *reinterpret_cast<const f32x4 *>(aw1 + kk * 8);
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b[t], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b[t], acc1, 0, 0, 0);
+                }
+            }
+            // D[row = co][col = pixel j]: register r holds co = (r&3) + 8*(r>>2) + 4*h (+32 for tile 1)
+#pragma unroll
+            for (int oo = 0; oo < 4; oo++) outv[bb][oo] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int co0 = (r & 3) + 8 * (r >> 2) + 4 * h, co1 = co0 + 32;
+                const float m0 = fmaxf(acc0[r] + b1s[g * 64 + co0], 0.f);
+                const float m1 = fmaxf(acc1[r] + b1s[g * 64 + co1], 0.f);
+#pragma unroll
+                for (int oo = 0; oo < 4; oo++) outv[bb][oo] += m0 * w2s[oo * HT_C + co0] + m1 * w2s[oo * HT_C + co1];
+            }
+            // the other half of the mid channels lives in lane ^ 32
+#pragma unroll
+            for (int oo = 0; oo < 4; oo++) outv[bb][oo] += __shfl_xor(outv[bb][oo], 32);
+        }
+        if (store) {
+            // output pixel (4y + 2a + a', 4x + 2b + b')
 #pragma unroll
             for (int ap = 0; ap < 2; ap++) {
                 f32x4 row;
-                row[0] = 1.f / (1.f + expf(-(outv[a * 2 + 0][ap * 2 + 0] + b2)));
-                row[1] = 1.f / (1.f + expf(-(outv[a * 2 + 0][ap * 2 + 1] + b2)));
-                row[2] = 1.f / (1.f + expf(-(outv[a * 2 + 1][ap * 2 + 0] + b2)));
-                row[3] = 1.f / (1.f + expf(-(outv[a * 2 + 1][ap * 2 + 1] + b2)));
+                row[0] = 1.f / (1.f + expf(-(outv[0][ap * 2 + 0] + b2)));
+                row[1] = 1.f / (1.f + expf(-(outv[0][ap * 2 + 1] + b2)));
+                row[2] = 1.f / (1.f + expf(-(outv[1][ap * 2 + 0] + b2)));
+                row[3] = 1.f / (1.f + expf(-(outv[1][ap * 2 + 1] + b2)));
                 *reinterpret_cast<f32x4 *>(o + (long)(2 * a + ap) * (4 * W)) = row;
             }
+        }
     }
     if (!has_next) break;
-    lstore(buf ^ 1);                                         // every wave finished reading buf^1 before the previous barrier
-    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++) xcur[kk] = xnext[kk];
     tile = next;
   }
 }
@@ -143,7 +135,7 @@ extern "C" int ptocr_db_head_tail_f32(const float *d_x, const float *d_w1, const
     const long x_bytes = npix * HT_C * 4;
     PT_CHECK(x_bytes < (1L << 31), "ptocr_db_head_tail_f32: tensor larger than 2 GiB");
     const int ntiles = (int)((npix + HT_PIX - 1) / HT_PIX);
-    const size_t lds = sizeof(float) * (256 * HT_LD + 2 * HT_PIX * HT_LD + 4 * HT_C + 256);
+    const size_t lds = sizeof(float) * (256 * HT_LD + 4 * HT_C + 256);
     static bool attr_set = false;
     if (!attr_set) {
         PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(db_head_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -155,7 +147,7 @@ extern "C" int ptocr_db_head_tail_f32(const float *d_x, const float *d_w1, const
         PT_HIP(hipGetDevice(&dev));
         PT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     }
-    const int grid = ntiles < n_cu ? ntiles : n_cu;
+    const int grid = ntiles < 2 * n_cu ? ntiles : 2 * n_cu;
     hipLaunchKernelGGL(db_head_tail_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, d_x, d_w1, d_b1, d_w2, b2, d_maps, H, W,
                        npix, ntiles, x_bytes);
     return launch_ok("db_head_tail_kernel");
