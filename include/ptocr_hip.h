@@ -161,6 +161,14 @@ int ptocr_asf_scale_channel_spatial_f32(const float *d_y, float *d_fuse, const f
                                         const float *d_w_sp3, float w_sp1, const float *d_w_att, float *d_work,
                                         int N, int H, int W, void *stream);
 long ptocr_asf_work_floats(int N, int H, int W);
+/* attention_type "scale_spatial" (asf.py:78-107, 146-162): as above without the channel gate. */
+int ptocr_asf_scale_spatial_f32(const float *d_y, float *d_fuse, const float *d_w_sp3, float w_sp1, const float *d_w_att, float *d_work,
+                                int N, int H, int W, void *stream);
+/* attention_type "scale_channel" (asf.py:9-29, 146-162): global average of y -> fc1 (d_w1 f32[32][64], d_b1 f32[32]: its BatchNorm
+ * folded in) -> ReLU -> fc2 (d_w2 f32[4][32]) -> softmax over the four levels; fuse[n, :, :, 64 i .. 64 i + 63] *= score[n][i]
+ * (the reference interpolates the 1x1 score map bilinearly to the map size: a constant). */
+int ptocr_asf_scale_channel_f32(const float *d_y, float *d_fuse, const float *d_w1, const float *d_b1, const float *d_w2, float *d_work,
+                                int N, int H, int W, void *stream);
 
 /* ---- bf16 inference path of the MobileNetV3 detector (BASELINE configs[3]) ---------------------------------------------
  * Activations are bf16 NHWC with the channel count padded to a multiple of 16 (padding channels hold zeros); weights bf16,

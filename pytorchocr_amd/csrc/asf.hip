@@ -1,6 +1,7 @@
-// DB++ Adaptive Scale Fusion (attention_type "scale_channel_spatial") around the MFMA conv.
-// Replaces pytocr/modeling/necks/asf.py:32-75 (ScaleChannelSpatialAttention.forward) and :146-162
-// (ScaleFeatureSelection.forward after its 3x3 conv, which runs on conv_mfma).  All four kernels are
+// DB++ Adaptive Scale Fusion around the MFMA conv: attention_type "scale_channel_spatial" (the yml default), "scale_spatial"
+// (the same data flow without the channel gate) and "scale_channel" (four softmax weights per image).
+// Replaces pytocr/modeling/necks/asf.py:32-75 (ScaleChannelSpatialAttention.forward), :78-107 (ScaleSpatialAttention.forward),
+// :9-29 (ScaleChannelAttention.forward) and :146-162 (ScaleFeatureSelection.forward after its 3x3 conv, which runs on conv_mfma).  All four kernels are
 // memory-bound (HBM roofline): y = conv(fuse) is f32[N,H,W,64], fuse is f32[N,H,W,256].
 //   1. asf_pool_kernel      partial sums of y over pixel chunks            (reads y once)
 //   2. asf_channel_kernel   ca = sigmoid(W2 relu(W1 mean(y)))              (one block per image, tiny)
@@ -122,6 +123,49 @@ __global__ __launch_bounds__(256) void asf_apply_kernel(const float *__restrict_
     }
 }
 
+// "scale_channel" (asf.py:9-29): mean over the image -> fc1 (64 -> 32, BatchNorm folded into w1 / b1) -> ReLU -> fc2 (32 -> 4) ->
+// softmax over the four levels.  One block per image.
+constexpr int ASF_MID2 = 32;
+__global__ __launch_bounds__(64) void asf_channel_softmax_kernel(const float *__restrict__ partial, const float *__restrict__ w1 /*[32][64]*/,
+                                                                 const float *__restrict__ b1 /*[32]*/, const float *__restrict__ w2 /*[4][32]*/,
+                                                                 float *__restrict__ score /*[N][4]*/, int HW, int nblk) {
+    const int n = blockIdx.x, c = threadIdx.x;
+    __shared__ float mean[ASF_C], mid[ASF_MID2], logit[ASF_F];
+    float s = 0.f;
+    for (int b = 0; b < nblk; b++) s += partial[((long)n * nblk + b) * ASF_C + c];
+    mean[c] = s / (float)HW;
+    __syncthreads();
+    if (c < ASF_MID2) {
+        float a = b1[c];
+        for (int k = 0; k < ASF_C; k++) a += w1[c * ASF_C + k] * mean[k];
+        mid[c] = fmaxf(a, 0.f);
+    }
+    __syncthreads();
+    if (c < ASF_F) {
+        float a = 0.f;
+        for (int k = 0; k < ASF_MID2; k++) a += w2[c * ASF_MID2 + k] * mid[k];
+        logit[c] = a;
+    }
+    __syncthreads();
+    if (c < ASF_F) {
+        const float m = fmaxf(fmaxf(logit[0], logit[1]), fmaxf(logit[2], logit[3]));
+        const float e0 = expf(logit[0] - m), e1 = expf(logit[1] - m), e2 = expf(logit[2] - m), e3 = expf(logit[3] - m);
+        score[n * ASF_F + c] = expf(logit[c] - m) / (e0 + e1 + e2 + e3);
+    }
+}
+
+// fuse[n, :, :, 64 i : 64 i + 64] *= score[n][i]: the bilinear interpolation of a 1x1 score map (asf.py:154) is that constant
+__global__ __launch_bounds__(256) void asf_scale_levels_kernel(float *__restrict__ fuse, const float *__restrict__ score, int HW, long nquads) {
+    const long q = blockIdx.x * 256L + threadIdx.x;             // one 16-byte piece of a 256-channel pixel
+    if (q >= nquads) return;
+    const long pix = q >> 6;
+    const int level = (int)(q & 63) >> 4;
+    const float sc = score[(pix / HW) * ASF_F + level];
+    f32x4 t = *reinterpret_cast<f32x4 *>(fuse + q * 4);
+    t *= sc;
+    *reinterpret_cast<f32x4 *>(fuse + q * 4) = t;
+}
+
 }  // namespace ptocr
 
 using namespace ptocr;
@@ -143,6 +187,39 @@ extern "C" int ptocr_asf_scale_channel_spatial_f32(const float *d_y, float *d_fu
     hipLaunchKernelGGL(asf_apply_kernel, dim3((unsigned)cdiv((int)((npix + 15) / 16 * 16), 16)), dim3(256), 0, s, d_y, ca, smean, d_w_sp3, w_sp1,
                        d_w_att, d_fuse, H, W, npix);
     return launch_ok("asf kernels");
+}
+
+// attention_type "scale_spatial" (asf.py:78-107): the data flow above with no channel gate (ca = 0: mean_c(y), g = sa + y)
+extern "C" int ptocr_asf_scale_spatial_f32(const float *d_y, float *d_fuse, const float *d_w_sp3, float w_sp1, const float *d_w_att, float *d_work,
+                                           int N, int H, int W, void *stream) {
+    PT_CHECK(d_y && d_fuse && d_w_sp3 && d_w_att && d_work && N >= 1 && N <= 65535, "ptocr_asf_scale_spatial_f32: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int HW = H * W;
+    const long npix = (long)N * HW;
+    float *ca = d_work + (long)N * cdiv(HW, POOL_PIX) * ASF_C;  // same layout as ptocr_asf_scale_channel_spatial_f32
+    float *smean = ca + (long)N * ASF_C;
+    PT_HIP(hipMemsetAsync(ca, 0, sizeof(float) * N * ASF_C, s));
+    hipLaunchKernelGGL(asf_mean_kernel, dim3((unsigned)cdiv((int)((npix + 15) / 16 * 16), 16)), dim3(256), 0, s, d_y, ca, smean, HW, npix);
+    hipLaunchKernelGGL(asf_apply_kernel, dim3((unsigned)cdiv((int)((npix + 15) / 16 * 16), 16)), dim3(256), 0, s, d_y, ca, smean, d_w_sp3, w_sp1,
+                       d_w_att, d_fuse, H, W, npix);
+    return launch_ok("asf scale_spatial kernels");
+}
+
+// attention_type "scale_channel" (asf.py:9-29, 146-162): d_w1 f32[32][64] and d_b1 f32[32] = fc1 with its BatchNorm folded in, d_w2 f32[4][32]
+extern "C" int ptocr_asf_scale_channel_f32(const float *d_y, float *d_fuse, const float *d_w1, const float *d_b1, const float *d_w2, float *d_work,
+                                           int N, int H, int W, void *stream) {
+    PT_CHECK(d_y && d_fuse && d_w1 && d_b1 && d_w2 && d_work && N >= 1 && N <= 65535, "ptocr_asf_scale_channel_f32: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int HW = H * W;
+    const int nblk = cdiv(HW, POOL_PIX);
+    float *partial = d_work;
+    float *score = partial + (long)N * nblk * ASF_C;            // [N][4] in the ca slot
+    hipLaunchKernelGGL(asf_pool_kernel, dim3(nblk, N), dim3(256), 0, s, d_y, partial, HW, nblk);
+    hipLaunchKernelGGL(asf_channel_softmax_kernel, dim3(N), dim3(64), 0, s, partial, d_w1, d_b1, d_w2, score, HW, nblk);
+    const long nquads = (long)N * HW * (ASF_F * ASF_C / 4);
+    PT_CHECK(nquads < (1L << 31) * 256L, "ptocr_asf_scale_channel_f32: tensor too large");
+    hipLaunchKernelGGL(asf_scale_levels_kernel, dim3((unsigned)((nquads + 255) / 256)), dim3(256), 0, s, d_fuse, score, HW, nquads);
+    return launch_ok("asf scale_channel kernels");
 }
 
 extern "C" long ptocr_asf_work_floats(int N, int H, int W) {

@@ -1,4 +1,5 @@
-"""ResNet-18/34 detection backbone on the HIP conv engine.
+"""ResNet-18/34 (BasicBlock) and ResNet-50/101/152 (Bottleneck, stride on the 3x3: "ResNet V1.5") detection backbones on the HIP
+conv engine, 7x7 stem or the three-conv 3x3 stem (mode_3x3).
 
 Mirror of the reference class `ResNet` (pytocr/modeling/backbones/det_resnet.py:143-312): same constructor
 arguments, same parameter/buffer names (state_dict contract), same four outputs
@@ -41,26 +42,66 @@ class BasicBlock(nn.Module):
         return ops.conv2d(out, p["c2"], res=idt, res_mode=ops.RES_ADD_PRE_RELU)
 
 
+class Bottleneck(nn.Module):
+    """reference det_resnet.py:85-140 (groups = 1, base width 64, no dilation): 1x1 -> 3x3 (stride here) -> 1x1 (x4), residual, ReLU"""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, 1, 0, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, 1, 0, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = downsample
+        self.stride = stride
+
+    def pack(self, dev):
+        p = {"c1": ops.PackedConv(self.conv1, self.bn1, dev, relu=True), "c2": ops.PackedConv(self.conv2, self.bn2, dev, relu=True),
+             "c3": ops.PackedConv(self.conv3, self.bn3, dev, relu=True)}
+        if self.downsample is not None:
+            p["ds"] = ops.PackedConv(self.downsample[0], self.downsample[1], dev, relu=False)
+        return p
+
+    @staticmethod
+    def run(p, x):
+        out = ops.conv2d(ops.conv2d(x, p["c1"]), p["c2"])
+        idt = ops.conv2d(x, p["ds"]) if "ds" in p else x
+        # conv3 + bn3, += identity, ReLU (det_resnet.py:128-138) in one epilogue
+        return ops.conv2d(out, p["c3"], res=idt, res_mode=ops.RES_ADD_PRE_RELU)
+
+
 class ResNet(ops.PackedModule):
     def __init__(self, in_channels=3, layers=50, mode_3x3=False, pretrained=False, ckpt_path=None, **kwargs):
         super().__init__()
-        if layers == 18:
-            depth = [2, 2, 2, 2]
-        elif layers == 34:
-            depth = [3, 4, 6, 3]
-        else:
-            raise NotImplementedError("pytorchocr_amd ResNet: only BasicBlock depths 18/34 are on the hot path (got %s)" % layers)
-        if mode_3x3:
-            raise NotImplementedError("pytorchocr_amd ResNet: mode_3x3 stem is not on the hot path")
-        self.inplanes = 64
-        self.conv1 = nn.Conv2d(in_channels, 64, 7, 2, 3, bias=False)
-        self.bn1 = nn.BatchNorm2d(64)
-        self.out_channels = []
+        table = {18: ([2, 2, 2, 2], BasicBlock), 34: ([3, 4, 6, 3], BasicBlock), 50: ([3, 4, 6, 3], Bottleneck),
+                 101: ([3, 4, 23, 3], Bottleneck), 152: ([3, 8, 36, 3], Bottleneck)}
+        if layers not in table:
+            raise ValueError("ResNet layers must be one of %s, got %r" % (sorted(table), layers))
+        for k in ("groups", "width_per_group", "replace_stride_with_dilation", "norm_layer"):
+            if kwargs.get(k) not in (None, 1, 64, [False, False, False]):
+                raise NotImplementedError("pytorchocr_amd ResNet: %s=%r is not built (plain ResNet only)" % (k, kwargs[k]))
+        depth, self.block = table[layers]
+        self.mode_3x3 = bool(mode_3x3)
+        if not self.mode_3x3:                                  # 7x7 kernel
+            self.inplanes = 64
+            self.conv1 = nn.Conv2d(in_channels, 64, 7, 2, 3, bias=False)
+            self.bn1 = nn.BatchNorm2d(64)
+        else:                                                  # three 3x3 convs (det_resnet.py:196-206)
+            self.inplanes = 128
+            self.conv1_1 = nn.Conv2d(in_channels, 64, 3, 2, 1, bias=False)
+            self.bn1_1 = nn.BatchNorm2d(64)
+            self.conv1_2 = nn.Conv2d(64, 64, 3, 1, 1, bias=False)
+            self.bn1_2 = nn.BatchNorm2d(64)
+            self.conv1_3 = nn.Conv2d(64, 128, 3, 1, 1, bias=False)
+            self.bn1_3 = nn.BatchNorm2d(128)
+        e = self.block.expansion
         self.layer1 = self._make_layer(64, depth[0], 1)
         self.layer2 = self._make_layer(128, depth[1], 2)
         self.layer3 = self._make_layer(256, depth[2], 2)
         self.layer4 = self._make_layer(512, depth[3], 2)
-        self.out_channels = [64, 128, 256, 512]
+        self.out_channels = [64 * e, 128 * e, 256 * e, 512 * e]
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
@@ -74,17 +115,22 @@ class ResNet(ops.PackedModule):
                                                   "(no network fetch in pytorchocr_amd)", ckpt_path)
 
     def _make_layer(self, planes, blocks, stride):
-        downsample = None
-        if stride != 1 or self.inplanes != planes:
-            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
-        layers = [BasicBlock(self.inplanes, planes, stride, downsample)]
-        self.inplanes = planes
+        block, downsample = self.block, None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False),
+                                       nn.BatchNorm2d(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
         for _ in range(1, blocks):
-            layers.append(BasicBlock(planes, planes))
+            layers.append(block(self.inplanes, planes))
         return nn.Sequential(*layers)
 
     def _pack(self, dev):
-        p = {"stem": ops.PackedConv(self.conv1, self.bn1, dev, relu=True, cin_pad=4)}
+        if self.mode_3x3:
+            p = {"stem3": [ops.PackedConv(self.conv1_1, self.bn1_1, dev, relu=True, cin_pad=4), ops.PackedConv(self.conv1_2, self.bn1_2, dev, relu=True),
+                           ops.PackedConv(self.conv1_3, self.bn1_3, dev, relu=True)]}
+        else:
+            p = {"stem": ops.PackedConv(self.conv1, self.bn1, dev, relu=True, cin_pad=4)}
         for li in (1, 2, 3, 4):
             p["layer%d" % li] = [blk.pack(dev) for blk in getattr(self, "layer%d" % li)]
         return p
@@ -93,14 +139,20 @@ class ResNet(ops.PackedModule):
         """x4: f32[N,H,W,4] (RGB + zero channel) -> [C2, C3, C4, C5] NHWC; or the model's NCHW input as `x_nchw` (x4 None)."""
         self._check_eval()
         p = self.packed()
-        x = ops.stem_relu_pool(x4, x_nchw, p["stem"])             # stem + ReLU + max pool in one kernel where it applies
-        if x is None:
-            x = ops.conv2d(x4, p["stem"]) if x_nchw is None else ops.stem_from_nchw(x_nchw, p["stem"])
+        if self.mode_3x3:
+            x = x4 if x_nchw is None else ops.nchw_to_nhwc(x_nchw, 4)
+            for pc in p["stem3"]:
+                x = ops.conv2d(x, pc)
             x = ops.maxpool2d(x, 3, 2, 1)
+        else:
+            x = ops.stem_relu_pool(x4, x_nchw, p["stem"])         # stem + ReLU + max pool in one kernel where it applies
+            if x is None:
+                x = ops.conv2d(x4, p["stem"]) if x_nchw is None else ops.stem_from_nchw(x_nchw, p["stem"])
+                x = ops.maxpool2d(x, 3, 2, 1)
         outs = []
         for li in (1, 2, 3, 4):
             for bp in p["layer%d" % li]:
-                x = BasicBlock.run(bp, x)
+                x = self.block.run(bp, x)
             outs.append(x)
         return outs
 

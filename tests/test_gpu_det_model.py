@@ -145,3 +145,39 @@ def test_mobilenetv3_small_db_matches_reference(gold_dir, contract):
     for a, b in zip(y["backbone_out"], ref["backbone_out"]):
         assert (a.cpu() - b).abs().max().item() <= 1e-4 * max(1.0, b.abs().max().item())
     assert np.abs(y["maps"].cpu().numpy() - ref["maps"].numpy()).max() <= 1e-4
+
+
+WIDENED = {
+    "detpp_r18_db_spatial": dict(DET_R18, Neck=dict(DET_R18["Neck"], use_asf=True, attention_type="scale_spatial")),
+    "detpp_r18_db_channel": dict(DET_R18, Neck=dict(DET_R18["Neck"], use_asf=True, attention_type="scale_channel")),
+    "det_r50_db": dict(DET_R18, Backbone=dict(name="ResNet", layers=50, pretrained=False)),
+    "det_r18_db_3x3stem": dict(DET_R18, Backbone=dict(name="ResNet", layers=18, mode_3x3=True, pretrained=False)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(WIDENED))
+def test_reference_options_next_to_the_headline_configs(name, gold_dir, contract):
+    """ASF attention types scale_spatial / scale_channel (necks/asf.py:9-29,78-107), Bottleneck ResNet-50 (det_resnet.py:85-140) and the
+    three-conv 3x3 stem (det_resnet.py:196-206): reference key names (strict load), maps within 1e-4 of outputs of the reference itself"""
+    from pytorchocr_amd.modeling.architectures import build_model
+    g = np.load(os.path.join(gold_dir, "%s_1x3x64x96.npz" % name))
+    m = build_model(dict(WIDENED[name], return_all_feats="c2" in g))
+    sd = synth_state_dict(contract[name])
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.to("cuda:0").eval()
+    x = torch.from_numpy(synth_images(1, 3, 64, 96, seed=int(g["seed"]))).to("cuda:0")
+    with torch.no_grad():
+        y = m(x)
+    if "c2" in g:
+        for k, f in zip(("c2", "c3", "c4", "c5"), y["backbone_out"]):
+            err = np.abs(f.cpu().numpy() - g[k]).max()
+            assert f.shape == g[k].shape and err <= 1e-4 * max(1.0, np.abs(g[k]).max()), (k, err)
+    maps = y["maps"].cpu().numpy()
+    assert maps.shape == g["maps"].shape and np.abs(maps - g["maps"]).max() <= 1e-4, np.abs(maps - g["maps"]).max()
+    # a batch of four copies at another size: the same bits per image, and images do not influence each other
+    xb = torch.from_numpy(synth_images(2, 3, 96, 160, seed=5)).to("cuda:0")
+    with torch.no_grad():
+        a = m(xb.repeat(2, 1, 1, 1))["maps"]
+        b = m(xb[:1])["maps"]
+    assert torch.equal(a[0], a[2]) and torch.equal(a[1], a[3]) and torch.equal(a[0], b[0])

@@ -90,11 +90,14 @@ def test_unsupported_options_raise():
     with pytest.raises(NotImplementedError):
         build_post_process(dict(name="DBPostProcess", cpp_speedup=False), {})
     assert build_post_process(dict(name="DBPostProcess", cpp_speedup=True, use_dilation=True), {}).use_dilation
+    for att in ("scale_spatial", "scale_channel", "scale_channel_spatial"):          # all three attention types of necks/asf.py are built
+        assert build_model(dict(DET, Neck=dict(DET["Neck"], use_asf=True, attention_type=att))).neck.concat_attention.type == att
+    with pytest.raises(ValueError):
+        build_model(dict(DET, Neck=dict(DET["Neck"], use_asf=True, attention_type="scale_nothing")))
+    assert build_model(dict(DET, Backbone=dict(name="ResNet", layers=50))).backbone.out_channels == [256, 512, 1024, 2048]
+    assert build_model(dict(DET, Backbone=dict(name="ResNet", layers=18, mode_3x3=True))).backbone.out_channels == [64, 128, 256, 512]
     with pytest.raises(NotImplementedError):
-        build_model(dict(DET, Neck=dict(DET["Neck"], use_asf=True, attention_type="scale_spatial")))
-    assert hasattr(build_model(dict(DET, Neck=dict(DET["Neck"], use_asf=True))).neck, "concat_attention")
-    with pytest.raises(NotImplementedError):
-        build_model(dict(DET, Backbone=dict(name="ResNet", layers=50)))
+        build_model(dict(DET, Backbone=dict(name="ResNet", layers=50, groups=32, width_per_group=4)))       # ResNeXt widths are not built
     with pytest.raises(AssertionError):
         build_model(dict(DET, Backbone=dict(name="ShuffleNetV2")))
     m = build_model(DET)

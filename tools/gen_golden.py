@@ -10,7 +10,7 @@ What it does (nothing from the reference is copied; only inputs-by-seed and outp
   * records the state_dict key/shape/dtype contract of each model.
 
 Usage: python tools/gen_golden.py   (writes every fixture under tests/golden/;
-       --cls-only / --mbv3s-scene-only / --labels-only / --clipper-only regenerate one group)
+       --cls-only / --mbv3s-scene-only / --widen-only / --labels-only / --clipper-only regenerate one group)
 """
 import importlib.util
 import json
@@ -273,6 +273,35 @@ def gen_mbv3s_scene_vectors():
           (r2, p.min(), p.max(), 100 * (p > 0.3).mean(), 100 * (p > 0.5).mean()))
 
 
+def gen_widen_vectors():
+    """reference options next to the headline configs: ASF attention types scale_spatial / scale_channel (necks/asf.py:9-29,78-107),
+    the Bottleneck ResNet-50 backbone (backbones/det_resnet.py:85-140; the README's best DB row) and the three-conv 3x3 stem
+    (mode_3x3, :196-206): state_dict contracts + maps (+ backbone features for r50) of the reference on one seeded 64x96 input"""
+    torch.manual_seed(0)
+    build_model = _import_reference_models()
+    path = os.path.join(GOLD, "state_dict_contract.json")
+    contract = json.load(open(path))
+    cases = (("detpp_r18_db_spatial", dict(DETPP_R18, Neck=dict(DETPP_R18["Neck"], attention_type="scale_spatial")), 31, False),
+             ("detpp_r18_db_channel", dict(DETPP_R18, Neck=dict(DETPP_R18["Neck"], attention_type="scale_channel")), 32, False),
+             ("det_r50_db", dict(DET_R18, Backbone=dict(name="ResNet", layers=50, pretrained=False)), 33, True),
+             ("det_r18_db_3x3stem", dict(DET_R18, Backbone=dict(name="ResNet", layers=18, mode_3x3=True, pretrained=False)), 34, False))
+    for name, cfg, seed, feats in cases:
+        m, shapes = build_with_synth(build_model, copy.deepcopy(cfg))
+        contract[name] = {k: [list(sh), d] for k, (sh, d) in shapes.items()}
+        x = torch.from_numpy(synth_images(1, 3, 64, 96, seed=seed))
+        m.return_all_feats = feats
+        with torch.no_grad():
+            y = m(x)
+        extra = {}
+        if feats:
+            extra = {"c%d" % (i + 2): f.numpy() for i, f in enumerate(y["backbone_out"])}
+        np.savez_compressed(os.path.join(GOLD, "%s_1x3x64x96.npz" % name), seed=np.int64(seed), maps=y["maps"].numpy(), **extra)
+        p = y["maps"].numpy()
+        print("%s: maps %.4f..%.4f" % (name, p.min(), p.max()))
+    with open(path, "w") as f:
+        json.dump(contract, f, indent=0, sort_keys=False)
+
+
 def gen_clipper_vectors():
     """Unclip golden vectors from the reference's vendored Clipper (oracle/_ref): input int path, delta,
     full solution.  The float mini-boxes come from seeded rotated rectangles (reference UnClip,
@@ -343,6 +372,9 @@ if __name__ == "__main__":
     if "--mbv3s-scene-only" in sys.argv:
         gen_mbv3s_scene_vectors()
         sys.exit(0)
+    if "--widen-only" in sys.argv:
+        gen_widen_vectors()
+        sys.exit(0)
     if "--labels-only" in sys.argv:
         gen_label_vectors()
         sys.exit(0)
@@ -350,5 +382,6 @@ if __name__ == "__main__":
         main()
         gen_cls_vectors()                 # adds cls_mbv3s to the contract main() has just rewritten
         gen_mbv3s_scene_vectors()
+        gen_widen_vectors()
     gen_clipper_vectors()
     gen_label_vectors()
