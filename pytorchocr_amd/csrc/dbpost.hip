@@ -1942,7 +1942,7 @@ __device__ int hull_candidates(const unsigned *st, int n, int xmin, int bw, unsi
             const unsigned long long bal = __ballot(has);
             const int pos = m_cols + __popcll(bal & ((1ull << lane) - 1));
             __syncthreads();
-            if (has) { col_lo[pos] = vlo; col_hi[pos] = vhi; col_x[pos] = i; }
+            if (has) { col_lo[pos] = i | (vlo << 11); col_hi[pos] = i | (vhi << 11); }     // packed (x, y): 11 + 15 bits; no x table in this form
             m_cols += __popcll(bal);
         }
         __syncthreads();
@@ -1976,12 +1976,6 @@ __device__ int hull_candidates(const unsigned *st, int n, int xmin, int bw, unsi
         // to the set); when a round removes nothing every consecutive triple is strictly convex, i.e. the chain is the hull chain.
         // Same survivors as the chord tests, in a handful of rounds of m / 64 steps.
         __shared__ unsigned long long keep_bits[MW / 64];
-        for (int i = tid; i < m_cols; i += 64) {                 // pack (x, y): 11 + 15 bits
-            const int x = col_x[i];
-            col_lo[i] = x | (col_lo[i] << 11);
-            col_hi[i] = x | (col_hi[i] << 11);
-        }
-        __syncthreads();
         int len[2];
 #pragma unroll
         for (int ch = 0; ch < 2; ch++) {
@@ -2167,6 +2161,7 @@ struct StageArgs {
     const float *maps; const Cand *cands; const int *totals; const Acc *acc; const unsigned *pool;
     Result *results; int *flags; const int *src_wh; F2 *hin; int *hn; float *mini;
     long long *stamps;                      // timing experiments: s_memtime stamps of the stage kernels' phases, 16 per wave (null: none)
+    int *big_list; int *big_n;              // borders whose mask is too large for one wave: scored by border_score_big_kernel
     int *list; int *list_n; int *tie;       // two-kernel form: per image the candidates pending their rectangle, their count; per border the score's tie marker
     float box_thresh, unclip_ratio; int use_padding_resize;
     int dbg_skip;      // timing experiments only (PTOCR_DBPOST_DBG_SKIP; results are wrong by design): bits 0-3 phases of the full-size pass,
@@ -2304,7 +2299,8 @@ PT_STAGE_KERNEL(unclip_kernel, unclip_body, __launch_bounds__(64))
 // border joins its image's list.  Kernel 2, four lanes per border: rectangle, filters, unclip, second rectangle, final box.
 constexpr int WAVE_NT = 64;                // threads per border in kernel 1 (128: 87 us against 78 -- the largest mask sets the time either way)
 constexpr int W_MW = 1024;                // border width a wave takes (wider: the full-size pass)
-constexpr int W_PLANE = 1536;             // mask plane words per wave (a larger mask goes through them in bands of rows)
+constexpr int W_PLANE = 1024;             // mask plane words per wave (a larger mask goes through them in bands of rows)
+constexpr int BIG_MASK_WORDS = 384;       // masks beyond 12 k pixels are scored by a 256-thread workgroup (border_score_big_kernel)
 __device__ __forceinline__ void border_wave_body(const StageArgs &a, const DbpostDims &d, int img, int k) {
     const int tid = threadIdx.x;
     const long bi = (long)img * MAX_CAND + k;
@@ -2315,7 +2311,7 @@ __device__ __forceinline__ void border_wave_body(const StageArgs &a, const Dbpos
     const int bw = ac.xmax - ac.xmin + 1, bh = ac.ymax - ac.ymin + 1;
     if ((bw - 1) * (bw - 1) + (bh - 1) * (bh - 1) <= 8) { if (tid == 0) res->status = ST_SKIP_SSID; return; }   // see hull_body
     if (bw > W_MW) { if (tid == 0) { res->status = ST_DEFER; atomicOr(&a.flags[img], 8); } return; }
-    constexpr int ARENA = 3 * W_MW > 2 * W_PLANE ? 3 * W_MW : 2 * W_PLANE;
+    constexpr int ARENA = 2 * W_MW > 2 * W_PLANE ? 2 * W_MW : 2 * W_PLANE;     // (the one-wave form of hull_candidates keeps no x table)
     __shared__ __attribute__((aligned(16))) unsigned arena[ARENA];             // column tables, then the two mask planes
     __shared__ int wave_cnt[WAVE_NT / 64];
     __shared__ int sh_n;
@@ -2331,6 +2327,10 @@ __device__ __forceinline__ void border_wave_body(const StageArgs &a, const Dbpos
     if (tid == 0) a.tie[bi] = 0;
     __syncthreads();
     if (a.dbg_skip & 4096) { if (tid == 0) res->status = ST_NONE; return; }
+    if (((bw + 31) >> 5) * bh > BIG_MASK_WORDS && (a.dbg_skip & 65536)) {    // experiment (65536): large masks scored by 256 threads each
+        if (tid == 0) { a.hn[bi] = n; a.big_list[(long)img * MAX_CAND + atomicAdd(&a.big_n[img], 1)] = k; }
+        return;
+    }
     int npix;
     const float score = border_score(st, ac.nstates, ac.xmin, ac.ymin, bw, bh, arena, arena + W_PLANE, W_PLANE,
                                      a.maps + (long)img * d.HW, d.W, red_d, red_i, &sh_tie, a.box_thresh, &a.tie[bi], &npix);
@@ -2341,10 +2341,38 @@ __device__ __forceinline__ void border_wave_body(const StageArgs &a, const Dbpos
     }
 }
 
+// (occupancy targets of 3 / 4 / 5 waves per SIMD measured 79 / 80 / 84 us, 12 KB against 8 KB of LDS the same: at ~5 400 borders of ~3 k
+// instructions each the kernel is bound by instruction issue over the chip, not by its footprint)
 __global__ __launch_bounds__(WAVE_NT) void border_wave_kernel(StageArgs a, DbpostDims d) {
     const int img = blockIdx.y, num = min(a.totals[img], MAX_CAND);
     for (int k = blockIdx.x; k < num; k += gridDim.x) {
         border_wave_body(a, d, img, k);
+        __syncthreads();
+    }
+}
+
+// Experiment (PTOCR_DBPOST_DBG_SKIP=65536): the masked mean of a large mask (touching text lines: 900 x 45 pixels, 160 KB of map) takes one
+// wave 127 k cycles; here such borders are scored by 256 threads each and then join the rectangle list.  Measured: the wave kernel
+// 78 -> 74 us, this kernel 21 us -- the wave kernel was bound by its LDS footprint (13 waves per CU, two rounds), not by those borders.
+__global__ __launch_bounds__(CT_THREADS) void border_score_big_kernel(StageArgs a, DbpostDims d) {
+    const int img = blockIdx.y, num = a.big_n[img], tid = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) unsigned planes[2 * S_PLANE];
+    __shared__ double red_d[CT_THREADS / 64];
+    __shared__ int red_i[CT_THREADS / 64];
+    __shared__ double sh_tie;
+    for (int e = blockIdx.x; e < num; e += gridDim.x) {
+        const int k = a.big_list[(long)img * MAX_CAND + e];
+        const long bi = (long)img * MAX_CAND + k;
+        Result *res = &a.results[bi];
+        const Acc ac = a.acc[bi];
+        const int bw = ac.xmax - ac.xmin + 1, bh = ac.ymax - ac.ymin + 1;
+        int npix;
+        const float score = border_score(a.pool + (long)img * d.pool_cap + ac.off, ac.nstates, ac.xmin, ac.ymin, bw, bh, planes, planes + S_PLANE, S_PLANE,
+                                         a.maps + (long)img * d.HW, d.W, red_d, red_i, &sh_tie, a.box_thresh, &a.tie[bi], &npix);
+        if (tid == 0) {
+            res->score = score; res->npix = npix; res->status = ST_PEND_RECT;
+            a.list[(long)img * MAX_CAND + atomicAdd(&a.list_n[img], 1)] = k;
+        }
         __syncthreads();
     }
 }
@@ -2569,8 +2597,9 @@ struct ptocr_dbpost {
     int *strip_runs;              // per image: run starts (both polarities) in the bottom strip, counted by binarize_kernel
     int strip_hint;               // run the bottom-strip labelling pass in the next call (see run_chain)
     int *h_strip;                 // pinned: the strip's run-start counts of the last call
-    int *zeroed;                  // ONE block cleared per call: flags | strip_totals | strip_runs | list_n (max_n ints each)
+    int *zeroed;                  // ONE block cleared per call: flags | strip_totals | strip_runs | list_n | big_n (max_n ints each)
     long long *stamps;            // PTOCR_DBPOST_STAMPS=1: phase time stamps of the stage kernels (max_n * MAX_CAND * 16)
+    int *big_list;                // borders with a large mask (per image; their count sits in the cleared block)
     int *list; int *tie;          // two-kernel stage form: candidates pending their rectangle per image; score tie marker per border
 };
 
@@ -2590,7 +2619,8 @@ extern "C" int ptocr_dbpost_create(ptocr_dbpost_t *out, int max_n, int max_h, in
     PT_HIP(hipMalloc(&h->word_lab, sizeof(int) * max_n * max_h * ww));
     PT_HIP(hipMalloc(&h->chunk_cnt, sizeof(int) * max_n * nch));
     PT_HIP(hipMalloc(&h->totals, sizeof(int) * max_n));
-    PT_HIP(hipMalloc(&h->zeroed, sizeof(int) * 4 * max_n));
+    PT_HIP(hipMalloc(&h->zeroed, sizeof(int) * 5 * max_n));
+    PT_HIP(hipMalloc(&h->big_list, sizeof(int) * max_n * MAX_CAND));
     PT_HIP(hipHostMalloc(&h->h_strip, sizeof(int) * max_n));
     h->strip_hint = 1;
     h->flags = h->zeroed; h->strip_totals = h->zeroed + max_n; h->strip_runs = h->zeroed + 2 * max_n;
@@ -2624,7 +2654,7 @@ extern "C" int ptocr_dbpost_create(ptocr_dbpost_t *out, int max_n, int max_h, in
 extern "C" int ptocr_dbpost_destroy(ptocr_dbpost_t h) {
     if (!h) return 0;
     void *bufs[] = {h->bits, h->bits2, h->labels, h->word_lab, h->chunk_cnt, h->totals, h->zeroed, h->cands, h->acc, h->pool, h->hin,
-                    h->hn, h->mini, h->results, h->src_wh, h->boxes, h->counts, h->list, h->tie, h->stamps};
+                    h->hn, h->mini, h->results, h->src_wh, h->boxes, h->counts, h->list, h->tie, h->stamps, h->big_list};
     for (void *b : bufs) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -2763,6 +2793,7 @@ static void run_chain(ptocr_dbpost *h, const float *d_maps, const uint8_t *d_bit
     a.box_thresh = box_thresh; a.unclip_ratio = unclip_ratio; a.use_padding_resize = use_padding_resize;
     a.dbg_skip = getenv("PTOCR_DBPOST_DBG_SKIP") ? atoi(getenv("PTOCR_DBPOST_DBG_SKIP")) : 0;
     a.list = h->list + (long)i0 * MAX_CAND; a.list_n = h->zeroed + 3 * h->max_n + i0; a.tie = h->tie + (long)i0 * MAX_CAND;
+    a.big_list = h->big_list + (long)i0 * MAX_CAND; a.big_n = h->zeroed + 4 * h->max_n + i0;
     a.stamps = h->stamps ? h->stamps + (long)i0 * MAX_CAND * 16 : nullptr;
     static const int four_stages = getenv("PTOCR_DBPOST_STAGES") && atoi(getenv("PTOCR_DBPOST_STAGES")) == 4;
     if (four_stages) {
@@ -2772,6 +2803,7 @@ static void run_chain(ptocr_dbpost *h, const float *d_maps, const uint8_t *d_bit
         hipLaunchKernelGGL(unclip_kernel, dim3(STAGE_GRID, N), dim3(64), 0, s, a, d);
     } else {
         hipLaunchKernelGGL(border_wave_kernel, dim3(STAGE_GRID, N), dim3(WAVE_NT), 0, s, a, d);
+        if (a.dbg_skip & 65536) hipLaunchKernelGGL(border_score_big_kernel, dim3(32, N), dim3(CT_THREADS), 0, s, a, d);
         hipLaunchKernelGGL(border_quad_kernel, dim3(cdiv(MAX_CAND, 16), N), dim3(64), 0, s, a, d);
     }
     hipLaunchKernelGGL(contour_big_kernel, dim3(64, N), dim3(BIG_THREADS), 0, s, a, d);
@@ -2798,7 +2830,7 @@ extern "C" int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, co
     hipStream_t s = (hipStream_t)stream;
     PT_HIP(hipMemcpyAsync(h->src_wh, h_src_wh, sizeof(int) * 2 * N, hipMemcpyHostToDevice, s));
     PT_HIP(hipEventRecord(h->ev0, s));
-    PT_HIP(hipMemsetAsync(h->zeroed, 0, sizeof(int) * 4 * h->max_n, s));     // flags, strip_totals (stay 0 for an image whose strip pass is left out), strip_runs, list_n
+    PT_HIP(hipMemsetAsync(h->zeroed, 0, sizeof(int) * 5 * h->max_n, s));     // flags, strip_totals (stay 0 for an image whose strip pass is left out), strip_runs, list_n, big_n
     // Most kernels of the chain are bound by the latency of ONE image's dependent steps (label chases, per-border geometry), not by
     // the chip: 2 maps take 0.25 ms of kernel time, 32 maps 0.51.  So a batch is cut into up to four parts whose chains run on four
     // streams of the workspace at once (fork / join on events around them): one part's latency-bound kernel fills the CUs another

@@ -23,6 +23,7 @@ _lib.check(lib.ptocr_dbpost_debug_stamps(post._ws.handle, st.ctypes.data_as(C.c_
 # quad kernel: records are per wave (blockIdx.y * gridDim.x + blockIdx.x), slots 0..11
 q = st[: B * 63][:, :12]
 q = q[(q[:, 0] > 0) & (q[:, 11] > 0)]
+q = q[q[:, 0] > q[:, 11].max() - 2000000]
 names = ["load pts", "hull 1", "calipers 1", "angle etc.", "mini boxes", "offset", "(union) + sort", "hull 2", "calipers 2", "angle etc. 2", "final box"]
 d = np.diff(q, axis=1)
 print("quad kernel: %d waves with a full record; cycles per phase (median / mean / max)" % len(q))
@@ -31,8 +32,16 @@ for i, nm in enumerate(names):
 print("  %-16s %8.0f %8.0f %8.0f" % ("total", np.median(q[:, 11] - q[:, 0]), (q[:, 11] - q[:, 0]).mean(), (q[:, 11] - q[:, 0]).max()))
 w = st[:, 12:15]
 w = w[(w[:, 0] > 0) & (w[:, 2] > 0)]
+w = w[w[:, 0] > w[:, 2].max() - 2000000]          # the last call only (records of borders that exist in earlier calls only stay behind)
 dw = np.diff(w, axis=1)
 print("wave kernel: %d borders; cycles (median / mean / max)" % len(w))
 for i, nm in enumerate(["hull candidates", "score"]):
     print("  %-16s %8.0f %8.0f %8.0f" % (nm, np.median(dw[:, i]), dw[:, i].mean(), dw[:, i].max()))
 print("  kernel span: quad %.0f cycles, wave %.0f cycles" % (q[:, 11].max() - q[:, 0].min(), w[:, 2].max() - w[:, 0].min()))
+t0 = w[:, 0].min()
+print("wave kernel timeline (cycles after the first start): starts p50 %.0f p90 %.0f p99 %.0f max %.0f; ends p50 %.0f p90 %.0f p99 %.0f max %.0f" % (
+    *np.percentile(w[:, 0] - t0, [50, 90, 99, 100]), *np.percentile(w[:, 2] - t0, [50, 90, 99, 100])))
+late = np.argsort(w[:, 2])[-8:]
+print("the eight borders that end last: start, hull cycles, score cycles")
+for i in late:
+    print("   %8d %8d %8d" % (w[i, 0] - t0, w[i, 1] - w[i, 0], w[i, 2] - w[i, 1]))
