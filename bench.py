@@ -44,14 +44,14 @@ DET_R18 = dict(model_type="det", algorithm="DB", Transform=None,
                Neck=dict(name="FPN", out_channels=256, mode="DB", use_asf=False, attention_type="scale_channel_spatial"),
                Head=dict(name="DBHead", k=50))
 # the other detectors of SURVEY 8a (--det-model); the headline metric is DBNet-r18
-DET_VARIANTS = {
-    "r18": (DET_R18, "det_r18_db", 114.195),
+DET_VARIANTS = {                                       # config, state_dict contract, GFLOP per image, scene read-out fixture
+    "r18": (DET_R18, "det_r18_db", 114.195, "r18"),
     "r18pp": (dict(DET_R18, Neck=dict(name="FPN", out_channels=256, mode="DB", use_asf=True, attention_type="scale_channel_spatial")),
-              "detpp_r18_db", 131.59),
+              "detpp_r18_db", 131.59, "detpp"),
     "mbv3s": (dict(model_type="det", algorithm="DB", Transform=None,
                    Backbone=dict(name="MobileNetV3", model_name="small", scale=1.0, pretrained=False),
                    Neck=dict(name="FPN", out_channels=96, mode="DB", use_asf=False), Head=dict(name="DBHead", k=50)),
-              "det_mbv3s_db", 8.43),
+              "det_mbv3s_db", 8.43, "mbv3s"),
 }
 DET_POST = dict(name="DBPostProcess", thresh=0.3, box_thresh=0.5, max_candidates=1000, unclip_ratio=1.7,
                 score_mode="poly", cpp_speedup=True, out_polygon=False)
@@ -110,14 +110,24 @@ def self_launch(argv, n):
     raise SystemExit(rc)
 
 
-def build_and_sync_weights(cfg, contract_name, device, rank, world):
-    """Random-init weights of the named architecture: rank 0 makes them, RCCL broadcast puts them on every GPU."""
+def det_state_dict(contract_name, scene):
+    """Random-init weights of the named architecture (utils/synth.py, seeded).  With `scene` (the default) two of the head's channels
+    carry a linear read-out of the neck features fitted to the scene images' text map, and the last layer a logit gain of 14
+    (synth_scene_state_dict; the fit is data under tests/golden): every backbone / neck convolution still runs on its dense random
+    weights, but the probability maps are text-like -- ~140 boxes per image -- instead of the speckle a fully random head gives."""
+    from pytorchocr_amd.utils.synth import load_scene_readout, synth_scene_state_dict, synth_state_dict
+    if scene:
+        return synth_scene_state_dict(load_contract(contract_name), *load_scene_readout(scene))
+    return synth_state_dict(load_contract(contract_name))
+
+
+def build_and_sync_weights(cfg, contract_name, device, rank, world, scene=None):
+    """Synthetic weights of the named architecture: rank 0 makes them, RCCL broadcast puts them on every GPU."""
     import torch
     from pytorchocr_amd.modeling.architectures import build_model
-    from pytorchocr_amd.utils.synth import synth_state_dict
     model = build_model(cfg)
     if rank == 0:
-        sd = synth_state_dict(load_contract(contract_name))
+        sd = det_state_dict(contract_name, scene)
         model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     model = model.to(device).eval()
     if world > 1:
@@ -126,33 +136,38 @@ def build_and_sync_weights(cfg, contract_name, device, rank, world):
     return model
 
 
-def det_cpu_baseline(n_img, H, W):
-    """The oracle (CPU restatement of the reference path: torch-CPU fp32 forward + C post-process with
-    cpp_speedup=True semantics) on a bounded sample of the same workload."""
+def det_cpu_baseline(n_img, H, W, det_model="r18", scene=True, tags=("model",)):
+    """The oracle (CPU restatement of the reference path: torch-CPU fp32 forward + C post-process with cpp_speedup=True semantics)
+    on a bounded sample of the same workload -- same checkpoint, same kind of input, the same maps post-processed as in the GPU step.
+    mbv3s: the reference has no reduced-precision mode, so configs[3] stands beside the fp32 forward."""
     import torch
     from oracle import dbpost, model_oracle
-    from pytorchocr_amd.utils.synth import synth_images, synth_prob_maps, synth_state_dict
+    from pytorchocr_amd.utils.synth import synth_images, synth_prob_maps, synth_scene_inputs
     torch.set_num_threads(min(16, os.cpu_count() or 1))            # the GPU box's CPU share for one GPU is 16 cores
-    sd = synth_state_dict(load_contract("det_r18_db"))
-    sd = {k: torch.from_numpy(v) for k, v in sd.items()}
-    x = torch.from_numpy(synth_images(1, 3, H, W, seed=2022))
+    _, contract_name, _, scene_name = DET_VARIANTS[det_model]
+    sd = {k: torch.from_numpy(v) for k, v in det_state_dict(contract_name, scene_name if scene else None).items()}
+    fwd = model_oracle.dbnet_forward
+    x = torch.from_numpy(synth_scene_inputs(1, H, W, seed=2022) if scene else synth_images(1, 3, H, W, seed=2022))
     stress = synth_prob_maps(1, H, W, seed=2022)[0]
-    model_oracle.dbnet_r18_forward(sd, x[:, :, :64, :64])          # warm-up of the thread pool
+    fwd(sd, x[:, :, :64, :64])                                     # warm-up of the thread pool
     t_model = t_post = 0.0
+    nbox = 0
     for _ in range(n_img):                                         # batch 1 each, as infer_det.py:85-103 does
         t0 = time.perf_counter()
-        maps = model_oracle.dbnet_r18_forward(sd, x)["maps"].numpy()
+        maps = fwd(sd, x)["maps"].numpy()
         t1 = time.perf_counter()
-        for m in (maps[0, 0], stress):                             # the net's own map + the text-like stress map
-            bm = dbpost.binarize(m, 0.3)
-            dbpost.boxes_from_bitmap(m, bm, 0.5, 1.7, W, H)
+        for t in tags:                                             # the net's own map and / or the text-like stress map
+            m = maps[0, 0] if t == "model" else stress
+            nbox += len(dbpost.boxes_from_bitmap(m, dbpost.binarize(m, 0.3), 0.5, 1.7, W, H))
         t2 = time.perf_counter()
         t_model += t1 - t0
-        t_post += (t2 - t1) / 2
+        t_post += t2 - t1
     total = t_model + t_post
     return {"value": round(n_img / total, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d images %dx%d, batch 1 each: torch-CPU fp32 forward %.3f s/img + C post-process %.4f s/img "
-                      "(single thread, like the GIL-bound reference extension)" % (n_img, H, W, t_model / n_img, t_post / n_img)}
+            "sample": "%d images %dx%d, batch 1 each: torch-CPU fp32 %s forward %.3f s/img + C post-process of the %s map%s %.4f s/img "
+                      "(%d boxes/img; single thread, like the GIL-bound reference extension)"
+                      % (n_img, H, W, det_model, t_model / n_img, " + ".join(tags), "s" if len(tags) > 1 else "", t_post / n_img,
+                         nbox // max(n_img, 1))}
 
 
 def crnn_cpu_baseline(n_lines):
@@ -189,33 +204,6 @@ def parallelism(what, world):
     return "%s x%d; %s; weight broadcast from rank 0 is the only collective" % (what, world, be)
 
 
-def mbv3s_cpu_baseline(n_img, H, W):
-    """configs[3] beside the CPU: the oracle's MobileNetV3-small DB forward in fp32 (the reference has no reduced-precision mode) +
-    the C post-process, batch 1 per image like infer_det.py"""
-    import torch
-    from oracle import dbpost, model_oracle
-    from pytorchocr_amd.utils.synth import synth_images, synth_prob_maps, synth_state_dict
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    sd = {k: torch.from_numpy(v) for k, v in synth_state_dict(load_contract("det_mbv3s_db")).items()}
-    x = torch.from_numpy(synth_images(1, 3, H, W, seed=2022))
-    stress = synth_prob_maps(1, H, W, seed=2022)[0]
-    model_oracle.dbnet_forward(sd, x[:, :, :64, :64])
-    t_model = t_post = 0.0
-    for _ in range(n_img):
-        t0 = time.perf_counter()
-        maps = model_oracle.dbnet_forward(sd, x)["maps"].numpy()
-        t1 = time.perf_counter()
-        for m in (maps[0, 0], stress):
-            dbpost.boxes_from_bitmap(m, dbpost.binarize(m, 0.3), 0.5, 1.7, W, H)
-        t2 = time.perf_counter()
-        t_model += t1 - t0
-        t_post += (t2 - t1) / 2
-    total = t_model + t_post
-    return {"value": round(n_img / total, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d images %dx%d, batch 1 each: torch-CPU fp32 MobileNetV3-small DB forward %.3f s/img + C post-process %.4f s/img "
-                      "(single thread)" % (n_img, H, W, t_model / n_img, t_post / n_img)}
-
-
 def ocr_cpu_baseline(n_img):
     """configs[4] beside the CPU, image by image and box by box as run_ocr.py:167-231 does: host resize + normalise, the oracle's
     DBNet++ r18 forward, the C post-process, sort_boxes, per box perspective crop -> gray -> resize/pad -> batch-1 CRNN forward ->
@@ -225,11 +213,11 @@ def ocr_cpu_baseline(n_img):
     import torch
     from oracle import ctc_oracle, dbpost, model_oracle
     from pytorchocr_amd.data.imaug import bgr_to_gray, resize_bilinear
-    from pytorchocr_amd.utils.synth import synth_brightness_detector_state_dict, synth_scene_images, synth_state_dict
+    from pytorchocr_amd.utils.synth import synth_scene_images, synth_state_dict
     from pytorchocr_amd.utils.utility import sort_boxes
     from pytorchocr_amd.utils.warp import get_part_img
     torch.set_num_threads(min(16, os.cpu_count() or 1))
-    det_sd = {k: torch.from_numpy(v) for k, v in synth_brightness_detector_state_dict(load_contract("detpp_r18_db"), use_asf=True).items()}
+    det_sd = {k: torch.from_numpy(v) for k, v in det_state_dict("detpp_r18_db", "detpp").items()}        # the checkpoint make_ocrer loads
     rec_sd = {k: torch.from_numpy(v) for k, v in synth_state_dict(load_contract("rec_vgg_bilstm_ctc")).items()}
     chars = ctc_oracle.load_characters(os.path.join(ROOT, "pytorchocr_amd", "utils", "char_dict_6623.txt"))
     imgs = synth_scene_images(n_img, 960, 1280, seed=100)
@@ -344,22 +332,28 @@ def run_det(args, rank, local, world, device):
     import torch
     from pytorchocr_amd.modeling import ops
     from pytorchocr_amd.postprocess import build_post_process
-    from pytorchocr_amd.utils.synth import synth_images, synth_prob_maps
+    from pytorchocr_amd.utils.synth import synth_images, synth_prob_maps, synth_scene_inputs
     B, H, W = args.batch or 32, 736, 1280
-    det_cfg, det_contract, gflop_img = DET_VARIANTS[args.det_model]
-    model = build_and_sync_weights(det_cfg, det_contract, device, rank, world)
+    det_cfg, det_contract, gflop_img, scene_name = DET_VARIANTS[args.det_model]
+    scene = args.weights == "scene"
+    model = build_and_sync_weights(det_cfg, det_contract, device, rank, world, scene=scene_name if scene else None)
     bf16 = args.dtype == "bf16"
     if bf16:
         model.set_compute_dtype("bf16")                  # BASELINE configs[3]: bf16 activations / weights, fp32 accumulation and maps
     post = build_post_process(DET_POST, dict(use_gpu=True, seed=2022))
     nd = min(args.distinct_images, B)
-    base = synth_images(nd, 3, H, W, seed=2022 + rank)               # nd distinct seeded images, tiled to the batch
+    # nd distinct seeded images, tiled to the batch: text-like scenes for the scene checkpoint (its maps then hold ~140 boxes per
+    # image and the step is the reference pipeline as it is: forward, post-process of the net's own maps), uniform noise otherwise
+    base = synth_scene_inputs(nd, H, W, seed=2022 + rank) if scene else synth_images(nd, 3, H, W, seed=2022 + rank)
     x = torch.from_numpy(base).to(device).repeat(B // nd + 1, 1, 1, 1)[:B].contiguous()
     shape_list = np.array([[H, W, 1.0, 1.0]] * B)
-    # Random weights give noise-like maps; so that the post-process does realistic work (~140 text boxes per
-    # image) text-like stress maps are post-processed inside the timed step as a SECOND pass
-    stress = torch.from_numpy(synth_prob_maps(nd, H, W, seed=7 + rank)).to(device).repeat(B // nd + 1, 1, 1)[:B, None].contiguous()
-    tags = [t for t in ("model", "stress") if args.post_input in (t, "both")]
+    # --weights random gives speckle maps; so that the post-process does realistic work there, text-like stress maps are
+    # post-processed inside the timed step as a SECOND pass (--post-input both, that mode's default)
+    post_input = args.post_input or ("model" if scene else "both")
+    tags = [t for t in ("model", "stress") if post_input in (t, "both")]
+    stress = None
+    if "stress" in tags:
+        stress = torch.from_numpy(synth_prob_maps(nd, H, W, seed=7 + rank)).to(device).repeat(B // nd + 1, 1, 1)[:B, None].contiguous()
 
     def step(pending):
         """forward of this batch; its post-process is queued on the post-process stream and collected one step later,
@@ -368,6 +362,7 @@ def run_det(args, rank, local, world, device):
         ev.record()
         with torch.no_grad():
             out = model(x)
+        last["maps"] = out["maps"]
         if fwd_events is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
@@ -382,6 +377,7 @@ def run_det(args, rank, local, world, device):
         return futs, [f.result() for f in pending], ev
 
     fwd_events = None
+    last = {}
     pending = []
     for _ in range(args.warmup):
         pending, _, _ = step(pending)
@@ -429,31 +425,36 @@ def run_det(args, rank, local, world, device):
     # post-process stage: device time of every call (HIP events on the post-process stream, inside the timed region, i.e. while
     # the next batch's convolutions share the chip), and the same call alone on an idle chip
     by_tag = {t: post_ms[i::len(tags)] for i, t in enumerate(tags)} if tags else {}
-    alone = []
-    if "stress" in tags or "model" in tags:
-        src = stress if "stress" in tags else None
-        if src is not None:
-            post.device_ms_log = alone
-            for _ in range(12):
+    # ... alone: on the text-like stress maps (the input rounds 1-2 quoted this stage on: clean bars, ~136 boxes per image) and on the
+    # last batch's own maps (the scene checkpoint's maps have ragged edges -- the read-out's residual -- and cost more)
+    alone = {}
+    if tags:
+        if stress is None:
+            stress = torch.from_numpy(synth_prob_maps(nd, H, W, seed=7 + rank)).to(device).repeat(B // nd + 1, 1, 1)[:B, None].contiguous()
+        for t, src in (("stress", stress), ("model", last["maps"])):
+            if t == "model" and "model" not in tags:
+                continue
+            post.device_ms_log = []
+            for _ in range(20):                                      # the workspace keeps its labelling route for eight calls after a change of input
                 post({"maps": src}, shape_list)
+            alone[t] = median(post.device_ms_log[10:])
             post.device_ms_log = None
-            alone = alone[2:]
     post_bytes = float(POST_BYTES_PER_PIXEL) * H * W * B
-    pk = "stress" if "stress" in tags else ("model" if tags else None)
     roofline_post = None
-    if pk:
-        ms_in = median(by_tag[pk])
-        ms_alone = median(alone) if alone else None
-        best = ms_alone or ms_in
+    if tags:
+        best = alone["stress"]
         roofline_post = {
             "bound": "hbm", "achieved": round(post_bytes / (best * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
             "frac": round(post_bytes / (best * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
             "traffic": (_profile_json("post_traffic.json") or {}).get("hbm_bytes_per_call"),
             "traffic_source": "profiles/post_traffic.json (rocprofv3 --pmc passes of tools/bench_post.py; per_kernel too): copied from the "
                               "committed profile, NOT measured in this run",
-            "stage": "DB post-process of %d maps %dx%d (%s maps): %d B/pixel accounting (SURVEY 8d) = %.1f MB per call / median device "
-                     "time of the call's kernels alone on the chip (HIP events on its stream)" % (B, H, W, pk, POST_BYTES_PER_PIXEL, post_bytes / 1e6),
-            "ms_per_call_alone": round(ms_alone, 4) if ms_alone else None,
+            "stage": "DB post-process of %d maps %dx%d: %d B/pixel accounting (SURVEY 8d) = %.1f MB per call / median device time of the "
+                     "call's kernels alone on the chip (HIP events on its stream), on the text-like stress maps (the same input as in "
+                     "rounds 1-2); frac_model_maps: the same on the timed step's own maps" % (B, H, W, POST_BYTES_PER_PIXEL, post_bytes / 1e6),
+            "ms_per_call_alone": round(best, 4),
+            "ms_per_call_alone_model_maps": round(alone["model"], 4) if "model" in alone else None,
+            "frac_model_maps": round(post_bytes / (alone["model"] * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4) if "model" in alone else None,
             "ms_per_call_overlapped": {t: round(median(v), 4) for t, v in by_tag.items()},
             "per_kernel": (_profile_json("post_traffic.json") or {}).get("per_kernel"),
         }
@@ -461,7 +462,7 @@ def run_det(args, rank, local, world, device):
     n_cpu = args.cpu_images if world == 1 else max(1, args.cpu_images // 2)
     cpu = None
     if args.cpu_images > 0:
-        cpu = mbv3s_cpu_baseline(n_cpu, H, W) if args.det_model == "mbv3s" else (det_cpu_baseline(n_cpu, H, W) if args.det_model == "r18" else None)
+        cpu = det_cpu_baseline(n_cpu, H, W, args.det_model, scene, tuple(tags) or ("model",))
     if bf16:
         fms = median([a.elapsed_time(b) for a, b in fwd_events])
         gbps = fwd_bytes / (fms * 1e-3) / 1e9
@@ -489,7 +490,11 @@ def run_det(args, rank, local, world, device):
         "config": {"workload": "DBNet %s %s, batch %d synthetic 736x1280 per GPU (%d distinct images tiled), HIP conv + HIP DBPostProcess "
                                "(BASELINE.json %s)" % (args.det_model, "bf16" if bf16 else "fp32", B, nd,
                                                        "configs[3]: batch 256 = 32 per GPU x 8" if bf16 else "configs[1]"),
-                   "global_batch": world * B, "post_input": args.post_input, "post_overlap": bool(args.overlap),
+                   "weights": ("scene checkpoint: seeded random-init weights in every backbone / neck layer and 62 of the head's 64 channels (22 of 24 for "
+                               "mbv3s); two head channels carry a linear read-out of the neck features fitted to the synthetic scenes' text map, "
+                               "so the net's own maps are text-like and the step is the reference pipeline as it is (forward, post-process of its maps)")
+                              if scene else "seeded random-init weights in every layer (the maps are speckle)",
+                   "global_batch": world * B, "post_input": post_input, "post_overlap": bool(args.overlap),
                    "boxes_per_image": {t: round(v / (B * args.steps), 1) for t, v in nbox.items()},
                    "parallelism": parallelism("image-sharded", world)},
         "roofline": roof, "roofline_post": roofline_post, "cpu_baseline": cpu,
@@ -607,10 +612,14 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 32 det / 512 crnn / 64 ocr)")
     ap.add_argument("--crnn-steps", type=int, default=-1, help="steps of the embedded CRNN measurement (default: --steps; 0 = skip it)")
     ap.add_argument("--distinct-images", type=int, default=32, help="distinct synthetic images / maps (tiled to the batch if fewer than it)")
-    ap.add_argument("--post-input", default="both", choices=["both", "stress", "model", "none"],
-                    help="maps post-processed inside the timed step: the model's own maps (true data flow; random weights "
-                         "give noise-like maps), text-like stress maps with ~140 boxes per image, or both (default: "
-                         "strictly more work than the real pipeline); none = forward only, a diagnostic that is NOT the metric")
+    ap.add_argument("--post-input", default=None, choices=["both", "stress", "model", "none"],
+                    help="maps post-processed inside the timed step: the model's own maps (the pipeline's data flow; default with "
+                         "--weights scene, whose maps hold ~140 boxes per image), text-like stress maps with ~140 boxes per image, or both "
+                         "(default with --weights random, whose own maps are speckle: strictly more work than the real pipeline); "
+                         "none = forward only, a diagnostic that is NOT the metric")
+    ap.add_argument("--weights", default="scene", choices=["scene", "random"],
+                    help="detector checkpoint: scene = random-init weights plus a fitted read-out in two head channels, so the maps of the "
+                         "synthetic scene images are text-like; random = random-init everywhere (speckle maps, rounds 1-2)")
     ap.add_argument("--det-model", default="r18", choices=sorted(DET_VARIANTS),
                     help="r18 = BASELINE configs[1] (the metric); r18pp (DB++ / ASF) and mbv3s (MobileNetV3-small) are the "
                          "other detectors of the hot path")

@@ -2596,6 +2596,7 @@ struct ptocr_dbpost {
     int timed;
     int *strip_runs;              // per image: run starts (both polarities) in the bottom strip, counted by binarize_kernel
     int strip_hint;               // run the bottom-strip labelling pass in the next call (see run_chain)
+    unsigned noise_hist;          // bit k: the call k + 1 calls ago met a noise-like image
     int *h_strip;                 // pinned: the strip's run-start counts of the last call
     int *zeroed;                  // ONE block cleared per call: flags | strip_totals | strip_runs | list_n | big_n (max_n ints each)
     long long *stamps;            // PTOCR_DBPOST_STAMPS=1: phase time stamps of the stage kernels (max_n * MAX_CAND * 16)
@@ -2623,6 +2624,7 @@ extern "C" int ptocr_dbpost_create(ptocr_dbpost_t *out, int max_n, int max_h, in
     PT_HIP(hipMalloc(&h->big_list, sizeof(int) * max_n * MAX_CAND));
     PT_HIP(hipHostMalloc(&h->h_strip, sizeof(int) * max_n));
     h->strip_hint = 1;
+    h->noise_hist = 1;
     h->flags = h->zeroed; h->strip_totals = h->zeroed + max_n; h->strip_runs = h->zeroed + 2 * max_n;
     if (getenv("PTOCR_DBPOST_STAMPS")) {
         PT_HIP(hipMalloc(&h->stamps, sizeof(long long) * 16 * (size_t)max_n * MAX_CAND));
@@ -2742,7 +2744,7 @@ static void run_chain(ptocr_dbpost *h, const float *d_maps, const uint8_t *d_bit
     Acc *w_acc = h->acc + (long)i0 * MAX_CAND;
     unsigned *w_pool = h->pool + i0 * h->pool_cap;
     // The strip pass pays on noise maps only (an image whose bottom 64 rows hold >= 1000 run starts); on text-like maps its four
-    // launches do nothing and cost ~20 us.  So it is launched when the PREVIOUS call on this workspace met such an image (or could
+    // launches do nothing and cost ~20 us.  So it is launched when one of the previous EIGHT calls on this workspace met such an image (or could
     // not count: caller's bitmap, dilation); the labels are the same either way, a first noise batch just takes the slower route once.
     // (Also tried: the 5-us single-block kernels -- chunk suffix sums, pool offsets, box compaction -- as "last block of the image"
     // tails of their predecessors: the ticket atomics and the lone tail block cost more than the launches saved, 0.504 against 0.490 ms.)
@@ -2860,8 +2862,13 @@ extern "C" int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, co
     PT_HIP(hipStreamSynchronize(s));
     for (int i = 0; i < N; i++) h_flags[i] &= 7;           // bit 3 is internal (deferred borders)
     if (!d_bitmap && !use_dilation) {
-        h->strip_hint = 0;
-        for (int i = 0; i < N; i++) h->strip_hint |= h->h_strip[i] >= MAX_CAND;
+        // the noise route stays on for eight calls after the last noise-like image: a workspace fed text-like and noise-like batches in
+        // turn (bench.py's two passes per step did exactly that) would otherwise take the wrong route every time -- one thread per word
+        // on a speckle map is 0.8-1.6 ms of merge, and the full-size labelling pass instead of the strip another 0.5 ms
+        int noisy = 0;
+        for (int i = 0; i < N; i++) noisy |= h->h_strip[i] >= MAX_CAND;
+        h->noise_hist = ((h->noise_hist << 1) | (unsigned)noisy) & 0xffu;
+        h->strip_hint = h->noise_hist != 0;
     }
     for (int i = 0; i < N; i++)
         if (h_flags[i] & 4) return fail("ptocr_db_postprocess: internal capacity exceeded on image %d (state pool %ld entries or hull "

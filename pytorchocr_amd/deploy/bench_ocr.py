@@ -3,9 +3,10 @@ recognise) over 64 source images of 1280x960, image-sharded over the ranks (no d
 only).  One step = `OCRer.run_batch` over this rank's shard, the u8 images already resident in HBM; every image's
 [box, text, prob] list is on the host when the step ends.
 
-Synthetic data: the detector carries the hand-made brightness checkpoint of utils/synth.py (its probability map is a soft
-threshold of the image brightness), the images are text-like scenes (~140 bright bars each), so the post-process, the crop
-stage and the CRNN see a realistic number of boxes; the CRNN has random-init weights (texts are gibberish, the work is real)."""
+Synthetic data: the detector carries the scene checkpoint of utils/synth.py (seeded random-init weights in every backbone /
+neck / ASF layer; two head channels hold a read-out of the neck features fitted to the scenes' text map), the images are
+text-like scenes (~140 bright bars each), so the post-process, the crop stage and the CRNN see a realistic number of boxes;
+the CRNN has random-init weights (texts are gibberish, the work is real)."""
 import json
 import os
 import time
@@ -19,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 def make_ocrer(device_index, rank=0, world=1):
     from ..parallel import broadcast_model_
     from ..utils.config import load_config
-    from ..utils.synth import synth_brightness_detector_state_dict, synth_state_dict
+    from ..utils.synth import load_scene_readout, synth_scene_state_dict, synth_state_dict
     from .run_ocr import OCRer
     cfgs = os.path.join(ROOT, "pytorchocr_amd", "configs")
     with open(os.path.join(ROOT, "tests", "golden", "state_dict_contract.json")) as f:
@@ -27,7 +28,7 @@ def make_ocrer(device_index, rank=0, world=1):
     ocr = OCRer(load_config(os.path.join(cfgs, "det", "det_r18_dbpp.yml")), None,
                 load_config(os.path.join(cfgs, "rec", "rec_vgg_bilstm_ctc.yml")), None, gpu_id=device_index, gpu_preprocess=True)
     if rank == 0:
-        det_sd = synth_brightness_detector_state_dict(contract["detpp_r18_db"], use_asf=True)
+        det_sd = synth_scene_state_dict(contract["detpp_r18_db"], *load_scene_readout("detpp"))
         ocr.det.deter.load_state_dict({k: torch.from_numpy(v) for k, v in det_sd.items()}, strict=True)
         rec_sd = synth_state_dict(contract["rec_vgg_bilstm_ctc"])
         ocr.rec.recer.load_state_dict({k: torch.from_numpy(v) for k, v in rec_sd.items()}, strict=True)

@@ -228,36 +228,67 @@ def synth_scene_inputs(n, h, w, seed=0):
     return np.ascontiguousarray(((img - mean) / std).astype(np.float32).transpose(0, 3, 1, 2))
 
 
-def synth_mbv3s_scene_state_dict(ref_shapes, readout, gain=14.0, level=0.45, seed=2022):
-    """A DBNet MobileNetV3-small checkpoint whose probability maps on synth_scene_inputs are TEXT-LIKE and cross both
-    post-process thresholds, with every backbone / neck layer carrying its random synth_state_dict weights (so reduced-precision
-    error of all those layers reaches the map, amplified by `gain`).  `readout` f32[9*C + 1] is a linear read-out of the 3x3
-    neighbourhood of the neck output (C = 96 channels, index c*9 + kh*3 + kw, last entry the intercept) fitted by
-    tools/gen_golden.py on the REFERENCE model's neck features to the scene's brightness (tests/golden/mbv3s_scene_readout.npz).
-    The head carries it: binarize.0 channel 0 = +readout, channel 1 = -readout (ReLU passes z as relu(z) - relu(-z)), BN bias
-    -+(intercept - level), both transposed convs replicate channels 0 / 1, the last one applies +-gain; the other 22 head channels
-    keep their random weights (a few 1e-2 of logit noise).  map ~ sigmoid(gain * (brightness_estimate - level))."""
+def synth_scene_state_dict(ref_shapes, readout, gain=14.0, level=0.45, seed=2022):
+    """A DBNet / DBNet++ checkpoint (any backbone: the read-out sits in the head) whose probability maps on synth_scene_inputs are
+    TEXT-LIKE and cross both post-process thresholds, with every backbone / neck layer carrying its random synth_state_dict weights
+    (so the error of all those layers reaches the map, amplified by `gain`).  `readout` is a linear read-out of the 3x3 neighbourhood
+    of the neck output (C channels: 96 for MobileNetV3-small, 256 for ResNet-18; row index c*9 + kh*3 + kw, last row the intercept)
+    fitted by tools/gen_golden.py on the REFERENCE model's neck features to the scene's text map
+    (tests/golden/{mbv3s,r18,detpp}_scene_readout.npz), in one of two forms:
+      f32[9C + 1]      one estimate per 1/4-resolution pixel (its 4x4 mean).  binarize.0 channel 0 = +readout, channel 1 = -readout
+                       (ReLU passes z as relu(z) - relu(-z)), BN bias -+(intercept - level), both transposed convs replicate channels
+                       0 / 1, the last one applies +-gain: map ~ sigmoid(gain * (estimate - level)) in 4x4 blocks.
+      f32[9C + 1, 16]  one estimate per FULL-resolution pixel of the 4x4 block, column (2a + a') * 4 + (2b + b') for the pixel
+                       (4y + 2a + a', 4x + 2b + b').  Estimate k travels in channels 2k / 2k + 1 (+-); binarize.3 hands it to
+                       sub-position (a, b) only and binarize.6 to (a', b') only, so each output pixel gets its own estimate (thin
+                       bars stay apart; needs 32 head channels, i.e. the 64-channel head of the ResNet detectors).
+    The remaining head channels (22 of 24, resp. 32 of 64) keep their random weights (a few 1e-2 of logit noise)."""
     out = synth_state_dict(ref_shapes, seed)
     c = ref_shapes["head.binarize.0.weight"][0][1]
+    mid = ref_shapes["head.binarize.0.weight"][0][0]
     readout = np.asarray(readout, np.float32)
-    assert readout.shape == (9 * c + 1,)
-    wr = readout[:-1].reshape(c, 3, 3)
-    out["head.binarize.0.weight"][0] = wr
-    out["head.binarize.0.weight"][1] = -wr
+    sub = readout.ndim == 2
+    assert readout.shape == ((9 * c + 1, 16) if sub else (9 * c + 1,))
+    cols = readout if sub else readout[:, None]
+    n = 2 * cols.shape[1]
+    assert n <= mid, "the sub-pixel read-out needs %d head channels, this head has %d" % (n, mid)
+    for k in range(cols.shape[1]):
+        wr = cols[:-1, k].reshape(c, 3, 3)
+        out["head.binarize.0.weight"][2 * k] = wr
+        out["head.binarize.0.weight"][2 * k + 1] = -wr
+        out["head.binarize.1.bias"][2 * k] = cols[-1, k] - np.float32(level)
+        out["head.binarize.1.bias"][2 * k + 1] = np.float32(level) - cols[-1, k]
     for bn in ("head.binarize.1", "head.binarize.4"):
-        out[bn + ".weight"][:2] = 1.0
-        out[bn + ".running_var"][:2] = 1.0
-        out[bn + ".running_mean"][:2] = 0.0
-        out[bn + ".bias"][:2] = 0.0
-    out["head.binarize.1.bias"][0] = readout[-1] - np.float32(level)
-    out["head.binarize.1.bias"][1] = np.float32(level) - readout[-1]
+        out[bn + ".weight"][:n] = 1.0
+        out[bn + ".running_var"][:n] = 1.0
+        out[bn + ".running_mean"][:n] = 0.0
+    out["head.binarize.4.bias"][:n] = 0.0
     w3 = out["head.binarize.3.weight"]                  # [Cin, Cout, 2, 2]
-    w3[:, :2] = 0.0
-    w3[:2, :] = 0.0
-    w3[0, 0] = 1.0
-    w3[1, 1] = 1.0
-    out["head.binarize.3.bias"][:2] = 0.0
-    out["head.binarize.6.weight"][0] = np.float32(gain)
-    out["head.binarize.6.weight"][1] = np.float32(-gain)
+    w3[:, :n] = 0.0
+    w3[:n, :] = 0.0
+    out["head.binarize.3.bias"][:n] = 0.0
+    w6 = out["head.binarize.6.weight"]                  # [Cin, 1, 2, 2]
+    w6[:n] = 0.0
+    for k in range(cols.shape[1]):
+        dy, dx = (k >> 2, k & 3) if sub else (0, 0)
+        for sgn, ch in ((1.0, 2 * k), (-1.0, 2 * k + 1)):
+            if sub:
+                w3[ch, ch, dy >> 1, dx >> 1] = 1.0
+                w6[ch, 0, dy & 1, dx & 1] = np.float32(sgn * gain)
+            else:
+                w3[ch, ch] = 1.0
+                w6[ch, 0] = np.float32(sgn * gain)
     out["head.binarize.6.bias"][:] = 0.0
     return out
+
+
+synth_mbv3s_scene_state_dict = synth_scene_state_dict
+
+
+def load_scene_readout(name):
+    """(readout, gain, level) of a scene checkpoint from the committed fixture tests/golden/<name>_scene_readout.npz
+    (name: mbv3s, r18, detpp); data only -- the fit was made by tools/gen_golden.py on the reference model"""
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden", name + "_scene_readout.npz")
+    r = np.load(path)
+    return r["readout"], float(r["gain"]), float(r["level"])

@@ -181,3 +181,44 @@ def test_reference_options_next_to_the_headline_configs(name, gold_dir, contract
         a = m(xb.repeat(2, 1, 1, 1))["maps"]
         b = m(xb[:1])["maps"]
     assert torch.equal(a[0], a[2]) and torch.equal(a[1], a[3]) and torch.equal(a[0], b[0])
+
+
+# ---- scene checkpoints (utils/synth.py: synth_scene_state_dict): random backbone / neck, a fitted read-out of the scene's brightness in
+# two head channels, logit gain 14 -- the maps are text-like, cross thresh and box_thresh, and produce boxes.  bench.py times these
+# checkpoints (configs[1], configs[4]); golden = outputs of the REFERENCE model (tools/gen_golden.py --scene-only).
+SCENES = {"r18": (DET_R18, "det_r18_db", "det_r18_scene_1x3x224x320.npz"),
+          "detpp": (dict(DET_R18, Neck=dict(DET_R18["Neck"], use_asf=True)), "detpp_r18_db", "detpp_r18_scene_1x3x224x320.npz")}
+
+
+@pytest.mark.parametrize("which", sorted(SCENES))
+def test_scene_checkpoint_maps_and_boxes_against_the_reference(which, gold_dir, contract):
+    from oracle import dbpost
+    from pytorchocr_amd.modeling.architectures import build_model
+    from pytorchocr_amd.postprocess import build_post_process
+    from pytorchocr_amd.utils.synth import load_scene_readout, synth_scene_inputs, synth_scene_state_dict
+    cfg, key, fixture = SCENES[which]
+    g = np.load(os.path.join(gold_dir, fixture))
+    sd = synth_scene_state_dict(contract[key], *load_scene_readout(which))
+    m = build_model(dict(cfg, return_all_feats=True))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.to("cuda:0").eval()
+    h, w = 224, 320
+    x = torch.from_numpy(synth_scene_inputs(1, h, w, seed=int(g["seed"]))).cuda()
+    with torch.no_grad():
+        y = m(x)
+    ref = g["maps"]
+    # the comparison means something: the reference's map lives on both sides of both thresholds
+    assert ref.max() - ref.min() > 0.99 and 0.15 <= (ref > 0.3).mean() <= 0.8 and 0.15 <= (ref > 0.5).mean() <= 0.8
+    for got, exp in ((y["neck_out"].cpu().numpy()[:, :, ::4, ::4], g["neck_sub"]), (y["backbone_out"][0].cpu().numpy()[:, :, ::4, ::4], g["c2_sub"]),
+                     (y["backbone_out"][3].cpu().numpy(), g["c5"])):
+        assert np.abs(got - exp).max() <= 1e-4 * np.abs(exp).max()
+    maps = y["maps"].cpu().numpy()
+    assert np.abs(maps - ref).max() <= 1e-4, np.abs(maps - ref).max()         # north_star's fp32 bar, gain 14 included
+    assert ((maps > 0.3) != (ref > 0.3)).mean() <= 1e-4
+    # boxes: the HIP post-process on the HIP maps against the oracle pipeline on the REFERENCE's maps
+    post = build_post_process(dict(name="DBPostProcess", thresh=0.3, box_thresh=0.5, unclip_ratio=1.7, cpp_speedup=True), {})
+    got = post({"maps": y["maps"]}, np.array([[h, w, 1.0, 1.0]]))[0]["points"]
+    exp = dbpost.boxes_from_bitmap(ref[0, 0], dbpost.binarize(ref[0, 0], 0.3), 0.5, 1.7, w, h).astype(np.int16)
+    assert len(exp) >= 6, len(exp)
+    same = sum(any(np.array_equal(a, b) for b in exp) for a in got)
+    assert abs(len(got) - len(exp)) <= 1 and same >= len(exp) - 1, (len(got), len(exp), same)
