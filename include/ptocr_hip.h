@@ -87,6 +87,13 @@ int ptocr_conv3x3_wino4_f32(const float *d_x, const float *d_u, const float *d_b
                             int N, int H, int W, int Cin, int Cout, int cout_store, int relu, int res_mode, int res_ldc,
                             int out_ldc, int out_coff, int up, void *stream);
 long ptocr_conv3x3_wino4_patches(int N, int H, int W);
+/* Experiment, not the fp32 path (the host enables it with PTOCR_WINO_SPLIT=1; off by default): ptocr_conv3x3_wino4_f32 with
+ * two-piece bf16 operands on the bf16 matrix pipe, fp32 accumulate -- x = h + m, h = bf16(x), m = bf16(x - h); a b becomes
+ * (a_h + a_m)(b_h + b_m), 16 mantissa bits per operand.  d_u: the packing above with every fp32 U replaced by the dword
+ * bf16(U) | bf16(U - bf16(U)) << 16.  Everything else as ptocr_conv3x3_wino4_f32. */
+int ptocr_conv3x3_wino4_split_f32(const float *d_x, const float *d_u, const float *d_bias, const float *d_res, float *d_y,
+                                  int N, int H, int W, int Cin, int Cout, int cout_store, int relu, int res_mode, int res_ldc,
+                                  int out_ldc, int out_coff, int up, void *stream);
 /* ResNet stem: conv 7x7 / stride 2 / pad 3 of an RGB image stored as f32[N,H,W,4] (4th channel ignored) -> f32[N,Ho,Wo,64],
  * Ho = (H-1)/2+1, Wo = (W-1)/2+1, + bias (folded BN) + optional ReLU (det_resnet.py:193-196).  d_w: f32[7][22][64],
  * w[ky][kx*3 + c][cout], row [ky][21] all zero (K runs over 7 x 22 = 154 instead of the generic kernel's 7*7*4 = 196). */

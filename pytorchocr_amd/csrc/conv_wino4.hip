@@ -35,6 +35,12 @@ namespace ptocr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// (bf16(x), bf16(x)) in one dword, round to nearest even
+__device__ __forceinline__ unsigned cvt_pk_same(float x) { const bf16x2_t v = {(__bf16)x, (__bf16)x}; return __builtin_bit_cast(unsigned, v); }
 
 // packed fp32 VALU ops (two lanes of math per instruction); the compiler scalarises <2 x float> arithmetic whose halves come from
 // separate LDS reads, so these are spelled out.  c: wave-uniform coefficient pair in SGPRs.
@@ -70,7 +76,14 @@ struct Wino4Args {
 };
 
 // MODE: 0 plain, 1 pre-ReLU residual add, 2 nearest-upsample replication (compile-time: the epilogue stays free of dead code)
-template <int TXN, int TYN, int TN, int MODE>
+// SPLIT (experiment, ptocr_conv3x3_wino4_split_f32): the 36 GEMMs on the bf16 matrix pipe with two-piece operands.  x = h + m,
+// h = bf16(x), m = bf16(x - h) (16 mantissa bits in all); a product a b becomes a_h (b_h + b_m) + a_m (b_h + b_m), fp32 accumulate:
+// two v_mfma_f32_32x32x8_bf16_1k (32 cycles each) per 4-channel chunk and accumulator tile instead of two v_mfma_f32_32x32x2_f32
+// (64 cycles each).  A lane half's four k slots are (c0, c0, c1, c1) of its two channels: the A operand is (h0, h0, h1, h1) in the
+// first pass and (m0, m0, m1, m1) in the second, the B operand (b_h(c0), b_m(c0), b_h(c1), b_m(c1)) in both -- the host packs the
+// weights that way, two bf16 in the place of each fp32, so the fragment loads and their registers do not change.  What is left out
+// (the third pieces: relative 2^-17 per operand) is 30x the rounding of an fp32 product: NOT the fp32 path, an opt-in.
+template <int TXN, int TYN, int TN, int MODE, bool SPLIT = false>
 __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args p) {
     constexpr int NTV = TN * TXN * TYN;             // tiles in use (<= 32)
     constexpr int PW = 4 * TXN + 2, PH = 4 * TYN + 2, NPX = TN * PW * PH;
@@ -181,9 +194,21 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args p) {
     f32x16 acc[3][2];
     f32x2 fa[3];                                // likewise one set: xi 0, 1 refreshed after the barrier, xi 2 after its last MFMA
     auto frag_load = [&](int e, int buf) { fa[e] = *reinterpret_cast<const f32x2 *>(Vb + buf * W4_V + f_off + e * 2 * W4_VH); };
-    auto mfma_g = [&](int g) {                                 // MFMA g of 12 of a chunk: xi e, k step t, n block nb
+    u32x2 sa_h, sa_m;                           // SPLIT: the two pieces of the current xi's A fragment
+    auto mfma_g = [&](int g) {                                 // MFMA g of 12 of a chunk: xi e, k step t (SPLIT: piece t), n block nb
         const int e = g >> 2, t = (g >> 1) & 1, nb = g & 1;
-        acc[e][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e][t], fb[e][2 * nb + t], acc[e][nb], 0, 0, 0);
+        if (!SPLIT) {
+            acc[e][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e][t], fb[e][2 * nb + t], acc[e][nb], 0, 0, 0);
+        } else {
+            if ((g & 3) == 0) {
+                sa_h[0] = cvt_pk_same(fa[e][0]); sa_h[1] = cvt_pk_same(fa[e][1]);
+                sa_m[0] = cvt_pk_same(fa[e][0] - __builtin_bit_cast(float, sa_h[0] & 0xffff0000u));
+                sa_m[1] = cvt_pk_same(fa[e][1] - __builtin_bit_cast(float, sa_h[1] & 0xffff0000u));
+            }
+            const f32x2 bq = {fb[e][2 * nb], fb[e][2 * nb + 1]};
+            acc[e][nb] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, t ? sa_m : sa_h), __builtin_bit_cast(s16x4, bq),
+                                                                 acc[e][nb], 0, 0, 0);
+        }
     };
 
     // ---- head
@@ -338,7 +363,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args p) {
     if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 3] = __builtin_readcyclecounter();
 }
 
-template <int TXN, int TYN, int TN, int MODE>
+template <int TXN, int TYN, int TN, int MODE, bool SPLIT>
 static int launch_wino4m(Wino4Args a, hipStream_t stream) {
     a.tiles_x = cdiv(a.W, 4 * TXN); a.tiles_y = cdiv(a.H, 4 * TYN);
     const long total = (long)cdiv(a.N, TN) * a.tiles_x * a.tiles_y * (a.Cout / 64);
@@ -347,19 +372,24 @@ static int launch_wino4m(Wino4Args a, hipStream_t stream) {
     const size_t lds = sizeof(float) * (2 * W4_V + 2 * w4_raw_floats(TXN, TYN, TN));
     static bool attr_set = false;
     if (!attr_set) {
-        const void *fn = reinterpret_cast<const void *>(&conv_wino4_kernel<TXN, TYN, TN, MODE>);
+        const void *fn = reinterpret_cast<const void *>(&conv_wino4_kernel<TXN, TYN, TN, MODE, SPLIT>);
         PT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_wino4_kernel<TXN, TYN, TN, MODE>), dim3((unsigned)a.total), dim3(W4_THREADS), lds, stream, a);
+    hipLaunchKernelGGL((conv_wino4_kernel<TXN, TYN, TN, MODE, SPLIT>), dim3((unsigned)a.total), dim3(W4_THREADS), lds, stream, a);
     return launch_ok("conv_wino4_kernel");
 }
 
 template <int TXN, int TYN, int TN>
-static int launch_wino4(const Wino4Args &a, hipStream_t stream) {
-    if (a.res_mode == PTOCR_RES_ADD_PRE_RELU) return launch_wino4m<TXN, TYN, TN, 1>(a, stream);
-    if (a.up > 1) return launch_wino4m<TXN, TYN, TN, 2>(a, stream);
-    return launch_wino4m<TXN, TYN, TN, 0>(a, stream);
+static int launch_wino4(const Wino4Args &a, hipStream_t stream, bool split) {
+    if (split) {
+        if (a.res_mode == PTOCR_RES_ADD_PRE_RELU) return launch_wino4m<TXN, TYN, TN, 1, true>(a, stream);
+        if (a.up > 1) return launch_wino4m<TXN, TYN, TN, 2, true>(a, stream);
+        return launch_wino4m<TXN, TYN, TN, 0, true>(a, stream);
+    }
+    if (a.res_mode == PTOCR_RES_ADD_PRE_RELU) return launch_wino4m<TXN, TYN, TN, 1, false>(a, stream);
+    if (a.up > 1) return launch_wino4m<TXN, TYN, TN, 2, false>(a, stream);
+    return launch_wino4m<TXN, TYN, TN, 0, false>(a, stream);
 }
 
 }  // namespace ptocr
@@ -390,9 +420,9 @@ extern "C" long ptocr_conv3x3_wino4_patches(int N, int H, int W) { return wino4_
 // f32[Cout/64][Cin/4][12][3][64][4]: wave w, xi = 3w + e, lane (n = lane & 31, h = lane >> 5) holds
 // {U[xi][c0+2h][n], U[xi][c0+2h+1][n], U[xi][c0+2h][32+n], U[xi][c0+2h+1][32+n]}, c0 = 4 chunk, n relative to the 64-block.
 // Everything else as ptocr_conv3x3_wino_f32.
-extern "C" int ptocr_conv3x3_wino4_f32(const float *d_x, const float *d_u, const float *d_bias, const float *d_res, float *d_y,
-                                       int N, int H, int W, int Cin, int Cout, int cout_store, int relu, int res_mode, int res_ldc,
-                                       int out_ldc, int out_coff, int up, void *stream) {
+static int wino4_run(bool split, const float *d_x, const float *d_u, const float *d_bias, const float *d_res, float *d_y,
+                     int N, int H, int W, int Cin, int Cout, int cout_store, int relu, int res_mode, int res_ldc,
+                     int out_ldc, int out_coff, int up, void *stream) {
     PT_CHECK(d_x && d_u && d_bias && d_y, "ptocr_conv3x3_wino4_f32: null argument");
     PT_CHECK(N > 0 && H > 0 && W > 0, "ptocr_conv3x3_wino4_f32: empty tensor");
     PT_CHECK(Cin % 16 == 0 && Cout % 64 == 0, "ptocr_conv3x3_wino4_f32: need Cin %% 16 == 0 and Cout %% 64 == 0");
@@ -415,12 +445,27 @@ extern "C" int ptocr_conv3x3_wino4_f32(const float *d_x, const float *d_u, const
     PT_CHECK(a.x_bytes < (1L << 31) && a.u_bytes < (1L << 31) && a.y_bytes < (1L << 31) && a.res_bytes < (1L << 31),
              "ptocr_conv3x3_wino4_f32: tensor larger than 2 GiB");
     switch (wino4_best_geo(N, H, W)) {
-        case 1: return launch_wino4<4, 8, 1>(a, (hipStream_t)stream);
-        case 2: return launch_wino4<5, 6, 1>(a, (hipStream_t)stream);
-        case 3: return launch_wino4<4, 4, 2>(a, (hipStream_t)stream);
-        case 4: return launch_wino4<8, 2, 2>(a, (hipStream_t)stream);
-        case 5: return launch_wino4<4, 2, 4>(a, (hipStream_t)stream);
-        case 6: return launch_wino4<7, 1, 4>(a, (hipStream_t)stream);
-        default: return launch_wino4<8, 4, 1>(a, (hipStream_t)stream);
+        case 1: return launch_wino4<4, 8, 1>(a, (hipStream_t)stream, split);
+        case 2: return launch_wino4<5, 6, 1>(a, (hipStream_t)stream, split);
+        case 3: return launch_wino4<4, 4, 2>(a, (hipStream_t)stream, split);
+        case 4: return launch_wino4<8, 2, 2>(a, (hipStream_t)stream, split);
+        case 5: return launch_wino4<4, 2, 4>(a, (hipStream_t)stream, split);
+        case 6: return launch_wino4<7, 1, 4>(a, (hipStream_t)stream, split);
+        default: return launch_wino4<8, 4, 1>(a, (hipStream_t)stream, split);
     }
+}
+
+extern "C" int ptocr_conv3x3_wino4_f32(const float *d_x, const float *d_u, const float *d_bias, const float *d_res, float *d_y,
+                                       int N, int H, int W, int Cin, int Cout, int cout_store, int relu, int res_mode, int res_ldc,
+                                       int out_ldc, int out_coff, int up, void *stream) {
+    return wino4_run(false, d_x, d_u, d_bias, d_res, d_y, N, H, W, Cin, Cout, cout_store, relu, res_mode, res_ldc, out_ldc, out_coff, up, stream);
+}
+
+// Experiment (PTOCR_WINO_SPLIT=1 on the host side, off by default): the same convolution with two-piece bf16 operands on the bf16
+// matrix pipe (see conv_wino4_kernel, SPLIT).  d_u: the same packing as ptocr_conv3x3_wino4_f32 with every fp32 U replaced by the dword
+// bf16(U) | bf16(U - bf16(U)) << 16.  Everything else as ptocr_conv3x3_wino4_f32.
+extern "C" int ptocr_conv3x3_wino4_split_f32(const float *d_x, const float *d_u, const float *d_bias, const float *d_res, float *d_y,
+                                             int N, int H, int W, int Cin, int Cout, int cout_store, int relu, int res_mode, int res_ldc,
+                                             int out_ldc, int out_coff, int up, void *stream) {
+    return wino4_run(true, d_x, d_u, d_bias, d_res, d_y, N, H, W, Cin, Cout, cout_store, relu, res_mode, res_ldc, out_ldc, out_coff, up, stream);
 }

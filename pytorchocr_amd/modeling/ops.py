@@ -15,6 +15,7 @@ PROFILE_LABELS = None                          # optional list: one text label p
 # 3x3 / stride 1 layers run as Winograd F(2x2,3x3) unless PTOCR_WINOGRAD=0 (then the direct implicit GEMM runs them)
 import os as _os
 USE_WINOGRAD = _os.environ.get("PTOCR_WINOGRAD", "1") != "0"
+WINO_SPLIT = _os.environ.get("PTOCR_WINO_SPLIT", "0") == "1"       # experiment: F(4x4) Winograd with two-piece bf16 operands (NOT the fp32 path)
 WINO4_MODE = _os.environ.get("PTOCR_WINO4", "auto")        # "0": F(2x2) only, "1": F(4x4) wherever it applies, else by cost
 WINO_COST = [2560, 14000, 2990, 23500]                     # cycles: F(2x2) per chunk / fixed, F(4x4) per chunk / fixed
 # the 7x7 / stride 2 RGB stem runs in its own kernel unless PTOCR_STEM_KERNEL=0 (then the generic implicit GEMM runs it)
@@ -138,6 +139,15 @@ class PackedConv:
             U6 = U6.reshape(cw // 64, 2, 32, cin // 4, 2, 2, 12, 3)               # [ct, nb, n, chunk, h, t, w, e]
             U6 = U6.permute(0, 3, 6, 7, 4, 2, 1, 5)                                # [ct, chunk, w, e, h, n, nb, t]
             self.wino4_u = U6.contiguous().float().to(device)
+            # experiment (PTOCR_WINO_SPLIT=1): the same layout with two bf16 pieces in the place of each fp32 -- bf16(U) in the low half,
+            # bf16(U - bf16(U)) in the high half (ptocr_conv3x3_wino4_split_f32)
+            self.wino4_us = None
+            if WINO_SPLIT:
+                u32 = U6.contiguous().float()
+                hi = u32.to(torch.bfloat16)
+                mid = (u32 - hi.float()).to(torch.bfloat16)
+                word = hi.view(torch.int16).to(torch.int32).bitwise_and(0xffff) | (mid.view(torch.int16).to(torch.int32) << 16)
+                self.wino4_us = word.view(torch.float32).contiguous().to(device)
 
 
 class PackedConvT2x2:
@@ -238,8 +248,9 @@ def conv2d(x, pc, res=None, res_mode=RES_NONE, out=None, out_up=1, out_coff=0, s
         if PROFILE is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        fn = _lib.lib().ptocr_conv3x3_wino4_f32 if four else _lib.lib().ptocr_conv3x3_wino_f32
-        _lib.check(fn(_lib.ptr(x), _lib.ptr(pc.wino4_u if four else pc.wino_u), _lib.ptr(pc.wino_b),
+        split = four and getattr(pc, "wino4_us", None) is not None
+        fn = (_lib.lib().ptocr_conv3x3_wino4_split_f32 if split else _lib.lib().ptocr_conv3x3_wino4_f32) if four else _lib.lib().ptocr_conv3x3_wino_f32
+        _lib.check(fn(_lib.ptr(x), _lib.ptr((pc.wino4_us if split else pc.wino4_u) if four else pc.wino_u), _lib.ptr(pc.wino_b),
                       _lib.ptr(res) if res is not None else C.c_void_p(0), _lib.ptr(out),
                       N, H, W, Cin, pc.wino_cout, cs, int(pc.relu), res_mode,
                       res.shape[3] if res is not None else 0, out.shape[3], out_coff,
