@@ -25,6 +25,9 @@
 // (optionally replicated up x up: the FPN's nearest upsample into the concat buffer).
 #include "common.h"
 
+#ifndef W4_RAW_SLOT
+#define W4_RAW_SLOT 0       // MFMA slot of a chunk at which the raw-patch refill (global loads / LDS stores of two pieces) is issued
+#endif
 #ifndef W4_DBG
 #define W4_DBG 0            // timing experiments only (PTOCR_EXTRA_HIPCC_FLAGS=-DW4_DBG=n): 1 no global stores, 2 no consumer, 4 no exchange writes,
                             // 8 no input transform, 16 no weight-fragment loads, 32 no raw refill, 64 no transform math (LDS traffic kept)
@@ -253,10 +256,11 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args p) {
                 mfma_g(g);
                 if (g == 3 && !(W4_DBG & 16)) u_gload(0, chunk + 1);
                 if (g == 7 && !(W4_DBG & 16)) u_gload(1, chunk + 1);
-                if (g < 2 && !(W4_DBG & 32)) {
-                    if (q == 0) raw_gload1(S + 1, g);
-                    if (q == 1) { raw_lstore1(sp ^ 1, g); if (g + 2 < NPIECE) raw_gload1(S + 1, g + 2); }
-                    if (q == 2 && g + 2 < NPIECE) raw_lstore1(sp ^ 1, g + 2);
+                if (g >= W4_RAW_SLOT && g < W4_RAW_SLOT + 2 && !(W4_DBG & 32)) {
+                    const int gi = g - W4_RAW_SLOT;
+                    if (q == 0) raw_gload1(S + 1, gi);
+                    if (q == 1) { raw_lstore1(sp ^ 1, gi); if (gi + 2 < NPIECE) raw_gload1(S + 1, gi + 2); }
+                    if (q == 2 && gi + 2 < NPIECE) raw_lstore1(sp ^ 1, gi + 2);
                 }
                 if (!(W4_DBG & 8)) {
                     if (g == 2 || g == 4 || g == 6) tr_col2(roff, (g - 2) >> 1);
