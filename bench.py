@@ -490,9 +490,11 @@ def run_det(args, rank, local, world, device):
         "config": {"workload": "DBNet %s %s, batch %d synthetic 736x1280 per GPU (%d distinct images tiled), HIP conv + HIP DBPostProcess "
                                "(BASELINE.json %s)" % (args.det_model, "bf16" if bf16 else "fp32", B, nd,
                                                        "configs[3]: batch 256 = 32 per GPU x 8" if bf16 else "configs[1]"),
-                   "weights": ("scene checkpoint: seeded random-init weights in every backbone / neck layer and 62 of the head's 64 channels (22 of 24 for "
-                               "mbv3s); two head channels carry a linear read-out of the neck features fitted to the synthetic scenes' text map, "
-                               "so the net's own maps are text-like and the step is the reference pipeline as it is (forward, post-process of its maps)")
+                   "weights": ("scene checkpoint: seeded random-init weights in every backbone / neck layer and in %s of the head's channels; the other "
+                               "%s carry a linear read-out of the neck features (%s) fitted to the synthetic scenes' text map and a logit gain of 14, so the "
+                               "net's own maps are text-like and the step is the reference pipeline as it is (forward, post-process of its maps)"
+                               % (("22 of 24", "2", "one estimate per 4x4 block") if args.det_model == "mbv3s" else
+                                  ("32 of 64", "32", "16 estimates, one per pixel of the 4x4 output block")))
                               if scene else "seeded random-init weights in every layer (the maps are speckle)",
                    "global_batch": world * B, "post_input": post_input, "post_overlap": bool(args.overlap),
                    "boxes_per_image": {t: round(v / (B * args.steps), 1) for t, v in nbox.items()},
