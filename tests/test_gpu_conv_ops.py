@@ -1,4 +1,6 @@
 """HIP conv / pool / layout kernels against plain torch fp32 CPU ops on the same seeded inputs (-m gpu)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -454,3 +456,50 @@ def test_conv_on_tensors_beyond_2gib_runs_as_half_batches():
     assert len(labels) >= 2 and all(l.startswith("wino") for l in labels), labels
     for i in (0, 2, 4):
         assert torch.equal(y[i:i + 1], ops.conv2d(x[i:i + 1].contiguous(), pc))
+
+
+@pytest.mark.parametrize("seed", range(6 + int(os.environ.get("PTOCR_CONV_FUZZ", "0"))))      # PTOCR_CONV_FUZZ=n: n more seeds
+def test_conv_random_shapes_against_torch(seed):
+    """random layer shapes through ops.conv2d against torch fp32: 3x3 / s1 (whichever Winograd form the cost model picks, with the
+    residual and the upsampled concat-slice store), 3x3 / s2 and 1x1 on the generic and the LDS-resident-weights kernels"""
+    from pytorchocr_amd.modeling import ops
+    rng = np.random.default_rng(7000 + seed)
+    dev = _dev()
+    kind = int(rng.integers(0, 3))                                   # 0: 3x3 s1, 1: 3x3 s2, 2: 1x1
+    N = int(rng.integers(1, 6))
+    H, W = int(rng.integers(3, 70)), int(rng.integers(3, 90))
+    Cin = int(rng.choice([16, 32, 48, 64, 96, 128, 256]))
+    Cout = int(rng.choice([24, 32, 64, 96, 128, 192, 256]))
+    k, stride, pad = (3, 1, 1) if kind == 0 else ((3, 2, 1) if kind == 1 else (1, 1, 0))
+    conv = nn.Conv2d(Cin, Cout, k, stride, pad, bias=False)
+    bn = nn.BatchNorm2d(Cout).eval()
+    with torch.no_grad():
+        conv.weight.copy_(_rand(Cout, Cin, k, k, seed=11 + seed) * (3.0 / (Cin * k * k)) ** 0.5)
+        bn.weight.copy_(_rand(Cout, seed=3) * 0.4 + 1); bn.bias.copy_(_rand(Cout, seed=4) * 0.2)
+        bn.running_mean.copy_(_rand(Cout, seed=5) * 0.2); bn.running_var.copy_(_rand(Cout, seed=6) * 0.5 + 1)
+    relu = bool(rng.integers(0, 2))
+    x = _rand(N, Cin, H, W, seed=70 + seed)
+    with torch.no_grad():
+        pre = bn(conv(x))
+        ref = F.relu(pre) if relu else pre
+    pc = ops.PackedConv(conv, bn, dev, relu=relu)                   # input channels padded as the models pad them (zeros)
+    xp = torch.zeros(N, H, W, pc.cin)
+    xp[..., :Cin] = _nhwc(x)
+    xd = xp.to(dev)
+    tol = 3e-5 * max(1.0, ref.abs().max().item())
+    y = ops.conv2d(xd, pc).cpu()
+    assert y.shape[3] >= Cout and float(y[..., Cout:].abs().max() if y.shape[3] > Cout else 0.0) == 0.0
+    assert (y[..., :Cout].permute(0, 3, 1, 2) - ref).abs().max().item() <= tol, (kind, N, H, W, Cin, Cout)
+    if kind == 0 and relu:
+        res = _rand(N, Cout, H, W, seed=90 + seed)
+        rp = torch.zeros(N, H, W, y.shape[3]); rp[..., :Cout] = _nhwc(res)
+        y = ops.conv2d(xd, pc, res=rp.to(dev), res_mode=ops.RES_ADD_PRE_RELU).cpu()
+        assert (y[..., :Cout].permute(0, 3, 1, 2) - F.relu(pre + res)).abs().max().item() <= tol, ("res", N, H, W, Cin, Cout)
+        if Cout % 4 == 0:
+            up = int(rng.choice([1, 2, 4]))
+            big = torch.full((N, H * up, W * up, Cout + 64), 3.0, device=dev)
+            ops.conv2d(xd, pc, out=big, out_up=up, out_coff=32, store=Cout)
+            big = big.cpu()
+            exp = ref.repeat_interleave(up, 2).repeat_interleave(up, 3)
+            assert (big[..., 32:32 + Cout].permute(0, 3, 1, 2) - exp).abs().max().item() <= tol, ("up", up, N, H, W, Cin, Cout)
+            assert float((big[..., :32] - 3).abs().max()) == 0 and float((big[..., 32 + Cout:] - 3).abs().max()) == 0
