@@ -160,3 +160,54 @@ def test_gpu_preprocess_and_crops_against_the_cv2_oracle():
         exp = np.zeros((32, 320), np.float32)
         exp[:, :rw] = (r / np.float32(255) - np.float32(0.5)) / np.float32(0.5)
         assert np.array_equal(x4[i, :, :, 0], exp)
+
+
+@pytest.mark.parametrize("seed", range(8 + int(os.environ.get("PTOCR_CV2_FUZZ", "0"))))        # PTOCR_CV2_FUZZ=n: n more seeds
+def test_gpu_preprocess_random_sizes_against_the_cv2_oracle(seed):
+    """random source / target sizes (up- and down-scaling, the exact 2x route, 1-pixel-wide targets) and random quadrilaterals through
+    the HIP pre-process and crop kernels, bit for bit against oracle/cv2_oracle.py"""
+    from oracle import cv2_oracle as cvo
+    from pytorchocr_amd.data.gpu_preprocess import det_preprocess, rec_preprocess, warp_crops
+    rng = np.random.default_rng(8000 + seed)
+    dev = torch.device("cuda:0")
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    h, w = int(rng.integers(20, 90)), int(rng.integers(20, 110))
+    if rng.uniform() < 0.25:
+        rh, rw = 32 * max(1, h // 64), 32 * max(1, w // 64)
+        h, w = 2 * rh, 2 * rw                                        # exactly half: cv2's 2x2 area route
+    else:
+        rh, rw = 32 * int(rng.integers(1, 4)), 32 * int(rng.integers(1, 5))
+    img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    x4 = det_preprocess(img, (rh, rw), mean, std, dev, swap_rb=True).cpu().numpy()[0]
+    rs = cvo.resize_linear_u8(np.ascontiguousarray(img[:, :, ::-1]), (rw, rh)).astype(np.float32)
+    exp = (torch.from_numpy(rs).div(255) - torch.tensor(mean)) / torch.tensor(std)
+    assert np.array_equal(x4[:, :, :3], exp.numpy()), ("resize", h, w, rh, rw)
+    boxes = []
+    for _ in range(int(rng.integers(1, 5))):
+        cx, cy = rng.uniform(8, w - 8), rng.uniform(8, h - 8)
+        bw, bh = rng.uniform(3, max(4.0, w / 2)), rng.uniform(2, max(3.0, h / 3))
+        th = rng.uniform(-0.6, 0.6)
+        c, s_ = np.cos(th), np.sin(th)
+        q = np.array([[-bw / 2, -bh / 2], [bw / 2, -bh / 2], [bw / 2, bh / 2], [-bw / 2, bh / 2]]) @ np.array([[c, s_], [-s_, c]]) + [cx, cy]
+        q = np.clip(np.rint(q), [0, 0], [w - 1, h - 1])               # the post-process clamps its boxes to the image (db_postprocess.cpp:303-310)
+        if q[:, 0].max() - q[:, 0].min() < 2 or q[:, 1].max() - q[:, 1].min() < 2:
+            continue
+        boxes.append(q.astype(np.int16))
+    if not boxes:
+        boxes.append(np.array([[2, 2], [w - 3, 3], [w - 4, h - 3], [3, h - 4]], np.int16))
+    buf, metas = warp_crops(torch.from_numpy(img).to(dev), boxes)
+    crops = []
+    for b, (off, ch, cw) in zip(boxes, metas):
+        c = cvo.get_part_img(img, b)
+        if c.shape[0] >= 1.5 * c.shape[1]:
+            c = np.rot90(c, 1)
+        crops.append(np.ascontiguousarray(c))
+        assert (ch, cw) == c.shape[:2] and np.array_equal(buf[off:off + ch * cw * 3].cpu().numpy().reshape(ch, cw, 3), c), ("crop", b.tolist())
+    x4 = rec_preprocess(buf, metas, [1, 32, 320], dev).cpu().numpy()
+    for i, c in enumerate(crops):
+        g = cvo.bgr2gray_u8(c)
+        rw_ = min(320, int(np.ceil(32 * g.shape[1] / float(g.shape[0]))))
+        r = cvo.resize_linear_u8(g, (rw_, 32)).astype(np.float32)
+        exp = np.zeros((32, 320), np.float32)
+        exp[:, :rw_] = (r / np.float32(255) - np.float32(0.5)) / np.float32(0.5)
+        assert np.array_equal(x4[i, :, :, 0], exp), ("rec", c.shape)
