@@ -49,6 +49,27 @@ def test_lstm_kernel_matches_torch():
         assert (got - ref).abs().max().item() <= 2e-5
 
 
+@pytest.mark.parametrize("seed", range(4 + int(os.environ.get("PTOCR_LSTM_FUZZ", "0"))))      # PTOCR_LSTM_FUZZ=n: n more seeds
+def test_lstm_random_batches_against_torch(seed):
+    """random (lines, steps, input width): ragged groups of 16 lines, both forms of the recurrence (split across four workgroups
+    when the groups fit the chip, one workgroup per group otherwise), against torch's LSTM + Linear"""
+    from pytorchocr_amd.modeling.necks.rnn import BidirectionalLSTM
+    rng = np.random.default_rng(9000 + seed)
+    torch.manual_seed(100 + seed)
+    B = int(rng.choice([1, 2, 15, 16, 17, 31, 33, 100, 255, 300, 513, 700]))
+    T = int(rng.integers(1, 90))
+    nin = int(rng.choice([64, 256, 512]))
+    blk = BidirectionalLSTM(nin, 256, 256).eval()
+    x = torch.randn(T, B, nin)
+    with torch.no_grad():
+        o, _ = blk.rnn(x)
+        ref = blk.embedding(o.reshape(T * B, 512)).reshape(T, B, 256)
+    p = blk.pack(torch.device("cuda:0"))
+    xb = x.permute(1, 0, 2).contiguous().reshape(B * T, nin).cuda()
+    got = BidirectionalLSTM.run(p, xb, B, T).reshape(B, T, 256).permute(1, 0, 2).cpu()
+    assert (got - ref).abs().max().item() <= 3e-5, (B, T, nin, (got - ref).abs().max().item())
+
+
 def test_lstm_split_exchange_timeout_is_repaired_on_the_stream():
     """Test hook: with the spin bound of the split form's exchange shrunk to one poll the four-workgroup exchange times out;
     the repair pass (exchange-free kernel, same stream) must still deliver the right output, and the event must be counted.
