@@ -222,3 +222,28 @@ def test_scene_checkpoint_maps_and_boxes_against_the_reference(which, gold_dir, 
     assert len(exp) >= 6, len(exp)
     same = sum(any(np.array_equal(a, b) for b in exp) for a in got)
     assert abs(len(got) - len(exp)) <= 1 and same >= len(exp) - 1, (len(got), len(exp), same)
+
+
+@pytest.mark.parametrize("seed", range(6 + int(os.environ.get("PTOCR_MODEL_FUZZ", "0"))))      # PTOCR_MODEL_FUZZ=n: n more seeds
+def test_detectors_random_sizes_against_the_oracle(seed, contract):
+    """DBNet-r18 / DBNet++-r18 / DBNet-mbv3s at random input sizes (multiples of 32, as DetResizeForTest makes them) and batch sizes
+    against the torch-fp32 oracle: every patch geometry / kernel choice the size-dependent cost models make must give the same maps"""
+    from oracle import model_oracle
+    from pytorchocr_amd.modeling.architectures import build_model
+    rng = np.random.default_rng(6000 + seed)
+    which = ("det_r18_db", "detpp_r18_db", "det_mbv3s_db")[int(rng.integers(0, 3))]
+    cfg = {"det_r18_db": DET_R18, "detpp_r18_db": dict(DET_R18, Neck=dict(DET_R18["Neck"], use_asf=True)),
+           "det_mbv3s_db": dict(model_type="det", algorithm="DB", Transform=None,
+                                Backbone=dict(name="MobileNetV3", model_name="small", scale=1.0, pretrained=False),
+                                Neck=dict(name="FPN", out_channels=96, mode="DB", use_asf=False), Head=dict(name="DBHead", k=50))}[which]
+    sd = synth_state_dict(contract[which])
+    m = build_model(cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.to("cuda:0").eval()
+    n, h, w = int(rng.integers(1, 4)), 32 * int(rng.integers(1, 12)), 32 * int(rng.integers(1, 14))
+    xs = synth_images(n, 3, h, w, seed=600 + seed)
+    with torch.no_grad():
+        y = m(torch.from_numpy(xs).cuda())["maps"].cpu().numpy()
+    fwd = model_oracle.dbnet_r18_forward if which == "detpp_r18_db" else model_oracle.dbnet_forward     # (the r18 form also runs the ASF neck)
+    ref = fwd(sd, torch.from_numpy(xs))["maps"].numpy()
+    assert y.shape == ref.shape and np.abs(y - ref).max() <= 1e-4, (which, n, h, w, np.abs(y - ref).max())
