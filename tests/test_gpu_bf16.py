@@ -324,6 +324,24 @@ def test_bf16_boxes_against_fp32_boxes_on_scene_images(gold_dir, contract):
     assert np.percentile(shifts, 90) <= 2, np.percentile(shifts, [50, 90, 99])
 
 
+@pytest.mark.parametrize("seed", range(4 + int(os.environ.get("PTOCR_BF16_FUZZ", "0"))))      # PTOCR_BF16_FUZZ=n: n more seeds
+def test_bf16_scene_random_sizes_against_fp32(seed, gold_dir, contract):
+    """the scene checkpoint at random input sizes and batch sizes: bf16 maps against the fp32 maps of the same HIP engine (itself
+    within 1e-4 of the reference), the bounds of the 736x1280 box test -- every tile shape / channel-group choice of the bf16 kernels"""
+    from pytorchocr_amd.utils.synth import synth_scene_inputs
+    rng = np.random.default_rng(4000 + seed)
+    m, sd = _scene_model(contract, gold_dir)
+    n, h, w = int(rng.integers(1, 5)), 32 * int(rng.integers(2, 14)), 32 * int(rng.integers(2, 16))
+    x = torch.from_numpy(synth_scene_inputs(n, h, w, seed=300 + seed)).cuda()
+    with torch.no_grad():
+        p32 = m(x)["maps"]
+        m.set_compute_dtype("bf16")
+        p16 = m(x)["maps"]
+    d = (p16 - p32).abs()
+    flips = ((p16 > 0.3) != (p32 > 0.3)).float().mean().item()
+    assert p16.shape == p32.shape and d.max().item() <= 1e-1 and d.mean().item() <= 3e-3 and flips <= 4e-3, (n, h, w, d.max().item(), d.mean().item(), flips)
+
+
 def test_bf16_config3_size_properties(contract):
     """736x1280 (BASELINE configs[3] geometry), batch 32: the maps of an image do not depend on the batch it travels in, and two runs
     give the same bits"""
