@@ -279,6 +279,18 @@ def test_random_scenes_bit_exact(seed):
     _compare(maps, src, box_thresh=float(rng.choice([0.3, 0.5, 0.7])), ratio=float(rng.choice([1.5, 1.7, 2.0])))
 
 
+@pytest.mark.parametrize("seed", range(2 + int(os.environ.get("PTOCR_DBPOST_FUZZ_BIG", "0"))))     # PTOCR_DBPOST_FUZZ_BIG=n: n more seeds
+def test_random_scenes_at_bench_size_bit_exact(seed):
+    """the random scenes at 600-736 x 1000-1280 pixels, up to four per call: the full-size pass, deferred wide / large borders, the
+    1000-border cut with and without the strip pass"""
+    rng = np.random.default_rng(2000 + seed)
+    h, w = int(rng.integers(600, 737)), int(rng.integers(1000, 1281))
+    n = int(rng.integers(1, 5))
+    maps = np.stack([_random_scene(rng, h, w) for _ in range(n)])
+    src = [[int(rng.integers(200, 3000)), int(rng.integers(200, 3000))] for _ in range(n)]
+    _compare(maps, src, box_thresh=float(rng.choice([0.3, 0.5, 0.7])), ratio=float(rng.choice([1.5, 1.7, 2.0])))
+
+
 @pytest.mark.parametrize("seed", range(4 + int(os.environ.get("PTOCR_DBPOST_FUZZ", "0")) // 4))
 def test_ragged_text_maps_bit_exact(seed):
     """text bars whose edges are ragged (a noisy estimate through a steep sigmoid, what the scene checkpoints of bench.py emit): many
