@@ -36,6 +36,10 @@ namespace ptocr {
 
 constexpr int MAX_CAND = 1000;          // reference db_postprocess.cpp:239 (hard-coded max_candidates)
 constexpr int CHUNK = 1024;             // pixels per root-count chunk
+#ifndef PT_SEL_CHUNKS
+#define PT_SEL_CHUNKS 2
+#endif
+constexpr int SEL_CHUNKS = PT_SEL_CHUNKS;   // chunks per block of select_starts_kernel
 constexpr int FRAME = -1;               // label of background connected to the image frame
 
 struct DbpostDims {
@@ -83,6 +87,50 @@ __global__ __launch_bounds__(256) void binarize_kernel(const float *__restrict__
         for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
         __shared__ int wsum[4];                                  // one atomic per block: 16 k atomics on 32 words doubled the kernel's time
         if (lane == 0) wsum[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            if (t) atomicAdd(&strip_runs[img], t);
+        }
+    }
+}
+
+// The same for W % 32 == 0 (every map the models emit): threads run over the image's pixel quads without regard to rows, so no
+// thread idles past the end of a row (1280 = 1024 + 256 left 3/8 of a row's second block idle), two quads per thread in flight.
+__global__ __launch_bounds__(256) void binarize_flat_kernel(const float *__restrict__ maps, unsigned *__restrict__ bits,
+                                                            DbpostDims d, float thresh, int *__restrict__ strip_runs) {
+    const int img = blockIdx.y;
+    const int qpr = d.W >> 2;                                    // quads per row (a multiple of 8: the 8 lanes of a word share a row)
+    const long nq = (long)d.H * qpr;
+    const float *base = maps + (long)img * d.HW;
+    int cnt = 0;
+    const bool any_strip = strip_runs && d.strip_y && (long)(blockIdx.x * 512 + 511) / qpr >= d.strip_y;      // uniform over the block
+#pragma unroll
+    for (int rep = 0; rep < 2; rep++) {
+        const long q = (long)blockIdx.x * 512 + rep * 256 + threadIdx.x;
+        const bool on = q < nq;
+        float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (on) v4 = *reinterpret_cast<const float4 *>(base + q * 4);
+        const unsigned nib = (v4.x > thresh) | ((v4.y > thresh) << 1) | ((v4.z > thresh) << 2) | ((v4.w > thresh) << 3);
+        unsigned v = nib << (4 * (threadIdx.x & 7));
+        v |= __shfl_xor(v, 1);
+        v |= __shfl_xor(v, 2);
+        v |= __shfl_xor(v, 4);
+        const int y = on ? (int)(q / qpr) : 0, x0 = on ? (int)(q - (long)y * qpr) * 4 : 0;
+        const int wi = x0 >> 5;
+        if (on && (threadIdx.x & 7) == 0) bits[((long)img * d.H + y) * d.WW + wi] = v;
+        if (any_strip) {
+            unsigned prev = __shfl_up(v, 8);                     // the word to the left, unless this is the wave's or the row's first word
+            if ((threadIdx.x & 63) < 8) prev = (on && x0 >= 32 && (base[q * 4 - 1 - (x0 & 31)] > thresh)) ? 0x80000000u : 0u;
+            if (x0 < 32) prev = 0u;
+            if (on && (threadIdx.x & 7) == 0 && y >= d.strip_y) cnt += __popc(v ^ ((v << 1) | (prev >> 31)));
+        }
+    }
+    if (any_strip) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
+        __shared__ int wsum[4];
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
         __syncthreads();
         if (threadIdx.x == 0) {
             const int t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
@@ -374,46 +422,60 @@ struct Acc { int nstates, npts, xmin, xmax, ymin, ymax, cursor, off; };
 __global__ __launch_bounds__(256) void select_starts_kernel(const unsigned *__restrict__ bits, int *__restrict__ labels,
                                                             const int *__restrict__ chunk_after, const int *__restrict__ totals,
                                                             Cand *__restrict__ cands, Acc *__restrict__ acc, DbpostDims d) {
-    const int img = blockIdx.y, chunk = blockIdx.x;
-    const int after = chunk_after[(long)img * d.nchunks + chunk];
-    if (after >= MAX_CAND) return;                              // every start here ranks beyond the first 1000
-    const int upto = chunk ? chunk_after[(long)img * d.nchunks + chunk - 1] : totals[img];
-    if (upto == after) return;                                  // no start in this chunk (most chunks of a clean map)
-    int *lab = labels + (long)img * d.HW;
-    __shared__ int wave_cnt[4];
-    __shared__ int base;                                        // starts already ranked in this chunk (from the top index down)
-    if (threadIdx.x == 0) base = 0;
-    __syncthreads();
+    const int img = blockIdx.y;
+    __shared__ int wave_cnt[4][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int k = CHUNK / 256 - 1; k >= 0; k--) {               // highest pixels first
-        const long p = (long)chunk * CHUNK + k * 256 + (255 - threadIdx.x);   // thread 0 takes the highest pixel
-        bool is = false;
+    int *lab = labels + (long)img * d.HW;
+    // eight chunks per block (29 000 blocks of which a few hundred had work were most of the kernel's 19 us)
+    for (int ci = 0; ci < SEL_CHUNKS; ci++) {
+    const int chunk = blockIdx.x * SEL_CHUNKS + ci;
+    if (chunk >= d.nchunks) break;
+    const int after = chunk_after[(long)img * d.nchunks + chunk];
+    if (after >= MAX_CAND) continue;                            // every start here ranks beyond the first 1000
+    const int upto = chunk ? chunk_after[(long)img * d.nchunks + chunk - 1] : totals[img];
+    if (upto == after) continue;                                // no start in this chunk (most chunks of a clean map)
+    // the chunk's 1024 pixels in one sweep, highest pixel first: slice k (k = 3 .. 0) holds pixels [256 k, 256 k + 256), thread 0 its
+    // highest.  All four label loads of a thread are issued before the first is used, one barrier in all (the first version walked
+    // the slices one after the other: four dependent round trips and twelve barriers, 25 us).
+    bool is[4];
+    int rx[4], ry[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const long p = (long)chunk * CHUNK + k * 256 + (255 - threadIdx.x);
+        is[k] = false; rx[k] = ry[k] = 0;
         if (p < d.HW) {                                         // only run starts carry labels
             const int y = (int)(p / d.W), x = (int)(p - (long)y * d.W);
             const unsigned *row = bits + ((long)img * d.H + y) * d.WW;
-            is = (x == 0 || pix(row, x) != pix(row, x - 1)) && lab[p] == (int)p;
+            ry[k] = y; rx[k] = x;
+            is[k] = (x == 0 || pix(row, x) != pix(row, x - 1)) && lab[p] == (int)p;
         }
-        const unsigned long long m = __ballot(is);
-        if (lane == 0) wave_cnt[wave] = __popcll(m);
-        __syncthreads();
-        int before = base;
-        for (int w = 0; w < wave; w++) before += wave_cnt[w];
-        before += __popcll(m & ((1ull << lane) - 1));
-        if (is) {
-            const int rank = after + before;
-            if (rank < MAX_CAND) {
-                const int y = (int)(p / d.W), x = (int)(p - (long)y * d.W);
-                const unsigned *row = bits + ((long)img * d.H + y) * d.WW;
-                Cand c; c.p = (int)p; c.is_hole = !pix(row, x);
-                cands[(long)img * MAX_CAND + rank] = c;
-                Acc a; a.nstates = 0; a.npts = 0; a.xmin = 0x7fffffff; a.xmax = -1; a.ymin = 0x7fffffff; a.ymax = -1; a.cursor = 0; a.off = -1;
-                acc[(long)img * MAX_CAND + rank] = a;
-                lab[p] = -2 - rank;
-            }
+    }
+    unsigned long long m[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        m[k] = __ballot(is[k]);
+        if (lane == 0) wave_cnt[k][wave] = __popcll(m[k]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 3; k >= 0; k--) {
+        if (!is[k]) continue;
+        int before = 0;
+        for (int kk = 3; kk > k; kk--) before += wave_cnt[kk][0] + wave_cnt[kk][1] + wave_cnt[kk][2] + wave_cnt[kk][3];
+        for (int w = 0; w < wave; w++) before += wave_cnt[k][w];
+        before += __popcll(m[k] & ((1ull << lane) - 1));
+        const int rank = after + before;
+        if (rank < MAX_CAND) {
+            const long p = (long)chunk * CHUNK + k * 256 + (255 - threadIdx.x);
+            const unsigned *row = bits + ((long)img * d.H + ry[k]) * d.WW;
+            Cand c; c.p = (int)p; c.is_hole = !pix(row, rx[k]);
+            cands[(long)img * MAX_CAND + rank] = c;
+            Acc a; a.nstates = 0; a.npts = 0; a.xmin = 0x7fffffff; a.xmax = -1; a.ymin = 0x7fffffff; a.ymax = -1; a.cursor = 0; a.off = -1;
+            acc[(long)img * MAX_CAND + rank] = a;
+            lab[p] = -2 - rank;
         }
-        __syncthreads();
-        if (threadIdx.x == 0) base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        __syncthreads();
+    }
+    __syncthreads();                                           // wave_cnt is reused by the next chunk
     }
 }
 
@@ -2899,7 +2961,10 @@ static void run_chain(ptocr_dbpost *h, const float *d_maps, const uint8_t *d_bit
     else {
         DbpostDims dc = d;                                       // the count is taken whether or not the strip pass runs this time
         dc.strip_y = H > 2 * STRIP_ROWS ? H - STRIP_ROWS : 0;
-        hipLaunchKernelGGL(binarize_kernel, row_grid, dim3(256), 0, s, d_maps, w_bits, dc, thresh, counted ? w_strip_runs : nullptr);
+        if ((W & 31) == 0)
+            hipLaunchKernelGGL(binarize_flat_kernel, dim3(cdiv(H * (W >> 2), 512), N), dim3(256), 0, s, d_maps, w_bits, dc, thresh, counted ? w_strip_runs : nullptr);
+        else
+            hipLaunchKernelGGL(binarize_kernel, row_grid, dim3(256), 0, s, d_maps, w_bits, dc, thresh, counted ? w_strip_runs : nullptr);
     }
     unsigned *bits = w_bits;
     if (use_dilation) {
@@ -2920,7 +2985,7 @@ static void run_chain(ptocr_dbpost *h, const float *d_maps, const uint8_t *d_bit
         hipLaunchKernelGGL(ccl_flatten_kernel, word_grid, dim3(256), 0, s, bits, w_labels, w_word_lab, w_chunk, d, ps);
         hipLaunchKernelGGL(chunk_suffix_kernel, dim3(N), dim3(1024), 0, s, w_chunk, w_totals, d, ps, w_strip_totals);
     }
-    hipLaunchKernelGGL(select_starts_kernel, dim3(d.nchunks, N), dim3(256), 0, s, bits, w_labels, w_chunk, w_totals, w_cands, w_acc, d);
+    hipLaunchKernelGGL(select_starts_kernel, dim3(cdiv(d.nchunks, SEL_CHUNKS), N), dim3(256), 0, s, bits, w_labels, w_chunk, w_totals, w_cands, w_acc, d);
     const dim3 all_words(cdiv(cdiv(H, 8) * cdiv(d.WW, 8), 4), N);      // 8 x 8-word tiles, four per block
     DbpostDims dk = d;
     if (getenv("PTOCR_DBPOST_DBG_SKIP") && (atoi(getenv("PTOCR_DBPOST_DBG_SKIP")) & 32768)) dk.N = -N;     // 32768: the count pass scans but books nothing
