@@ -256,7 +256,8 @@ __device__ __forceinline__ WordCtx word_ctx(const unsigned *row, int wi, const D
 // strip) -- and when an image has >= MAX_CAND starts there (speckle / noise maps: tens of thousands of components) pass B,
 // the whole image, is skipped for it.  Clean maps have few components and go through both passes (pass A costs 9 %).
 constexpr int STRIP_ROWS = 64;
-struct CclPass { int y_first; const int *skip_if_full; const int *skip_if_few; int dbg; };   // skip_if_full: per-image start counts of pass A (pass B), skip_if_few: run starts of the strip (pass A), or null
+struct CclPass { int y_first; const int *skip_if_full; const int *skip_if_few; int dbg; int row_step; };
+// row_step: the merge kernel visits only the rows y_first + k row_step, k >= 1 (the slab boundaries of ccl_slab_kernel)   // skip_if_full: per-image start counts of pass A (pass B), skip_if_few: run starts of the strip (pass A), or null
 
 __device__ __forceinline__ bool ccl_skip(const CclPass &ps, int img) {
     return (ps.skip_if_full && ps.skip_if_full[img] >= MAX_CAND) || (ps.skip_if_few && ps.skip_if_few[img] < MAX_CAND);
@@ -286,21 +287,11 @@ __global__ __launch_bounds__(256) void ccl_init_kernel(const unsigned *__restric
 // on bit masks): vertical links where one of the two runs starts; for foreground (8-connected) the NW link at a run
 // start and the NE link at a run end, when the pixel straight above is background; background is 4-connected and every
 // background run touching the image border is united with the virtual FRAME root.
-template <int TPW>                                              // threads per word: 4 on noise maps, 1 otherwise (see below)
-__global__ __launch_bounds__(256) void ccl_merge_kernel(const unsigned *__restrict__ bits, int *__restrict__ labels, DbpostDims d,
-                                                        CclPass ps) {
-    const int img = blockIdx.y;
-    if (ccl_skip(ps, img)) return;
+// one bitmap word's links of row y to the row above (and to FRAME); `part`: the bits of the word this thread takes
+__device__ __forceinline__ void merge_word(const unsigned *__restrict__ bits, int *__restrict__ labels, const DbpostDims &d, int img, int y, int wi,
+                                           bool cut, unsigned part, int dbg, bool up_links = true) {
     int dummy = 0;
-#define MU(l, x, y) do { if (ps.dbg & 1) dummy += (x) ^ (y); else if (ps.dbg & 2) dummy += uf_find(l, x) ^ uf_find(l, y); else uf_union(l, x, y); } while (0)
-    // speckle maps put ~10 unions into a word, each a chain of atomics: four threads per word there, one byte of its boundary masks
-    // each.  A text-like map has a union in one word of ten, and walking its 30 000 words with 120 000 threads was half of the
-    // kernel's time (38 of 79 us with every union compiled out): one thread per word there.
-    const int idx = TPW == 4 ? (blockIdx.x * 256 + threadIdx.x) >> 2 : blockIdx.x * 256 + threadIdx.x;
-    const unsigned part = TPW == 4 ? 0xffu << (8 * (threadIdx.x & 3)) : 0xffffffffu;
-    if (idx >= (d.H - ps.y_first) * d.WW) return;
-    const int y = ps.y_first + idx / d.WW, wi = idx % d.WW;
-    const bool cut = y == ps.y_first && y > 0;                    // first row of the strip: links upwards end in FRAME
+#define MU(l, x, y) do { if (dbg & 1) dummy += (x) ^ (y); else if (dbg & 2) dummy += uf_find(l, x) ^ uf_find(l, y); else uf_union(l, x, y); } while (0)
     const unsigned *row = bits + ((long)img * d.H + y) * d.WW;
     int *lab = labels + (long)img * d.HW;
     const WordCtx c = word_ctx(row, wi, d);
@@ -319,7 +310,7 @@ __global__ __launch_bounds__(256) void ccl_merge_kernel(const unsigned *__restri
             MU(lab, rs_cur(i), FRAME);
         }
     }
-    if (y == 0) return;
+    if (y == 0 || !up_links) return;
     const unsigned *up = row - d.WW;
     const WordCtx u = word_ctx(up, wi, d);
     const int ubase = base - d.W;
@@ -347,8 +338,181 @@ __global__ __launch_bounds__(256) void ccl_merge_kernel(const unsigned *__restri
         ne &= ne - 1;
         MU(lab, rs_cur(i), cut ? FRAME : ubase + i + 1);      // up(x) = 0, up(x+1) = 1: a run start
     }
-    if ((ps.dbg & 3) && dummy == 0x7fffffff) lab[0] = dummy;
+    if ((dbg & 3) && dummy == 0x7fffffff) lab[0] = dummy;
 #undef MU
+}
+
+template <int TPW>                                              // threads per word: 4 on noise maps, 1 otherwise (see below)
+__global__ __launch_bounds__(256) void ccl_merge_kernel(const unsigned *__restrict__ bits, int *__restrict__ labels, DbpostDims d,
+                                                        CclPass ps) {
+    const int img = blockIdx.y;
+    if (ccl_skip(ps, img)) return;
+    // speckle maps put ~10 unions into a word, each a chain of atomics: four threads per word there, one byte of its boundary masks
+    // each.  A text-like map has a union in one word of ten, and walking its 30 000 words with 120 000 threads was half of the
+    // kernel's time (38 of 79 us with every union compiled out): one thread per word there.
+    const int idx = TPW == 4 ? (blockIdx.x * 256 + threadIdx.x) >> 2 : blockIdx.x * 256 + threadIdx.x;
+    const unsigned part = TPW == 4 ? 0xffu << (8 * (threadIdx.x & 3)) : 0xffffffffu;
+    int y, wi;
+    if (ps.row_step) {                                            // slab boundaries only
+        y = ps.y_first + (idx / d.WW + 1) * ps.row_step; wi = idx % d.WW;
+        if (y >= d.H) return;
+    } else {
+        if (idx >= (d.H - ps.y_first) * d.WW) return;
+        y = ps.y_first + idx / d.WW; wi = idx % d.WW;
+    }
+    merge_word(bits, labels, d, img, y, wi, y == ps.y_first && y > 0, part, ps.dbg);
+}
+
+// Slab labelling (text route, late round 3): one workgroup labels SLAB_ROWS rows in LDS -- its runs numbered in raster order by a
+// prefix sum over the words' run starts, the same union rules as ccl_merge_kernel on LDS union-find nodes (node 0 = FRAME) -- and
+// writes label[run start] = the slab-local root's pixel (or FRAME).  ccl_merge_kernel then links only the slab boundary rows in global
+// memory (row_step), and the flatten pass resolves the short chains that leaves.  Replaces ccl_init_kernel + ccl_merge_kernel<1>
+// (6 + 62 us per 32 text-like maps: every union two pointer chases and an atomic in global memory).  A slab with more than
+// SLAB_RUNS runs (speckle) is labelled by its workgroup through the global union-find instead.
+#ifndef PT_SLAB_ROWS
+#define PT_SLAB_ROWS 8
+#endif
+constexpr int SLAB_ROWS = PT_SLAB_ROWS;         // 8 or 16 (the slab kernel runs one thread per word: 16 x 64 words = 1024 threads at most)
+constexpr int SLAB_RUNS = 4096;
+__device__ __forceinline__ int lds_find(int *par, int v) {
+    for (;;) {
+        const int p = par[v];
+        if (p == v) return v;
+        const int gp = par[p];
+        if (gp != p) par[v] = gp;
+        v = p;
+    }
+}
+__device__ __forceinline__ void lds_union(int *par, int a, int b) {
+    for (;;) {
+        a = lds_find(par, a);
+        b = lds_find(par, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(&par[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+__global__ __launch_bounds__(SLAB_ROWS * 64) void ccl_slab_kernel(const unsigned *__restrict__ bits, int *__restrict__ labels, int *__restrict__ chunk_cnt,
+                                                       DbpostDims d, CclPass ps) {
+    const int img = blockIdx.y;
+    if (ccl_skip(ps, img)) return;
+    __shared__ unsigned sb[SLAB_ROWS * 64];                        // the slab's bitmap words (WW <= 64)
+    __shared__ int sbase[SLAB_ROWS * 64 + 1];                      // run starts in the words before this one
+    __shared__ int wsum[SLAB_ROWS];
+    __shared__ int par[SLAB_RUNS + 1];
+    __shared__ unsigned short rpix[SLAB_RUNS];                     // run -> its first pixel, relative to the slab (< 16 * 2048)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int y0 = ps.y_first + blockIdx.x * SLAB_ROWS;
+    const int rows = min(SLAB_ROWS, d.H - y0);
+    const int nw = rows * d.WW;
+    if (blockIdx.x == 0)
+        for (int i = tid; i < d.nchunks; i += blockDim.x) chunk_cnt[(long)img * d.nchunks + i] = 0;
+    const unsigned *bimg = bits + ((long)img * d.H + y0) * d.WW;
+    if (tid < nw) sb[tid] = bimg[tid];
+    __syncthreads();
+    const int yl = tid / d.WW, wi = tid - yl * d.WW;              // tid >= nw: idle along (barriers)
+    const bool on = tid < nw;
+    WordCtx c = {0u, 0u, 0u, 0u};
+    if (on) c = word_ctx(sb + yl * d.WW, wi, d);
+    // exclusive prefix of the run-start counts over the slab's words
+    int cnt = __popc(c.starts), incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int wbase = 0, total = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) { if (w < wave) wbase += wsum[w]; total += wsum[w]; }
+    const int base = wbase + incl - cnt;
+    if (total > SLAB_RUNS) {                                       // uniform
+        // a slab too dense for the LDS tables (speckle): the same result through the global union-find, by this workgroup alone --
+        // label[s] = s for its run starts, then the links of its rows (the first row's upward links are the boundary pass's)
+        int *lab = labels + (long)img * d.HW;
+        if (on) {
+            unsigned m = c.starts;
+            const int b0 = (y0 + yl) * d.W + wi * 32;
+            while (m) {
+                const int i = __ffs(m) - 1;
+                m &= m - 1;
+                lab[b0 + i] = b0 + i;
+            }
+        }
+        __threadfence();
+        __syncthreads();
+        if (on) {
+            const int y = y0 + yl;
+            const bool cut = yl == 0 && y == ps.y_first && y > 0;
+            merge_word(bits, labels, d, img, y, wi, cut, 0xffffffffu, 0, yl > 0 || cut);
+        }
+        return;
+    }
+    if (on) sbase[tid] = base;
+    for (int i = tid; i <= total; i += blockDim.x) par[i] = i;
+    {
+        unsigned m = c.starts; int k = 0;
+        while (m) {
+            const int i = __ffs(m) - 1;
+            m &= m - 1;
+            rpix[base + k] = (unsigned short)(yl * d.W + wi * 32 + i);
+            k++;
+        }
+    }
+    __syncthreads();
+    // node of the run that holds pixel x of slab row r: the number of run starts at or before it in raster order (x = 0 always starts one)
+    auto node = [&](int r, int x) {
+        const int wq = r * d.WW + (x >> 5);
+        const unsigned st = word_ctx(sb + r * d.WW, x >> 5, d).starts;
+        return sbase[wq] + __popc(st & (0xffffffffu >> (31 - (x & 31))));
+    };
+    if (on) {
+        const int y = y0 + yl, x0 = wi * 32;
+        auto ncur = [&](int i) { return base + __popc(c.starts & (0xffffffffu >> (31 - i))); };
+        {   // background touching the image border belongs to the frame component
+            unsigned m = ~c.w & c.valid;
+            unsigned f = (y == 0 || y == d.H - 1) ? (m & c.starts) : 0u;
+            if (wi == 0) f |= m & 1u;
+            if (x0 + 32 >= d.W) f |= m & (1u << (d.W - 1 - x0));
+            while (f) {
+                const int i = __ffs(f) - 1;
+                f &= f - 1;
+                lds_union(par, ncur(i), 0);
+            }
+        }
+        const bool cut = yl == 0 && y == ps.y_first && y > 0;       // first row of the strip: links upwards end in FRAME
+        if (yl > 0 || cut) {
+            // the row above: inside the slab, or (cut) the global row above the strip, read for its bits only
+            const unsigned *uprow = cut ? bits + ((long)img * d.H + y - 1) * d.WW : sb + (yl - 1) * d.WW;
+            const WordCtx u = word_ctx(uprow, wi, d);
+            unsigned v = ~(c.w ^ u.w) & c.valid & (c.starts | u.starts);
+            while (v) {
+                const int i = __ffs(v) - 1;
+                v &= v - 1;
+                lds_union(par, ncur(i), cut ? 0 : node(yl - 1, x0 + i));
+            }
+            const unsigned fgbg = c.w & ~u.w & c.valid;
+            const unsigned ucarry = wi ? uprow[wi - 1] >> 31 : 0u;
+            unsigned nwm = fgbg & c.starts & ((u.w << 1) | ucarry);
+            while (nwm) {
+                const int i = __ffs(nwm) - 1;
+                nwm &= nwm - 1;
+                lds_union(par, ncur(i), cut ? 0 : node(yl - 1, x0 + i - 1));
+            }
+            const unsigned unext = (wi + 1 < d.WW) ? (uprow[wi + 1] & 1u) : 0u;
+            unsigned ne = fgbg & c.ends & ((u.w >> 1) | (unext << 31));
+            while (ne) {
+                const int i = __ffs(ne) - 1;
+                ne &= ne - 1;
+                lds_union(par, ncur(i), cut ? 0 : node(yl - 1, x0 + i + 1));
+            }
+        }
+    }
+    __syncthreads();
+    int *lab = labels + (long)img * d.HW + (long)y0 * d.W;
+    for (int r = tid; r < total; r += blockDim.x) {
+        const int root = lds_find(par, r + 1);
+        lab[rpix[r]] = root == 0 ? FRAME : y0 * d.W + (int)rpix[root - 1];
+    }
 }
 
 // label[s] = root for every run start s; word_lab[word] = root of the run that covers bit 0 of the word (so that the root of
@@ -2979,9 +3143,24 @@ static void run_chain(ptocr_dbpost *h, const float *d_maps, const uint8_t *d_bit
         ps.skip_if_few = (pass == 0 && counted) ? w_strip_runs : nullptr;
         const int words = (H - ps.y_first) * d.WW;
         const dim3 word_grid(cdiv(words > d.nchunks ? words : d.nchunks, 256), N);
-        hipLaunchKernelGGL(ccl_init_kernel, word_grid, dim3(256), 0, s, bits, w_labels, w_chunk, d, ps);
-        if (h->strip_hint || !counted) hipLaunchKernelGGL(ccl_merge_kernel<4>, dim3(cdiv(4 * words, 256), N), dim3(256), 0, s, bits, w_labels, d, ps);
-        else hipLaunchKernelGGL(ccl_merge_kernel<1>, dim3(cdiv(words, 256), N), dim3(256), 0, s, bits, w_labels, d, ps);
+        ps.row_step = 0;
+        static const int global_ccl = getenv("PTOCR_DBPOST_GLOBAL_CCL") && atoi(getenv("PTOCR_DBPOST_GLOBAL_CCL")) == 1;
+        if (h->strip_hint || !counted) {                            // noise route (or no count): the global union-find, four threads per word
+            hipLaunchKernelGGL(ccl_init_kernel, word_grid, dim3(256), 0, s, bits, w_labels, w_chunk, d, ps);
+            hipLaunchKernelGGL(ccl_merge_kernel<4>, dim3(cdiv(4 * words, 256), N), dim3(256), 0, s, bits, w_labels, d, ps);
+        } else if (global_ccl) {                                    // rounds 2-3: global union-find, one thread per word
+            hipLaunchKernelGGL(ccl_init_kernel, word_grid, dim3(256), 0, s, bits, w_labels, w_chunk, d, ps);
+            hipLaunchKernelGGL(ccl_merge_kernel<1>, dim3(cdiv(words, 256), N), dim3(256), 0, s, bits, w_labels, d, ps);
+        } else {
+            // text route: slabs of eight rows labelled in LDS, then the slab boundary rows linked globally
+            const int rows = H - ps.y_first, nslab = cdiv(rows, SLAB_ROWS);
+            hipLaunchKernelGGL(ccl_slab_kernel, dim3(nslab, N), dim3(cdiv(SLAB_ROWS * d.WW, 64) * 64), 0, s, bits, w_labels, w_chunk, d, ps);
+            if (nslab > 1) {
+                CclPass pb = ps;
+                pb.row_step = SLAB_ROWS;
+                hipLaunchKernelGGL(ccl_merge_kernel<1>, dim3(cdiv((nslab - 1) * d.WW, 256), N), dim3(256), 0, s, bits, w_labels, d, pb);
+            }
+        }
         hipLaunchKernelGGL(ccl_flatten_kernel, word_grid, dim3(256), 0, s, bits, w_labels, w_word_lab, w_chunk, d, ps);
         hipLaunchKernelGGL(chunk_suffix_kernel, dim3(N), dim3(1024), 0, s, w_chunk, w_totals, d, ps, w_strip_totals);
     }

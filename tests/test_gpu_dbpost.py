@@ -117,6 +117,20 @@ def test_noisy_maps_many_tiny_borders():
         _compare(m, [[w, h]], thresh=0.3 + 0.2 * seed, box_thresh=0.5)
 
 
+def test_speckle_after_text_like_batches_goes_through_the_slab_kernel():
+    """the labelling route follows the previous calls: after nine text-like calls the workspace is on the text route (LDS slabs), and a
+    speckle batch then meets slabs with far more runs than the LDS tables hold -- each such slab falls back to the global union-find
+    inside the slab kernel; borders and boxes must still be the oracle's.  (The next call is back on the noise route.)"""
+    clean = synth_prob_maps(1, 192, 1280, seed=3)
+    for _ in range(9):
+        _gpu(clean, [[1280, 192]])
+    rng = np.random.default_rng(77)
+    noisy = (rng.uniform(size=(2, 192, 1280)) < 0.5).astype(np.float32) * 0.9 + 0.05       # ~640 runs per row: 5 100 per 8-row slab (tables: 4 096)
+    noisy[1, :96] = clean[0, :96]                                  # second image: clean top half, speckle bottom half
+    _compare(noisy, [[1280, 192], [2560, 384]])
+    _compare(clean, [[1280, 192]])
+
+
 def test_strip_pass_is_chosen_per_image_and_never_changes_the_result():
     """The bottom-strip labelling pass is a shortcut for maps with >= 1000 starts in their last 64 rows; it is left out for an image whose
     strip has fewer than 1000 run starts (counted while binarizing).  Text and noise maps alone and MIXED in one batch; every call must
