@@ -1,4 +1,5 @@
-"""GPU box: device and wall time of the post-process call on 32 text-like maps, with PTOCR_DBPOST_GRAPH / PTOCR_DBPOST_PARTS from the env"""
+"""GPU box: device and wall time of the post-process call on 32 text-like maps with PTOCR_DBPOST_PARTS from the env (the hipGraph replay
+this script also measured -- PTOCR_DBPOST_GRAPH, DESIGN 3.3 -- was not kept in the library)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
