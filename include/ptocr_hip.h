@@ -145,7 +145,8 @@ int ptocr_convt2x2_sigmoid_f32(const float *d_x, const float *d_w, float bias, f
 int ptocr_db_head_tail_f32(const float *d_x, const float *d_w1, const float *d_b1, const float *d_w2, float b2, float *d_maps,
                            int N, int H, int W, int C, void *stream);
 /* Depthwise conv (groups == C) + folded BN bias + activation (0 none / 1 ReLU / 2 Hardswish), NHWC, C % 4 == 0.
- * d_w f32[k*k][C] (tap-major), pad = (k-1)/2.  (MobileNetV3 InvertedResidual.conv2, det_mobilenet_v3.py:123-126) */
+ * d_w f32[k*k][C] (tap-major), k in {2, 3, 5}, pad = (k-1)/2 (none for k = 2).  (MobileNetV3 InvertedResidual.conv2,
+ * det_mobilenet_v3.py:123-126; the depthwise layers of the CRNN's VGG v2, rec_vgg.py:62-76) */
 int ptocr_dwconv_f32(const float *d_x, const float *d_w, const float *d_bias, float *d_y, int N, int H, int W, int C, int k,
                      int stride, int act, void *stream);
 /* the same with separate vertical / horizontal strides (the recognition-style MobileNetV3 of the direction classifier strides its

@@ -259,8 +259,8 @@ using namespace ptocr;
 
 extern "C" int ptocr_dwconv2_f32(const float *d_x, const float *d_w, const float *d_bias, float *d_y, int N, int H, int W, int C, int k,
                                  int stride_h, int stride_w, int act, void *stream) {
-    PT_CHECK(d_x && d_w && d_bias && d_y && C % 4 == 0 && (k == 3 || k == 5) && (stride_h == 1 || stride_h == 2) && (stride_w == 1 || stride_w == 2) &&
-             act >= 0 && act <= 2, "ptocr_dwconv2_f32: need C %% 4 == 0, k in {3,5}, strides in {1,2}");
+    PT_CHECK(d_x && d_w && d_bias && d_y && C % 4 == 0 && (k == 2 || k == 3 || k == 5) && (stride_h == 1 || stride_h == 2) && (stride_w == 1 || stride_w == 2) &&
+             act >= 0 && act <= 2, "ptocr_dwconv2_f32: need C %% 4 == 0, k in {2,3,5} (padding (k-1)/2: none for k = 2), strides in {1,2}");
     const int pad = (k - 1) / 2;
     const int Ho = (H + 2 * pad - k) / stride_h + 1, Wo = (W + 2 * pad - k) / stride_w + 1;
     const long total = (long)N * Ho * Wo * (C / 4);

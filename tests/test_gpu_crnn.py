@@ -233,3 +233,44 @@ def test_bench_batch_properties(contract):
     for i in range(16, 512, 16):
         assert torch.equal(idx[i:i + 16], idx16) and torch.equal(prob[i:i + 16], prob16), i
     assert int((idx16 != 0).sum()) > 0 and float(prob.min()) > 0.0 and float(prob.max()) <= 1.0
+
+
+@pytest.mark.parametrize("name,scale", [("rec_vgg2_bilstm_ctc", 1.0), ("rec_vgg2_half_bilstm_ctc", 0.5)])
+def test_crnn_with_the_vgg_v2_backbone_matches_reference(name, scale, gold_dir, contract):
+    """the depthwise-separable VGG v2 stack (rec_vgg.py:37-44, 62-76; a 5x5 / s2 first conv, depthwise k x k + pointwise layers, the
+    2x2 depthwise last layer) at both widths: reference key names (strict load), backbone features and softmax within 1e-4 of
+    outputs of the reference itself"""
+    from pytorchocr_amd.modeling.architectures import build_model
+    g = np.load(os.path.join(gold_dir, "%s_2x1x32x160.npz" % name))
+    cfg = _cfg(37)
+    cfg["Backbone"] = dict(cfg["Backbone"], model_name="v2", scale=scale)
+    m = build_model(cfg)
+    sd = synth_state_dict(contract[name])
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.to("cuda:0").eval()
+    x = torch.from_numpy(synth_text_lines(2, 32, 160, seed=int(g["seed"]))).cuda()
+    with torch.no_grad():
+        feat = m.backbone(x).cpu().numpy()
+        p = m(x).cpu().numpy()
+    assert feat.shape == g["backbone"].shape and np.abs(feat - g["backbone"]).max() <= 1e-4 * max(1.0, np.abs(g["backbone"]).max())
+    assert p.shape == g["probs"].shape and np.abs(p - g["probs"]).max() <= 1e-4
+    assert np.array_equal(p.argmax(2), g["probs"].argmax(2))
+
+
+def test_crnn_vgg_v1_half_width_against_the_oracle(contract):
+    """VGG v1 at scale 0.5 (rec_vgg.py:33-34: 32-64-128-128-256-256-512 channels; conv0 then runs on the generic kernels): softmax against
+    the torch-fp32 oracle with a state_dict drawn over the model's own shapes"""
+    from pytorchocr_amd.modeling.architectures import build_model
+    cfg = _cfg(37)
+    cfg["Backbone"] = dict(cfg["Backbone"], scale=0.5)
+    m = build_model(cfg)
+    shapes = {k: (tuple(v.shape), str(v.dtype)) for k, v in m.state_dict().items()}
+    sd = synth_state_dict(shapes)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.to("cuda:0").eval()
+    xs = synth_text_lines(3, 32, 200, seed=5)
+    with torch.no_grad():
+        p = m(torch.from_numpy(xs).cuda()).cpu().numpy()
+    ref = model_oracle.crnn_forward(sd, torch.from_numpy(xs)).numpy()
+    assert p.shape == ref.shape and np.abs(p - ref).max() <= 1e-4

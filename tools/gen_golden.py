@@ -317,6 +317,20 @@ def gen_widen_vectors():
         np.savez_compressed(os.path.join(GOLD, "%s_1x3x64x96.npz" % name), seed=np.int64(seed), maps=y["maps"].numpy(), **extra)
         p = y["maps"].numpy()
         print("%s: maps %.4f..%.4f" % (name, p.min(), p.max()))
+    # CRNN with the depthwise-separable VGG v2 stack (rec_vgg.py:37-44, 62-76), both widths; 37 classes keep the fixture small
+    for name, scale, seed in (("rec_vgg2_bilstm_ctc", 1.0, 35), ("rec_vgg2_half_bilstm_ctc", 0.5, 36)):
+        cfg = crnn_cfg(37)
+        cfg["Backbone"] = dict(cfg["Backbone"], model_name="v2", scale=scale)
+        m, shapes = build_with_synth(build_model, cfg)
+        contract[name] = {k: [list(sh), d] for k, (sh, d) in shapes.items()}
+        x = torch.from_numpy(synth_text_lines(2, 32, 160, seed=seed))
+        feats = {}
+        hook = m.backbone.register_forward_hook(lambda mod, i, o: feats.__setitem__("b", o.detach().clone()))
+        with torch.no_grad():
+            pr = m(x)                          # softmax [T,B,C]
+        hook.remove()
+        np.savez_compressed(os.path.join(GOLD, "%s_2x1x32x160.npz" % name), seed=np.int64(seed), probs=pr.numpy(), backbone=feats["b"].numpy())
+        print("%s: T %d, backbone %s" % (name, pr.shape[0], tuple(feats["b"].shape)))
     with open(path, "w") as f:
         json.dump(contract, f, indent=0, sort_keys=False)
 
