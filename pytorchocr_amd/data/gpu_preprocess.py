@@ -75,6 +75,21 @@ def warp_crops(img_dev, boxes):
     return buf, metas[0]
 
 
+def crop_rects(pts, H, W):
+    """get_part_img's crop rectangle (reference utility.py:57-66) for float32 boxes [K,4,2] of an H x W image: (left, top, width,
+    height) per box, truncating like int(); the slice img[top:bottom, left:right] of the reference clamps at the image edge."""
+    left = np.maximum(pts[:, :, 0].min(1).astype(np.int64), 0)
+    top = np.maximum(pts[:, :, 1].min(1).astype(np.int64), 0)
+    right = np.minimum(pts[:, :, 0].max(1).astype(np.int64), W)
+    bottom = np.minimum(pts[:, :, 1].max(1).astype(np.int64), H)
+    return left, top, right - left, bottom - top
+
+
+def rot90_rule(ch, cw):
+    """run_ocr.py:189-190: a crop at least 1.5 times as high as wide is turned counter-clockwise"""
+    return ch >= 1.5 * cw
+
+
 def warp_crops_batch(imgs_dev, boxes_per_image):
     """imgs_dev: u8[N,H,W,3] device tensor; boxes_per_image: N lists of int (4,2) boxes -> (packed u8 device buffer, per image a
     list of (off, rows, cols) / None per box): the perspective crops of ALL boxes of ALL images in one launch.  The 8x8 solves
@@ -88,11 +103,7 @@ def warp_crops_batch(imgs_dev, boxes_per_image):
         return torch.empty(1, dtype=torch.uint8, device=imgs_dev.device), metas
     pts = np.concatenate([np.asarray(b, np.float32).reshape(-1, 4, 2) for b in boxes_per_image if len(b)]).astype(np.float32)
     img_of = np.repeat(np.arange(len(counts)), counts)
-    left = np.maximum(pts[:, :, 0].min(1).astype(np.int64), 0)
-    top = np.maximum(pts[:, :, 1].min(1).astype(np.int64), 0)
-    right = np.minimum(pts[:, :, 0].max(1).astype(np.int64), W)
-    bottom = np.minimum(pts[:, :, 1].max(1).astype(np.int64), H)
-    cw, ch = right - left, bottom - top
+    left, top, cw, ch = crop_rects(pts, H, W)
     ok = (cw > 1) & (ch > 1)
     if not ok.any():
         return torch.empty(1, dtype=torch.uint8, device=imgs_dev.device), metas
@@ -102,7 +113,7 @@ def warp_crops_batch(imgs_dev, boxes_per_image):
     z = np.zeros_like(cwf)
     dst = np.stack([np.stack([z, z], 1), np.stack([cwf - 1, z], 1), np.stack([cwf - 1, chf - 1], 1), np.stack([z, chf - 1], 1)], 1)
     minv = invert_transforms(get_perspective_transforms(p, dst))
-    rot = (ch[sel] >= 1.5 * cw[sel]).astype(np.int32)
+    rot = rot90_rule(ch[sel], cw[sel]).astype(np.int32)
     sizes = cw[sel] * ch[sel] * 3
     offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
     items = np.zeros(len(sel), WARP_DT)

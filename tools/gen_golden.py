@@ -10,7 +10,7 @@ What it does (nothing from the reference is copied; only inputs-by-seed and outp
   * records the state_dict key/shape/dtype contract of each model.
 
 Usage: python tools/gen_golden.py   (writes every fixture under tests/golden/;
-       --cls-only / --mbv3s-scene-only / --widen-only / --labels-only / --clipper-only regenerate one group)
+       --cls-only / --mbv3s-scene-only / --widen-only / --labels-only / --shapes-only / --clipper-only regenerate one group)
 """
 import importlib.util
 import json
@@ -398,6 +398,162 @@ def gen_label_vectors():
     print("label-encode vectors:", len(cases))
 
 
+def _load_ref_with_cv2_stub():
+    """The reference's host operators use cv2 only for the final pixel call.  With a `cv2` stub in sys.modules (resize / warpPerspective ->
+    zeros of the requested size, every call's arguments recorded) their SHAPE logic runs here unchanged: sort_boxes, DetResizeForTest,
+    resize_norm_img / RecResizeImgForTest, get_part_img are loaded BY FILE PATH from the reference tree."""
+    calls = []
+    cv2 = types.ModuleType("cv2")
+    cv2.BORDER_REPLICATE, cv2.INTER_LINEAR, cv2.COLOR_GRAY2RGB, cv2.COLOR_BGR2GRAY, cv2.COLOR_BGR2RGB, cv2.IMREAD_COLOR = 1, 1, 8, 6, 4, 1
+
+    def resize(img, dsize, *a, **k):
+        calls.append(("resize", tuple(int(v) for v in dsize), tuple(img.shape)))
+        return np.zeros((dsize[1], dsize[0]) + tuple(img.shape[2:]), img.dtype)
+
+    def get_perspective_transform(src, dst, *a, **k):
+        calls.append(("getPerspectiveTransform", np.asarray(src).copy(), np.asarray(dst).copy()))
+        return np.eye(3)
+
+    def warp_perspective(img, M, dsize, *a, **k):
+        calls.append(("warpPerspective", tuple(int(v) for v in dsize), tuple(img.shape), dict(k)))
+        return np.zeros((dsize[1], dsize[0]) + tuple(img.shape[2:]), img.dtype)
+
+    cv2.resize, cv2.getPerspectiveTransform, cv2.warpPerspective = resize, get_perspective_transform, warp_perspective
+    tv = types.ModuleType("torchvision"); tvt = types.ModuleType("torchvision.transforms"); tvf = types.ModuleType("torchvision.transforms.functional")
+    tv.transforms = tvt; tvt.functional = tvf
+    saved = {k: sys.modules.get(k) for k in ("cv2", "torchvision", "torchvision.transforms", "torchvision.transforms.functional")}
+    sys.modules.update({"cv2": cv2, "torchvision": tv, "torchvision.transforms": tvt, "torchvision.transforms.functional": tvf})
+    mods = {}
+    try:
+        pkg = types.ModuleType("ref_imaug")                      # a package shell so that rec_img_aug's `.text_image_aug` import resolves
+        pkg.__path__ = [os.path.join(REF, "pytocr/data/imaug")]
+        sys.modules["ref_imaug"] = pkg
+        for name, rel in (("ref_utility", "pytocr/utils/utility.py"), ("ref_imaug.operators", "pytocr/data/imaug/operators.py"),
+                          ("ref_imaug.rec_img_aug", "pytocr/data/imaug/rec_img_aug.py")):
+            spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules[name] = mod
+            spec.loader.exec_module(mod)
+            assert os.path.abspath(mod.__file__).startswith(os.path.abspath(REF))
+            mods[name] = mod
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return mods, calls
+
+
+def gen_shape_vectors():
+    """The judge's "free pins" (round-3 VERDICT, item 5): sort_boxes, DetResizeForTest's size / ratio logic, resize_norm_img's width logic,
+    RecResizeImgForTest's batch widths and get_part_img's crop geometry, recorded from the reference's own functions."""
+    import warnings
+    mods, calls = _load_ref_with_cv2_stub()
+    util, ops, rec = mods["ref_utility"], mods["ref_imaug.operators"], mods["ref_imaug.rec_img_aug"]
+    rng = np.random.RandomState(20260)
+    out = {}
+    # ---- sort_boxes (utility.py:32-50): int16 box sets -- rows closer than 10 px, equal keys, chains of inversions, wrap-around rows
+    sets, sorted_sets = [], []
+    for case in range(200):
+        k = int(rng.randint(0, 40))
+        b = np.zeros((k, 4, 2), np.int16)
+        if k:
+            mode = case % 5
+            ys = rng.randint(0, 60 if mode == 0 else 700, k)
+            if mode == 1:
+                ys = (ys // 12) * 12 + rng.randint(0, 9, k)       # text rows: many |dy| < 10 neighbours
+            if mode == 2:
+                ys = rng.choice([5, 5, 14, 15, 24], k)            # equal keys and exact-10 gaps
+            xs = rng.randint(0, 1200, k)
+            if mode == 3:
+                xs = np.sort(xs)[::-1]                            # long chains of inverted neighbours (one pass only)
+            b[:, 0, 0], b[:, 0, 1] = xs, ys
+            if mode == 4:                                         # int16 wrap-around in |dy|
+                b[rng.randint(0, k), 0, 1] = -32768
+                b[rng.randint(0, k), 0, 1] = 32767
+                b[rng.randint(0, k), 0, 1] = -32760
+            b[:, 1:, :] = rng.randint(-5, 1300, (k, 3, 2))        # the other vertices ride along (they identify the box)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")                       # int16 overflow in the reference's abs(): recorded as it behaves
+            r = util.sort_boxes(b if k else np.zeros((0,), np.float32))
+        sets.append(b)
+        sorted_sets.append(np.array(r, np.int16).reshape(-1, 4, 2))
+    out["sort_counts"] = np.array([len(s) for s in sets], np.int32)
+    out["sort_in"] = np.concatenate(sets, 0)
+    out["sort_out"] = np.concatenate(sorted_sets, 0)
+    # ---- DetResizeForTest (operators.py:155-275): (h, w, kwargs) -> requested cv2.resize size, data["shape"]
+    det_cases, det_out = [], []
+    sizes = [(720, 1280), (736, 1280), (960, 1280), (1280, 960), (32, 32), (16, 16), (1, 1000), (1000, 1), (47, 49), (48, 48), (2000, 3000),
+             (735, 1000), (737, 1000), (752, 1000), (751, 999), (1104, 1471), (1105, 1473), (720, 720)]
+    while len(sizes) < 200:
+        sizes.append((int(rng.randint(8, 2500)), int(rng.randint(8, 2500))))
+    kws = [dict(limit_side_len=736, limit_type="min"), dict(limit_side_len=960, limit_type="max"), dict(limit_side_len=1024, limit_type="resize_long"),
+           dict(), dict(image_shape=[640, 960]), dict(resize_long=960), dict(limit_side_len=48, limit_type="min")]
+    for i, (h, w) in enumerate(sizes):
+        for kw in (kws if i < 18 else [kws[i % len(kws)]]):
+            del calls[:]
+            d = ops.DetResizeForTest(**kw)({"image": np.zeros((h, w, 3), np.uint8)})
+            assert len(calls) == 1 and calls[0][0] == "resize"
+            rw, rh = calls[0][1]
+            assert d["image"].shape[:2] == (rh, rw)
+            det_cases.append({"h": h, "w": w, "kw": kw})
+            det_out.append({"resize_h": rh, "resize_w": rw, "shape": [float(v) for v in d["shape"]]})
+    out_json = {"det_resize": [dict(c, **o) for c, o in zip(det_cases, det_out)]}
+    # ---- resize_norm_img (rec_img_aug.py:108-134): requested width; RecResizeImgForTest (:55-106): batch tensor shapes
+    rn = []
+    for i in range(200):
+        h, w = int(rng.randint(4, 120)), int(rng.randint(4, 1500))
+        if i % 7 == 0:
+            h, w = 32, int(rng.choice([320, 319, 321, 100, 10]))
+        gray = bool(i % 2)
+        shape = [1 if gray else 3, 32, int(rng.choice([100, 320, 640]))]
+        padding = i % 5 != 0
+        rw_arg = None if i % 3 else int(rng.randint(1, shape[2] + 1))
+        del calls[:]
+        t = rec.resize_norm_img(np.zeros((h, w) if gray else (h, w, 3), np.uint8), shape, resized_w=rw_arg, padding=padding)
+        assert len(calls) == 1
+        rn.append({"h": h, "w": w, "gray": gray, "image_shape": shape, "padding": padding, "resized_w_arg": rw_arg,
+                   "resize_dsize": list(calls[0][1]), "out_shape": list(t.shape)})
+    out_json["resize_norm_img"] = rn
+    rb = []
+    for i in range(40):
+        n = int(rng.randint(1, 40))
+        hw = [(int(rng.randint(8, 90)), int(rng.randint(8, 2000))) for _ in range(n)]
+        kw = dict(imgC=1, imgH=32, max_w=int(rng.choice([320, 1200])), batch_size=int(rng.choice([4, 16])))
+        op = rec.RecResizeImgForTest(**kw)
+        del calls[:]
+        ts = op([np.zeros(s, np.uint8) for s in hw])
+        rb.append({"hw": hw, "kw": kw, "batch_shapes": [list(t.shape) for t in ts], "resize_dsizes": [list(c[1]) for c in calls]})
+        del calls[:]
+        t1 = op(np.zeros(hw[0], np.uint8))
+        rb[-1]["single_shape"] = list(t1.shape)
+        rb[-1]["single_dsize"] = list(calls[0][1])
+    out_json["rec_resize_for_test"] = rb
+    # ---- get_part_img (utility.py:53-78): crop rectangle, shifted source points, destination points, warp size
+    gp = []
+    for i in range(200):
+        cx, cy = rng.uniform(100, 1100), rng.uniform(100, 800)
+        bw_, bh_ = rng.uniform(4, 300), rng.uniform(4, 120)
+        ang = rng.uniform(-0.6, 0.6) if i % 4 else rng.uniform(1.0, 2.1)      # some upright lines: the rot90 rule of run_ocr.py:189-190
+        c, s_ = np.cos(ang), np.sin(ang)
+        q = np.array([[-bw_, -bh_], [bw_, -bh_], [bw_, bh_], [-bw_, bh_]]) / 2
+        pts = np.round(q @ np.array([[c, s_], [-s_, c]]) + [cx, cy])
+        pts = np.stack([np.clip(pts[:, 0], 0, 1280), np.clip(pts[:, 1], 0, 960)], 1).astype(np.int16)    # DBPostProcess clamps to [0, src] (db_postprocess.cpp:303-311)
+        img = np.zeros((960, 1280, 3), np.uint8)
+        del calls[:]
+        crop = util.get_part_img(img, pts)
+        assert [c_[0] for c_ in calls] == ["getPerspectiveTransform", "warpPerspective"]
+        gp.append({"pts": pts.tolist(), "src": calls[0][1].tolist(), "dst": calls[0][2].tolist(), "dsize": list(calls[1][1]),
+                   "crop_in_shape": list(calls[1][2]), "out_shape": list(crop.shape)})
+    out_json["get_part_img"] = gp
+    np.savez_compressed(os.path.join(GOLD, "sort_boxes.npz"), **out)
+    with open(os.path.join(GOLD, "host_shapes.json"), "w") as f:
+        json.dump(out_json, f)
+    print("shape pins: %d sort sets, %d det sizes, %d rec widths, %d rec batches, %d crops" % (
+        len(sets), len(det_cases), len(rn), len(rb), len(gp)))
+
+
 if __name__ == "__main__":
     if "--cls-only" in sys.argv:
         gen_cls_vectors()
@@ -415,6 +571,9 @@ if __name__ == "__main__":
     if "--labels-only" in sys.argv:
         gen_label_vectors()
         sys.exit(0)
+    if "--shapes-only" in sys.argv:
+        gen_shape_vectors()
+        sys.exit(0)
     if "--clipper-only" not in sys.argv:
         main()
         gen_cls_vectors()                 # adds cls_mbv3s to the contract main() has just rewritten
@@ -423,3 +582,4 @@ if __name__ == "__main__":
         gen_widen_vectors()
     gen_clipper_vectors()
     gen_label_vectors()
+    gen_shape_vectors()
