@@ -262,8 +262,8 @@ int ptocr_dbpost_debug_states(ptocr_dbpost_t h, int img, int k, uint32_t *h_stat
 int ptocr_dbpost_debug_labels(ptocr_dbpost_t h, int img, int H, int W, int32_t *h_labels, int32_t *h_word_labels);
 
 /* Timing experiments only (tools/dbg/post_stamps.py): with PTOCR_DBPOST_STAMPS=1 in the environment when the workspace is created, the
- * two per-border stage kernels record s_memtime stamps of their phases, 16 per record; copies the first n_records records of the
- * last call. */
+ * two per-border stage kernels record s_memtime stamps of their phases, 16 per record; copies the first n_records records.
+ * h_stamps == NULL clears the buffer instead (the next call's records then stand alone). */
 int ptocr_dbpost_debug_stamps(ptocr_dbpost_t h, int64_t *h_stamps, long n_records);
 
 /* ---- pre-process next to the path --------------------------------------------------------------

@@ -709,7 +709,6 @@ __global__ __launch_bounds__(256) void border_states_kernel(const unsigned *__re
     const bool above = y < y_first;
     const unsigned *bimg = bits + (long)img * d.H * d.WW;
     unsigned w = in_range ? bimg[(long)y * d.WW + wi] : 0u;
-    if (d.N < 0 && w) w = 0;                                   // timing experiment (run_chain passes N negated): the scan without any state
     auto ld = [&](int yy, int ww) -> unsigned {                  // (an all-background word has no border point: no neighbour loads)
         return (w && (unsigned)yy < (unsigned)d.H && (unsigned)ww < (unsigned)d.WW) ? bimg[(long)yy * d.WW + ww] : 0u;
     };
@@ -922,26 +921,49 @@ __global__ __launch_bounds__(256) void border_states_kernel(const unsigned *__re
     }
 }
 
+// per-border stage limits the planner below shares with the stage kernels
+constexpr int W_MW = 1024;                // border width a wave takes (wider: the full-size pass)
+constexpr int BAND_WORDS = 256;           // mask words per score band (two LDS planes of this size per wave)
+#ifndef PT_SCORE_UF
+#define PT_SCORE_UF 16
+#endif
+constexpr int SCORE_UF = PT_SCORE_UF;     // 16-byte map loads a lane of the score role keeps in flight
+// rows per score band of a border whose bounding box is bw wide
+__device__ __forceinline__ int band_rows(int bw) { const int pw = (bw + 31) >> 5; return BAND_WORDS / pw > 0 ? BAND_WORDS / pw : 1; }
+__device__ __forceinline__ bool border_is_tiny(int bw, int bh) { return (bw - 1) * (bw - 1) + (bh - 1) * (bh - 1) <= 8; }
+
 // exclusive scan of the state counts over the candidates of one image (borders with <= 2 points are dropped by the
-// reference, db_postprocess.cpp:255, and get no pool space)
+// reference, db_postprocess.cpp:255, and get no pool space); in the same sweep the plan of the score stage: a border that the hull
+// role of border_wave_kernel will not filter out gets one item per band of band_rows() rows of its bounding box -- sc_off[k] = its
+// first item, sc_n[img] = items of the image, sc_item[] = (border | band << 10) of every item
 __global__ __launch_bounds__(1024) void pool_offsets_kernel(Acc *__restrict__ acc, const int *__restrict__ totals,
-                                                            int *__restrict__ flags, DbpostDims d) {
+                                                            int *__restrict__ flags, DbpostDims d, int *__restrict__ sc_off,
+                                                            int *__restrict__ sc_n, int *__restrict__ sc_item, long sc_cap) {
     const int img = blockIdx.x, k = threadIdx.x;
     __shared__ long sh[1024];
+    __shared__ int shb[1024];
     const int num = min(totals[img], MAX_CAND);
-    int n = 0;
-    if (k < num) { const Acc a = acc[(long)img * MAX_CAND + k]; n = a.npts > 2 ? a.nstates : 0; }
-    sh[k] = n;
+    int n = 0, nb = 0;
+    if (k < num) {
+        const Acc a = acc[(long)img * MAX_CAND + k];
+        n = a.npts > 2 ? a.nstates : 0;
+        const int bw = a.xmax - a.xmin + 1, bh = a.ymax - a.ymin + 1;
+        if (n && !border_is_tiny(bw, bh) && bw <= W_MW) { const int R = band_rows(bw); nb = (bh + R - 1) / R; }
+    }
+    sh[k] = n; shb[k] = nb;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
         const long v = k >= off ? sh[k - off] : 0;
+        const int vb = k >= off ? shb[k - off] : 0;
         __syncthreads();
-        sh[k] += v;
+        sh[k] += v; shb[k] += vb;
         __syncthreads();
     }
-    const bool fits = sh[1023] <= d.pool_cap;
+    const bool fits = sh[1023] <= d.pool_cap && shb[1023] <= sc_cap;
     if (k < num && n && fits) acc[(long)img * MAX_CAND + k].off = (int)(sh[k] - n);
-    if (k == 1023 && !fits) atomicOr(&flags[img], 4);
+    if (k < MAX_CAND) sc_off[(long)img * MAX_CAND + k] = shb[k] - nb;
+    if (fits) for (int b = 0; b < nb; b++) sc_item[(long)img * sc_cap + shb[k] - nb + b] = k | (b << 10);      // item -> (border, band): no search in the score role
+    if (k == 1023) { sc_n[img] = fits ? shb[1023] : 0; if (!fits) atomicOr(&flags[img], 4); }
 }
 
 // One-enumeration form: moves the staged records of every word to their borders' pool slots (acc[].off, set by pool_offsets_kernel;
@@ -1958,6 +1980,10 @@ __device__ void rotating_calipers_q4(const F2 *points, int n, float4 *ev, float 
 __device__ __forceinline__ void stamp(long long *st, int i) {
     if (st && (threadIdx.x & 63) == 0) st[i] = (long long)__builtin_amdgcn_s_memtime();
 }
+// the same on the 100 MHz clock all XCDs share (s_memtime counts per XCD from different origins): for timelines across the chip
+__device__ __forceinline__ void stamp_rt(long long *st, int i) {
+    if (st && (threadIdx.x & 63) == 0) st[i] = (long long)__builtin_amdgcn_s_memrealtime();
+}
 __device__ RRect min_area_rect_q4(QuadArena &A, int n, long long *st = nullptr) {
     RRect box; box.cx = box.cy = box.w = box.h = box.angle = 0.f;
     if (n <= 0) return box;                                     // uniform over the quad
@@ -2114,11 +2140,10 @@ enum { ST_OK = 0, ST_SKIP_NPTS = 1, ST_SKIP_SSID = 2, ST_SKIP_SCORE = 3, ST_SKIP
 
 struct Result { int status; int box[8]; float score; float rect[5]; int npix; float distance; };
 
-constexpr int CT_THREADS = 256;
 constexpr int MAXW = 2048;                // widest map the column tables hold
 constexpr int LDS_PLANE_WORDS = 4096;     // full-size pass: mask planes of 131072 pixels in LDS (larger masks go through them in bands)
 constexpr int MAXHULL = 512;              // full-size pass: strict hull vertices of a lattice polygon inside 2048 x 32767 stay far below
-constexpr int S_MW = 1024, S_PLANE = 1984, S_MH = 96;      // small-footprint stages: border width, mask plane words, hull / offset points
+constexpr int S_MH = 96;                  // row pitch of the hull-candidate table (hin)
 
 __device__ __forceinline__ long long cross3(int ax, int ay, int bx, int by, int px, int py) {
     return (long long)(bx - ax) * (py - ay) - (long long)(by - ay) * (px - ax);
@@ -2150,16 +2175,22 @@ __device__ T block_reduce_sum(T v, T *sh) {
 // sum reads the probability map fully coalesced: a half-wave takes the 32 pixels of one mask word.
 // raster == false: returns sum (double; fixed order: per-thread over its words, then the block tree) and pixel count.
 // raster == true: the sum is taken by ONE lane in raster order, the order of cv::mean (only when the decision is within rounding).
-__device__ void score_mask(const unsigned *st, int n, int xmin, int ymin, int bw, int bh, unsigned *border, unsigned *toggle, int plane_words,
-                           const float *pimg, int W, double *red_d, int *red_i, bool raster, double *sum_out, int *cnt_out) {
+__device__ __forceinline__ void stamp_rt(long long *st, int i);
+template <int UF = 8>                                           // 16-byte map loads in flight per lane in the masked sum
+__device__ void score_mask(const unsigned *st, int n, int xmin, int ymin, int bw, int bh, int row_lo, int row_hi, unsigned *border, unsigned *toggle,
+                           int plane_words, const float *pimg, int W, double *red_d, int *red_i, bool raster, double *sum_out, int *cnt_out, long long *ts = nullptr) {
     const int tid = threadIdx.x, nt = blockDim.x;
+    stamp_rt(ts, 0);
     const int pw = (bw + 31) >> 5;
     const int R = plane_words / pw;                             // rows per band (>= 1: callers size the planes for the widest map)
     double s = 0; int cnt = 0;
-    for (int r0 = 0; r0 < bh; r0 += R) {
-        const int rows = min(R, bh - r0);
+    for (int r0 = row_lo; r0 < row_hi; r0 += R) {               // rows [row_lo, row_hi) of the bounding box (the whole mask: 0, bh)
+        const int rows = min(R, row_hi - r0);
         for (int i = tid; i < rows * pw; i += nt) { border[i] = 0; toggle[i] = 0; }
         __syncthreads();
+#if defined(SC_DBG) && (SC_DBG & 2)
+        if (n < 0)
+#endif
         for (int i0 = 0; i0 < n; i0 += 8 * nt)
 #pragma unroll
         for (int u8 = 0; u8 < 8; u8++) {                        // (the compiler hoists the eight loads of a round: independent addresses, no store between them)
@@ -2180,6 +2211,10 @@ __device__ void score_mask(const unsigned *st, int n, int xmin, int ymin, int bw
             }
         }
         __syncthreads();
+        stamp_rt(ts, 1);
+#if defined(SC_DBG) && (SC_DBG & 4)
+        if (n < 0)
+#endif
         for (int y = tid; y < rows; y += nt) {
             unsigned carry = 0;
             for (int w = 0; w < pw; w++) {
@@ -2191,6 +2226,10 @@ __device__ void score_mask(const unsigned *st, int n, int xmin, int ymin, int bw
             }
         }
         __syncthreads();
+        stamp_rt(ts, 2);
+#if defined(SC_DBG) && (SC_DBG & 1)
+        if (n >= 0) { cnt = 1; } else
+#endif
         if (raster) {
             if (tid == 0)
                 for (int y = 0; y < rows; y++)
@@ -2200,44 +2239,61 @@ __device__ void score_mask(const unsigned *st, int n, int xmin, int ymin, int bw
                         while (m) { const int b = __ffs(m) - 1; m &= m - 1; s += (double)prow[b]; }
                     }
         } else {
-            // eight lanes per mask word, four consecutive pixels (one 16-byte load) per lane: a wave instruction covers eight words,
-            // and four of them are in flight per lane (a lone workgroup summing a full-image mask is bound by bytes in flight)
+            // eight lanes per mask word, four consecutive pixels (one 16-byte load) per lane: a wave instruction covers eight words, and
+            // UF of them are in flight per lane.  The stage is a chain of memory round trips, not bytes (round 4: a 256-word band took a
+            // wave eight dependent trips at UF = 4, 7 us median and 47 us in the tail), so the loads are straight-line code -- every
+            // lane loads, from a harmless address when its nibble is empty -- and the word index advances without a division.
             struct __attribute__((packed, aligned(4))) F4 { float v[4]; };
             const int grp = tid >> 3, q = tid & 7;
             const int ng = nt >> 3, nw = rows * pw;
-            constexpr int UF = 8;                                // loads in flight per lane
+            const int qs = ng / pw, rs = ng - qs * pw;           // a step of ng words = qs rows + rs words
+            const float *base = pimg + (long)(r0 + ymin) * W + xmin + 4 * q;
             for (int i0 = grp; i0 < nw; i0 += UF * ng) {
                 F4 v[UF];
                 unsigned mm[UF];
+                int y = i0 / pw, w = i0 - y * pw;
+                bool any_edge = false;
 #pragma unroll
                 for (int u = 0; u < UF; u++) {
                     const int i = i0 + u * ng;
-                    mm[u] = 0;
-                    if (i < nw) {
-                        const unsigned m = (border[i] >> (4 * q)) & 15u;
-                        const int y = i / pw, w = i - y * pw;
-                        const int x = w * 32 + 4 * q;
-                        // the last word of a row may reach past the map's right edge: its bits there are clear, and a load that
-                        // would cross the end of the row is not issued
-                        if (m && xmin + x + 3 < W) { v[u] = *reinterpret_cast<const F4 *>(pimg + (long)(y + r0 + ymin) * W + xmin + x); mm[u] = m; }
-                        else if (m) {
-                            for (int e = 0; e < 4; e++) v[u].v[e] = ((m >> e) & 1u) ? pimg[(long)(y + r0 + ymin) * W + xmin + x + e] : 0.f;
-                            mm[u] = m;
-                        }
-                    }
+                    const unsigned m = i < nw ? (border[i] >> (4 * q)) & 15u : 0u;
+                    // the last word of a row may reach past the map's right edge: its bits there are clear, and a 16-byte load that would
+                    // cross the end of the row is not issued (those few pixels are added one by one below)
+                    const bool edge = xmin + w * 32 + 4 * q + 3 >= W;
+                    any_edge |= edge && m;
+                    mm[u] = edge ? 0u : m;
+                    v[u] = *reinterpret_cast<const F4 *>(mm[u] ? base + (y * W + w * 32) : pimg);
+                    y += qs; w += rs;
+                    if (w >= pw) { w -= pw; y++; }
                 }
 #pragma unroll
-                for (int u = 0; u < UF; u++)
+                for (int u = 0; u < UF; u++) {
 #pragma unroll
-                    for (int e = 0; e < 4; e++)
-                        if ((mm[u] >> e) & 1u) { s += (double)v[u].v[e]; cnt++; }
+                    for (int e = 0; e < 4; e++) s += (double)(((mm[u] >> e) & 1u) ? v[u].v[e] : 0.f);      // (+ 0.0 leaves a sum of non-negative terms as it is)
+                    cnt += __popc(mm[u]);
+                }
+                if (any_edge) {
+                    y = i0 / pw; w = i0 - y * pw;
+                    for (int u = 0; u < UF; u++) {
+                        const int i = i0 + u * ng;
+                        if (i < nw && xmin + w * 32 + 4 * q + 3 >= W) {
+                            const unsigned m = (border[i] >> (4 * q)) & 15u;
+                            for (int e = 0; e < 4; e++)
+                                if ((m >> e) & 1u) { s += (double)base[y * W + w * 32 + e]; cnt++; }
+                        }
+                        y += qs; w += rs;
+                        if (w >= pw) { w -= pw; y++; }
+                    }
+                }
             }
         }
         __syncthreads();
     }
+    stamp_rt(ts, 3);
     if (raster) { *sum_out = s; return; }                        // valid on thread 0
     *sum_out = block_reduce_sum<double>(s, red_d);
     *cnt_out = block_reduce_sum<int>(cnt, red_i);
+    stamp_rt(ts, 4);
 }
 
 // score of a border (db_postprocess.cpp:194-229 + the float compare of :272): parallel sum; when the score lands within 1e-6 of
@@ -2245,11 +2301,11 @@ __device__ void score_mask(const unsigned *st, int n, int xmin, int ymin, int bw
 __device__ float border_score(const unsigned *st, int n, int xmin, int ymin, int bw, int bh, unsigned *border, unsigned *toggle, int plane_words,
                               const float *pimg, int W, double *red_d, int *red_i, double *sh_tie, float box_thresh, int *flag_word, int *npix_out) {
     double total; int npix;
-    score_mask(st, n, xmin, ymin, bw, bh, border, toggle, plane_words, pimg, W, red_d, red_i, false, &total, &npix);
+    score_mask(st, n, xmin, ymin, bw, bh, 0, bh, border, toggle, plane_words, pimg, W, red_d, red_i, false, &total, &npix);
     float score = (float)(npix ? total / npix : 0.0);
     if (fabs((double)score - (double)box_thresh) <= 1e-6) {      // uniform: every thread holds the same total
         double t2; int dummy;
-        score_mask(st, n, xmin, ymin, bw, bh, border, toggle, plane_words, pimg, W, red_d, red_i, true, &t2, &dummy);
+        score_mask(st, n, xmin, ymin, bw, bh, 0, bh, border, toggle, plane_words, pimg, W, red_d, red_i, true, &t2, &dummy);
         if (threadIdx.x == 0) { *sh_tie = t2; atomicOr(flag_word, 2); }
         __syncthreads();
         score = (float)(npix ? *sh_tie / npix : 0.0);
@@ -2516,246 +2572,199 @@ __device__ int unclip_finish(const F2 *pts, int np, F2 *hull, int *stack, float 
     return unclip_box(ub, res, src_w, src_h, use_padding_resize, d);
 }
 
+struct ScorePart { double sum; int cnt; int pad; };
 struct StageArgs {
     const float *maps; const Cand *cands; const int *totals; const Acc *acc; const unsigned *pool;
     Result *results; int *flags; const int *src_wh; F2 *hin; int *hn; float *mini;
-    long long *stamps;                      // timing experiments: s_memtime stamps of the stage kernels' phases, 16 per wave (null: none)
-    int *big_list; int *big_n;              // borders whose mask is too large for one wave: scored by border_score_big_kernel
-    int *list; int *list_n; int *tie;       // two-kernel form: per image the candidates pending their rectangle, their count; per border the score's tie marker
+    long long *stamps;                      // timing experiments: s_memtime stamps of the stage kernels' phases, 16 per record (null: none)
+    int *pend; int *tie;                    // per border: 1 = pending its rectangle (hull role -> quad kernel); the score's tie marker
+    const int *sc_off; const int *sc_n; const int *sc_item;   // score bands: first item of every border, items per image, item -> border | band << 10
+    ScorePart *sc_part; long sc_cap;        // partial sums per item (a fixed slice of sc_cap items per image)
+    int *sc_done;                           // per border: bands finished (returns to zero by itself)
     float box_thresh, unclip_ratio; int use_padding_resize;
-    int dbg_skip;      // timing experiments only (PTOCR_DBPOST_DBG_SKIP; results are wrong by design): bits 0-3 phases of the full-size pass,
-                       // 16 unclip without its rectangle, 32 no unclip, 64 unclip without hull + calipers, 128 unclip with the hull only;
-                       // quad kernel: 256 stop after the first rectangle, 512 stop after the offset, 1024 stop after the sort, 2048 no first rectangle;
-                       // wave kernel: 4096 no score
 };
 
-// ---- stage A kernel: one workgroup per border (12 KB of LDS: fits beside a Winograd workgroup of the next batch's forward)
-__device__ __forceinline__ void hull_body(const StageArgs &a, const DbpostDims &d, int img, int k) {
+
+// ---- the per-border stages (round 4).  Rounds 2-3 gave a border ONE wave for its hull candidates and then its BoxScore mask
+// (db_postprocess.cpp:194-229): 78 us per call = the 160 KB masked sum of the LARGEST border (a merged blob 900 x 45 pixels) by one wave,
+// while the median border took 18 us.  The score needs only the border's states and its bounding box -- not the hull -- and a mask's rows
+// are independent (the crossing parity never leaves a row).  So border_wave_kernel now has two roles in ONE launch: its first blocks
+// compute hull candidates (one wave per border), the others score the masks as BANDS of rows of at most BAND_WORDS words, one band per
+// wave, planned by pool_offsets_kernel from the bounding boxes: the merged blob is six waves' work instead of one's.  The last band of a
+// border to finish (a ticket per border) adds the partial sums in band order -- a fixed order, whoever finishes last.  No block waits
+// for another one.  border_quad_kernel (four lanes per border: rectangle, filters, unclip, second rectangle, final box) follows.
+constexpr int WAVE_NT = 64;               // threads per border in the hull kernel
+#ifndef PT_STAGE_GRID
+#define PT_STAGE_GRID 256
+#endif
+#ifndef PT_SCORE_GRID
+#define PT_SCORE_GRID 256
+#endif
+constexpr int STAGE_GRID = PT_STAGE_GRID;           // hull-role blocks per image (a text-like map has ~150-300 borders of the 1000 slots)
+constexpr int SCORE_GRID = PT_SCORE_GRID;           // score-role blocks per image (each walks the image's band items with this stride)
+
+__device__ __forceinline__ bool border_hull_body(const StageArgs &a, const DbpostDims &d, int img, int k, unsigned *arena) {
     const int tid = threadIdx.x;
     const long bi = (long)img * MAX_CAND + k;
     Result *res = &a.results[bi];
     const Acc ac = a.acc[bi];
-    if (a.flags[img] & 4) { if (tid == 0) res->status = ST_NONE; return; }
-    if (ac.npts <= 2) { if (tid == 0) res->status = ST_SKIP_NPTS; return; }     // db_postprocess.cpp:255
+    if (a.flags[img] & 4) { if (tid == 0) res->status = ST_NONE; return false; }
+    if (ac.npts <= 2) { if (tid == 0) res->status = ST_SKIP_NPTS; return false; }     // db_postprocess.cpp:255
     const int bw = ac.xmax - ac.xmin + 1, bh = ac.ymax - ac.ymin + 1;
-    // Speckle: both sides of a min-area rectangle are projections of the point set, so neither exceeds its diameter, which is
-    // at most the diagonal of the bounding box; a diagonal <= sqrt(8) means ssid < 3 (db_postprocess.cpp:265) without
-    // computing the rectangle.  Noise maps are made of thousands of such borders.
-    if ((bw - 1) * (bw - 1) + (bh - 1) * (bh - 1) <= 8) { if (tid == 0) res->status = ST_SKIP_SSID; return; }
-    if (bw > S_MW) { if (tid == 0) { res->status = ST_DEFER; atomicOr(&a.flags[img], 8); } return; }
-    __shared__ __attribute__((aligned(16))) unsigned arena[3 * S_MW];
-    __shared__ int wave_cnt[CT_THREADS / 64];
-    __shared__ int sh_n;
-    const int n = hull_candidates<S_MW, CT_THREADS>(a.pool + (long)img * d.pool_cap + ac.off, ac.nstates, ac.xmin, bw, arena, a.hin + bi * S_MH, S_MH,
-                                        wave_cnt, &sh_n);
-    if (tid == 0) {
-        if (n > S_MH) { res->status = ST_DEFER; atomicOr(&a.flags[img], 8); }
-        else { a.hn[bi] = n; res->status = ST_PEND_RECT; }
-    }
-}
-
-// ---- stage B kernel: one WAVE per border (3.7 KB of LDS, no other resource: thousands are resident at once, so the stage
-// lasts as long as ONE rectangle).  The rectangle is the reference's sequential float32 code, run by lane 0 on LDS arrays.
-__device__ __forceinline__ void rect_body(const StageArgs &a, const DbpostDims &d, int img, int k) {
-    const long bi = (long)img * MAX_CAND + k;
-    Result *res = &a.results[bi];
-    if (res->status != ST_PEND_RECT) return;                    // uniform over the wave
-    __shared__ F2 cand[S_MH], hull[S_MH];
-    __shared__ int stack[2 * (S_MH + 2)];
-    __shared__ float scratch[3 * S_MH + 4];
-    const int n = a.hn[bi];
-    for (int i = threadIdx.x; i < n; i += 64) cand[i] = a.hin[bi * S_MH + i];
-    __shared__ int sh_hn;
-    __syncthreads();
-    const RRect box = min_area_rect_wave(cand, n, hull, stack, scratch, &sh_hn);
-    if (threadIdx.x == 0) res->status = rect_finish(box, res, reinterpret_cast<float (*)[2]>(a.mini + bi * 8));
-}
-
-// ---- stage C kernel: BoxScore (db_postprocess.cpp:194-229), one workgroup per border (15.6 KB of LDS: mask planes of 63 488 px;
-// a larger mask goes through them in bands of rows)
-__device__ __forceinline__ void score_body(const StageArgs &a, const DbpostDims &d, int img, int k) {
-    const int tid = threadIdx.x;
-    const long bi = (long)img * MAX_CAND + k;
-    Result *res = &a.results[bi];
-    if (res->status != ST_PEND_SCORE) return;                   // uniform over the workgroup (written by an earlier kernel)
-    const Acc ac = a.acc[bi];
-    const int bw = ac.xmax - ac.xmin + 1, bh = ac.ymax - ac.ymin + 1;
-    __shared__ __attribute__((aligned(16))) unsigned planes[2 * S_PLANE];
-    __shared__ double red_d[CT_THREADS / 64];
-    __shared__ int red_i[CT_THREADS / 64];
-    __shared__ double sh_tie;
-    int npix;
-    const float score = border_score(a.pool + (long)img * d.pool_cap + ac.off, ac.nstates, ac.xmin, ac.ymin, bw, bh, planes, planes + S_PLANE, S_PLANE,
-                                     a.maps + (long)img * d.HW, d.W, red_d, red_i, &sh_tie, a.box_thresh, &a.flags[img], &npix);
-    if (tid == 0) {
-        res->score = score; res->npix = npix;
-        res->status = score < a.box_thresh ? ST_SKIP_SCORE : ST_PEND_UNCLIP;              // db_postprocess.cpp:272
-    }
-}
-
-// ---- stage D kernel: one WAVE per border (3.5 KB of LDS): lane 0 offsets the mini-box (double-precision trigonometry), the
-// wave sorts the offset polygon by rank, lane 0 runs the second rectangle and the final box
-__device__ __forceinline__ void unclip_body(const StageArgs &a, const DbpostDims &d, int img, int k) {
-    const long bi = (long)img * MAX_CAND + k;
-    Result *res = &a.results[bi];
-    if (res->status != ST_PEND_UNCLIP) return;                  // uniform over the wave
-    __shared__ F2 raw[S_MH], pts[S_MH], hull[S_MH];
-    __shared__ int stack[2 * (S_MH + 2)];
-    __shared__ float scratch[3 * S_MH + 4];
-    __shared__ long long cl_ws[24];
-    __shared__ int sh_np;
-    const float (*mini)[2] = reinterpret_cast<const float (*)[2]>(a.mini + bi * 8);
-    if (a.dbg_skip & 32) { if (threadIdx.x == 0) res->status = ST_NONE; return; }
-    if (threadIdx.x == 0) {
-        int n0 = unclip_offset(mini, a.unclip_ratio, raw, S_MH, res, &a.flags[img], cl_ws);
-        if (a.dbg_skip & 16) n0 = 0;
-        if (n0 > 0 && n0 <= S_MH && res->distance < UNION_MAX_DISTANCE) n0 = clipper_union_cut(raw, n0, pts, stack);   // Execute's union (scratch: the arrays of the next steps)
-        sh_np = n0;
-    }
-    __syncthreads();
-    const int np = sh_np;
-    if (np > S_MH) { if (threadIdx.x == 0) { res->status = ST_DEFER; atomicOr(&a.flags[img], 8); } return; }
-    // sort by (x, y) like cv::convexHull: every lane ranks its point (equal points keep their order: they are identical anyway)
-    for (int i = threadIdx.x; i < np; i += 64) {
-        const F2 t = raw[i];
-        int rank = 0;
-        for (int j = 0; j < np; j++) {
-            const F2 o = raw[j];
-            rank += (o.x < t.x || (o.x == t.x && (o.y < t.y || (o.y == t.y && j < i)))) ? 1 : 0;
-        }
-        pts[rank] = t;
-    }
-    __shared__ int sh_hn;
-    __syncthreads();
-    RRect ub;
-    if (np <= 0 || (a.dbg_skip & 64)) { ub.cx = 0; ub.cy = 0; ub.w = 1; ub.h = 1; ub.angle = 0; }
-    else if (a.dbg_skip & 128) { ub.cx = 0; ub.cy = 0; ub.h = 1; ub.angle = 0; ub.w = (float)convex_hull_sorted_wave(pts, np < 64 ? np : 64, hull, stack); }
-    else ub = min_area_rect_wave(pts, np, hull, stack, scratch, &sh_hn);
-    if (threadIdx.x == 0) res->status = unclip_box(ub, res, a.src_wh[2 * img], a.src_wh[2 * img + 1], a.use_padding_resize, d);
-}
-
-// The stage kernels proper: STAGE_GRID workgroups per image, each walking candidates k, k + STAGE_GRID, ... -- a text-like map has ~150
-// candidates of the 1000 slots, and 32 000 workgroups that read one word and leave cost each stage ~7 us.
-constexpr int STAGE_GRID = 256;
-#define PT_STAGE_KERNEL(NAME, BODY, BOUNDS) \
-    __global__ BOUNDS void NAME(StageArgs a, DbpostDims d) { \
-        const int img = blockIdx.y, num = min(a.totals[img], MAX_CAND); \
-        for (int k = blockIdx.x; k < num; k += gridDim.x) { \
-            BODY(a, d, img, k); \
-            __syncthreads();                                     /* the body's LDS is reused by the next candidate */ \
-        } \
-    }
-PT_STAGE_KERNEL(hull_kernel, hull_body, __launch_bounds__(CT_THREADS, 6))
-PT_STAGE_KERNEL(rect_kernel, rect_body, __launch_bounds__(64))
-PT_STAGE_KERNEL(score_kernel, score_body, __launch_bounds__(CT_THREADS, 6))
-PT_STAGE_KERNEL(unclip_kernel, unclip_body, __launch_bounds__(64))
-#undef PT_STAGE_KERNEL
-
-// ---- the two-kernel form of the per-border stages (default; PTOCR_DBPOST_STAGES=4 runs the four kernels above).
-// Kernel 1, ONE WAVE per border (6 KB of LDS, no workgroup barrier that spans waves): hull candidates, then -- for every border that
-// is not filtered out before -- the BoxScore mask and its masked mean (the reference scores only borders whose rectangle passes the
-// size filter; scoring the few others as well costs less than a kernel boundary between the two passes over the states), and the
-// border joins its image's list.  Kernel 2, four lanes per border: rectangle, filters, unclip, second rectangle, final box.
-constexpr int WAVE_NT = 64;                // threads per border in kernel 1 (128: 87 us against 78 -- the largest mask sets the time either way)
-constexpr int W_MW = 1024;                // border width a wave takes (wider: the full-size pass)
-constexpr int W_PLANE = 1024;             // mask plane words per wave (a larger mask goes through them in bands of rows)
-constexpr int BIG_MASK_WORDS = 384;       // masks beyond 12 k pixels are scored by a 256-thread workgroup (border_score_big_kernel)
-__device__ __forceinline__ void border_wave_body(const StageArgs &a, const DbpostDims &d, int img, int k) {
-    const int tid = threadIdx.x;
-    const long bi = (long)img * MAX_CAND + k;
-    Result *res = &a.results[bi];
-    const Acc ac = a.acc[bi];
-    if (a.flags[img] & 4) { if (tid == 0) res->status = ST_NONE; return; }
-    if (ac.npts <= 2) { if (tid == 0) res->status = ST_SKIP_NPTS; return; }     // db_postprocess.cpp:255
-    const int bw = ac.xmax - ac.xmin + 1, bh = ac.ymax - ac.ymin + 1;
-    if ((bw - 1) * (bw - 1) + (bh - 1) * (bh - 1) <= 8) { if (tid == 0) res->status = ST_SKIP_SSID; return; }   // see hull_body
-    if (bw > W_MW) { if (tid == 0) { res->status = ST_DEFER; atomicOr(&a.flags[img], 8); } return; }
-    constexpr int ARENA = 2 * W_MW > 2 * W_PLANE ? 2 * W_MW : 2 * W_PLANE;     // (the one-wave form of hull_candidates keeps no x table)
-    __shared__ __attribute__((aligned(16))) unsigned arena[ARENA];             // column tables, then the two mask planes
+    // Speckle: both sides of a min-area rectangle are projections of the point set, so neither exceeds its diameter, which is at most
+    // the diagonal of the bounding box; a diagonal <= sqrt(8) means ssid < 3 (db_postprocess.cpp:265) without computing the rectangle.
+    if (border_is_tiny(bw, bh)) { if (tid == 0) res->status = ST_SKIP_SSID; return false; }
+    if (bw > W_MW) { if (tid == 0) { res->status = ST_DEFER; atomicOr(&a.flags[img], 8); } return false; }
     __shared__ int wave_cnt[WAVE_NT / 64];
     __shared__ int sh_n;
+    const unsigned *st = a.pool + (long)img * d.pool_cap + ac.off;
+    long long *ts = a.stamps ? a.stamps + ((long)img * MAX_CAND + k) * 16 + 12 : nullptr;   // slots 12..13 of the border's record
+    stamp_rt(ts, 0);
+    const int n = hull_candidates<W_MW, WAVE_NT>(st, ac.nstates, ac.xmin, bw, arena, a.hin + bi * S_MH, Q_PTS, wave_cnt, &sh_n);
+    stamp_rt(ts, 1);
+    if (tid == 0) {
+        if (n > Q_PTS) { res->status = ST_DEFER; atomicOr(&a.flags[img], 8); }
+        else { a.hn[bi] = n; res->status = ST_PEND_RECT; }
+    }
+    return n <= Q_PTS;
+}
+
+// ---- score role: one band of one border (one wave)
+__device__ __forceinline__ void score_band_item(const StageArgs &a, const DbpostDims &d, int img, int item, unsigned *planes) {
+    const int tid = threadIdx.x;
+    const int *off = a.sc_off + (long)img * MAX_CAND;
+    const int code = a.sc_item[(long)img * a.sc_cap + item];
+    const int k = code & 1023, band = code >> 10;
+    const long bi = (long)img * MAX_CAND + k;
+    Result *res = &a.results[bi];
+    const Acc ac = a.acc[bi];                                   // (pool_offsets_kernel plans items only for borders the hull role does not filter out)
+    const int bw = ac.xmax - ac.xmin + 1, bh = ac.ymax - ac.ymin + 1;
+    const int R = band_rows(bw), nb = (bh + R - 1) / R;
     __shared__ double red_d[WAVE_NT / 64];
     __shared__ int red_i[WAVE_NT / 64];
-    __shared__ double sh_tie;
+    __shared__ int sh_ticket;
     const unsigned *st = a.pool + (long)img * d.pool_cap + ac.off;
-    long long *ts = a.stamps ? a.stamps + ((long)img * MAX_CAND + k) * 16 + 12 : nullptr;   // slots 12..14 of the border's record
-    stamp(ts, 0);
-    const int n = hull_candidates<W_MW, WAVE_NT>(st, ac.nstates, ac.xmin, bw, arena, a.hin + bi * S_MH, Q_PTS, wave_cnt, &sh_n);
-    stamp(ts, 1);
-    if (n > Q_PTS) { if (tid == 0) { res->status = ST_DEFER; atomicOr(&a.flags[img], 8); } return; }
-    if (tid == 0) a.tie[bi] = 0;
-    __syncthreads();
-    if (a.dbg_skip & 4096) { if (tid == 0) res->status = ST_NONE; return; }
-    if (((bw + 31) >> 5) * bh > BIG_MASK_WORDS && (a.dbg_skip & 65536)) {    // experiment (65536): large masks scored by 256 threads each
-        if (tid == 0) { a.hn[bi] = n; a.big_list[(long)img * MAX_CAND + atomicAdd(&a.big_n[img], 1)] = k; }
-        return;
-    }
-    int npix;
-    const float score = border_score(st, ac.nstates, ac.xmin, ac.ymin, bw, bh, arena, arena + W_PLANE, W_PLANE,
-                                     a.maps + (long)img * d.HW, d.W, red_d, red_i, &sh_tie, a.box_thresh, &a.tie[bi], &npix);
-    stamp(ts, 2);
-    if (tid == 0) {
-        a.hn[bi] = n; res->score = score; res->npix = npix; res->status = ST_PEND_RECT;
-        a.list[(long)img * MAX_CAND + atomicAdd(&a.list_n[img], 1)] = k;
-    }
-}
-
-// (occupancy targets of 3 / 4 / 5 waves per SIMD measured 79 / 80 / 84 us, 12 KB against 8 KB of LDS the same: at ~5 400 borders of ~3 k
-// instructions each the kernel is bound by instruction issue over the chip, not by its footprint)
-__global__ __launch_bounds__(WAVE_NT) void border_wave_kernel(StageArgs a, DbpostDims d) {
-    const int img = blockIdx.y, num = min(a.totals[img], MAX_CAND);
-    for (int k = blockIdx.x; k < num; k += gridDim.x) {
-        border_wave_body(a, d, img, k);
-        __syncthreads();
-    }
-}
-
-// Experiment (PTOCR_DBPOST_DBG_SKIP=65536): the masked mean of a large mask (touching text lines: 900 x 45 pixels, 160 KB of map) takes one
-// wave 127 k cycles; here such borders are scored by 256 threads each and then join the rectangle list.  Measured: the wave kernel
-// 78 -> 74 us, this kernel 21 us -- the wave kernel was bound by its LDS footprint (13 waves per CU, two rounds), not by those borders.
-__global__ __launch_bounds__(CT_THREADS) void border_score_big_kernel(StageArgs a, DbpostDims d) {
-    const int img = blockIdx.y, num = a.big_n[img], tid = threadIdx.x;
-    __shared__ __attribute__((aligned(16))) unsigned planes[2 * S_PLANE];
-    __shared__ double red_d[CT_THREADS / 64];
-    __shared__ int red_i[CT_THREADS / 64];
-    __shared__ double sh_tie;
-    for (int e = blockIdx.x; e < num; e += gridDim.x) {
-        const int k = a.big_list[(long)img * MAX_CAND + e];
-        const long bi = (long)img * MAX_CAND + k;
-        Result *res = &a.results[bi];
-        const Acc ac = a.acc[bi];
-        const int bw = ac.xmax - ac.xmin + 1, bh = ac.ymax - ac.ymin + 1;
-        int npix;
-        const float score = border_score(a.pool + (long)img * d.pool_cap + ac.off, ac.nstates, ac.xmin, ac.ymin, bw, bh, planes, planes + S_PLANE, S_PLANE,
-                                         a.maps + (long)img * d.HW, d.W, red_d, red_i, &sh_tie, a.box_thresh, &a.tie[bi], &npix);
+    const float *pimg = a.maps + (long)img * d.HW;
+    long long *ts = a.stamps ? a.stamps + ((long)img * MAX_CAND + k) * 16 + 14 : nullptr;   // slots 14..15: band 0 of the border
+    if (band == 0) stamp_rt(ts, 0);
+    double total; int npix;
+    score_mask<SCORE_UF>(st, ac.nstates, ac.xmin, ac.ymin, bw, bh, band * R, min(bh, band * R + R), planes, planes + BAND_WORDS, BAND_WORDS, pimg, d.W, red_d, red_i,
+               false, &total, &npix, (a.stamps && band < 2 && img >= 4) ? a.stamps + ((long)img * MAX_CAND + k) * 16 + band * 6 : nullptr);    // (records the quads do not use)
+    if (a.stamps && band < 2 && img >= 4) stamp_rt(a.stamps + ((long)img * MAX_CAND + k) * 16 + band * 6, 5);
+    if (nb > 1) {
+        // partial sums meet through memory: every band stores its pair, then takes a ticket; the holder of the last ticket reads them all.
+        // The XCDs' L2s are not coherent with each other, and a device-scope FENCE here writes back / invalidates a whole L2 (measured:
+        // with two __threadfence() per multi-band border the map loads of every wave on the chip grew tails of 40-70 us).  So the pair
+        // goes out as device-scope relaxed atomic stores (write-through, no cache operation), the wave waits for them to be
+        // acknowledged (a workgroup-scope release = s_waitcnt), and only then takes its ticket; the reader's loads are device-scope
+        // atomics as well and depend on the ticket's value.
+        ScorePart *part = a.sc_part + (long)img * a.sc_cap + off[k];
         if (tid == 0) {
-            res->score = score; res->npix = npix; res->status = ST_PEND_RECT;
-            a.list[(long)img * MAX_CAND + atomicAdd(&a.list_n[img], 1)] = k;
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(&part[band].sum), (unsigned long long)__double_as_longlong(total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&part[band].cnt, npix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+            sh_ticket = __hip_atomic_fetch_add(&a.sc_done[bi], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
+        const bool last = sh_ticket == nb - 1;
+        __syncthreads();
+        if (!last) return;
+        total = 0; npix = 0;
+        for (int b = 0; b < nb; b++) {                          // band order, whoever came last
+            total += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(&part[b].sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            npix += __hip_atomic_load(&part[b].cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid == 0) __hip_atomic_store(&a.sc_done[bi], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the counters clean themselves for the next call
+    }
+    float score = (float)(npix ? total / npix : 0.0);
+    int tie = 0;
+    if (fabs((double)score - (double)a.box_thresh) <= 1e-6) {   // uniform: within rounding of the filter -> cv::mean's raster order decides
+        double t2; int dummy;
+        score_mask<SCORE_UF>(st, ac.nstates, ac.xmin, ac.ymin, bw, bh, 0, bh, planes, planes + BAND_WORDS, BAND_WORDS, pimg, d.W, red_d, red_i, true, &t2, &dummy);
+        __shared__ double sh_tie;
+        if (tid == 0) sh_tie = t2;
+        __syncthreads();
+        score = (float)(npix ? sh_tie / npix : 0.0);
+        tie = 1;
+        __syncthreads();
+    }
+    if (tid == 0) { res->score = score; res->npix = npix; a.tie[bi] = tie; }
+    if (band == 0 || nb > 1) stamp_rt(ts, 1);
+}
+
+// One launch, two roles: blocks [0, STAGE_GRID) of an image walk its borders (hull candidates), the other SCORE_GRID blocks its band items.
+// (the hull role needs 32 VGPRs and the 8 KB column tables, the score role 2 KB and as many registers as it is given for loads in
+// flight: one LDS block for both, and a register budget of five waves per SIMD -- the LDS admits 4.75)
+#ifndef PT_WAVE_OCC
+#define PT_WAVE_OCC 4
+#endif
+__global__ __launch_bounds__(WAVE_NT, PT_WAVE_OCC) void border_wave_kernel(StageArgs a, DbpostDims d) {
+    const int img = blockIdx.y;
+    static_assert(2 * W_MW >= 2 * BAND_WORDS, "the column tables hold the two mask planes of a band");
+    __shared__ __attribute__((aligned(16))) unsigned arena[2 * W_MW];          // hull role: column tables (no x table in the one-wave form); score role: mask planes
+    if (blockIdx.x < STAGE_GRID) {
+#if defined(SC_DBG) && (SC_DBG & 8)
+        return;
+#endif
+        const int num = min(a.totals[img], MAX_CAND);
+        for (int k = blockIdx.x; k < num; k += STAGE_GRID) {
+            // pend[k] = 1: the border goes on to the quads.  (Rounds 2-3 appended k to a per-image list with an atomicAdd: ~170 returning
+            // atomics on ONE address per image, ~200 ns each behind one another, were 35 us of this kernel.)
+            const bool pend = border_hull_body(a, d, img, k, arena);
+            if (threadIdx.x == 0) a.pend[(long)img * MAX_CAND + k] = pend ? 1 : 0;
+            __syncthreads();
+        }
+        return;
+    }
+#if defined(SC_DBG) && (SC_DBG & 16)
+    return;
+#endif
+    const int items = a.sc_n[img];
+    for (int item = blockIdx.x - STAGE_GRID; item < items; item += SCORE_GRID) {
+        score_band_item(a, d, img, item, arena);
+        __syncthreads();
     }
 }
 
+// ---- geometry: FOUR LANES per border, sixteen borders per wave (quad-lane primitives above)
+constexpr int QUAD_GROUPS = (MAX_CAND + 15) / 16;
 __global__ __launch_bounds__(64) void border_quad_kernel(StageArgs a, DbpostDims d) {
-    const int img = blockIdx.y;
-    const int cnt = a.list_n[img];
-    if (blockIdx.x * 16 >= cnt) return;
+    const int img = blockIdx.y, group = blockIdx.x;
     __shared__ QuadArena arena[16];
-    const int c = threadIdx.x & 3, slot = blockIdx.x * 16 + (threadIdx.x >> 2);
+    // the (16 group + j)-th pending border of the image, j = 0 .. 15: every lane reads sixteen of the image's flags, ballots rank them
+    const int num = min(a.totals[img], MAX_CAND);
+    if (group * 16 >= num) return;
+    __shared__ int sh_k[16];
+    const int lane = threadIdx.x;
+    const int *pend = a.pend + (long)img * MAX_CAND;
+    int fl[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) { const int kk = r * 64 + lane; fl[r] = kk < num ? pend[kk] : 0; }
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const unsigned long long bal = __ballot(fl[r] != 0);
+        const int rank = cnt + __popcll(bal & ((1ull << lane) - 1)) - group * 16;
+        if (fl[r] && rank >= 0 && rank < 16) sh_k[rank] = r * 64 + lane;
+        cnt += __popcll(bal);
+    }
+    wave_sync();
+    if (group * 16 >= cnt) return;
+    const int c = threadIdx.x & 3, slot = group * 16 + (threadIdx.x >> 2);
     if (slot >= cnt) return;                                    // whole quads leave; nothing below spans quads
     QuadArena &A = arena[threadIdx.x >> 2];
-    long long *st = a.stamps ? a.stamps + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 16 : nullptr;
+    long long *st = a.stamps ? a.stamps + ((long)img * QUAD_GROUPS + group) * 16 : nullptr;
     stamp(st, 0);
-    const int k = a.list[(long)img * MAX_CAND + slot];
+    const int k = sh_k[threadIdx.x >> 2];
     const long bi = (long)img * MAX_CAND + k;
     Result *res = &a.results[bi];
     const int n = a.hn[bi];
     for (int i = c; i < n; i += 4) A.pts[i] = a.hin[bi * S_MH + i];
     wave_sync();
     // minAreaRect of the border, mini-box, first size filter (db_postprocess.cpp:259-265)
-    RRect box; box.cx = 100; box.cy = 100; box.w = 80; box.h = 20; box.angle = 3;
     stamp(st, 1);
-    if (!(a.dbg_skip & 2048)) box = min_area_rect_q4(A, n, st ? st + 2 : nullptr);      // 2: hull, 3: calipers
+    const RRect box = min_area_rect_q4(A, n, st ? st + 2 : nullptr);      // 2: hull, 3: calipers
     stamp(st, 4);
     float mini[4][2], ssid;
     get_mini_boxes(box, mini, &ssid);
@@ -2767,7 +2776,6 @@ __global__ __launch_bounds__(64) void border_quad_kernel(StageArgs a, DbpostDims
         if (c == 0 && a.tie[bi]) atomicOr(&a.flags[img], 2);    // the score was within rounding of box_thresh and was re-summed in raster order
         status = res->score < a.box_thresh ? ST_SKIP_SCORE : ST_PEND_UNCLIP;          // db_postprocess.cpp:272
     }
-    if (a.dbg_skip & 256) status = ST_NONE;
     if (status == ST_PEND_UNCLIP) {
         // UnClip (db_postprocess.cpp:16-49): distance from the float mini-box, Clipper's round offset of its truncated vertices
         float area = 0.0f, dist = 0.0f;
@@ -2791,7 +2799,6 @@ __global__ __launch_bounds__(64) void border_quad_kernel(StageArgs a, DbpostDims
             wave_sync();
             np = __shfl(np, 0, 4);
         }
-        if (a.dbg_skip & 512) { if (c == 0) res->status = ST_NONE; return; }
         if (np > Q_PTS) { status = ST_DEFER; if (c == 0) atomicOr(&a.flags[img], 8); }
         else {
             // sort by (x, y) like cv::convexHull: every lane ranks a quarter of the points.  The offset polygon has integer vertices, so a
@@ -2822,7 +2829,6 @@ __global__ __launch_bounds__(64) void border_quad_kernel(StageArgs a, DbpostDims
                 }
             }
             wave_sync();
-            if (a.dbg_skip & 1024) { if (c == 0) res->status = ST_NONE; return; }
             stamp(st, 7);
             RRect ub;
             if (np <= 0) { ub.cx = 0; ub.cy = 0; ub.w = 1; ub.h = 1; ub.angle = 0; }
@@ -2866,9 +2872,7 @@ __global__ __launch_bounds__(BIG_THREADS, 1) void contour_big_kernel(StageArgs a
         const Acc ac = a.acc[bi];
         const unsigned *st = a.pool + (long)img * d.pool_cap + ac.off;
         const int bw = ac.xmax - ac.xmin + 1, bh = ac.ymax - ac.ymin + 1;
-        if (a.dbg_skip & 1) { if (tid == 0) res->status = ST_NONE; continue; }
         const int n = hull_candidates<MAXW, BIG_THREADS>(st, ac.nstates, ac.xmin, bw, arena, cand_pts, MAXHULL, wave_cnt, &sh_n);
-        if (a.dbg_skip & 2) { if (tid == 0) res->status = ST_NONE; continue; }
         if (n > MAXHULL) { if (tid == 0) { atomicOr(&a.flags[img], 4); res->status = ST_NONE; } continue; }
         if (tid < 64) {
             const RRect box = min_area_rect_wave(cand_pts, n, hull_pts, stack, cal_scratch, &sh_hn);
@@ -2876,12 +2880,10 @@ __global__ __launch_bounds__(BIG_THREADS, 1) void contour_big_kernel(StageArgs a
         }
         __syncthreads();
         if (sh_status != ST_PEND_SCORE) { if (tid == 0) res->status = sh_status; continue; }
-        if (a.dbg_skip & 4) { if (tid == 0) res->status = ST_NONE; continue; }
         int npix;
         const float score = border_score(st, ac.nstates, ac.xmin, ac.ymin, bw, bh, arena, arena + LDS_PLANE_WORDS, LDS_PLANE_WORDS,
                                          a.maps + (long)img * d.HW, d.W, red_d, red_i, &sh_tie, a.box_thresh, &a.flags[img], &npix);
         __syncthreads();
-        if (a.dbg_skip & 8) { if (tid == 0) res->status = ST_NONE; continue; }
         if (tid == 0) {
             res->score = score; res->npix = npix;
             if (score < a.box_thresh) { res->status = ST_SKIP_SCORE; sh_np = -2; }       // db_postprocess.cpp:272
@@ -2957,10 +2959,10 @@ struct ptocr_dbpost {
     int strip_hint;               // run the bottom-strip labelling pass in the next call (see run_chain)
     unsigned noise_hist;          // bit k: the call k + 1 calls ago met a noise-like image
     int *h_strip;                 // pinned: the strip's run-start counts of the last call
-    int *zeroed;                  // ONE block cleared per call: flags | strip_totals | strip_runs | list_n | big_n (max_n ints each)
+    int *zeroed;                  // ONE block cleared per call: flags | strip_totals | strip_runs (max_n ints each)
     long long *stamps;            // PTOCR_DBPOST_STAMPS=1: phase time stamps of the stage kernels (max_n * MAX_CAND * 16)
-    int *big_list;                // borders with a large mask (per image; their count sits in the cleared block)
-    int *list; int *tie;          // two-kernel stage form: candidates pending their rectangle per image; score tie marker per border
+    int *sc_off; int *sc_n; int *sc_item; ScorePart *sc_part; long sc_cap; int *sc_done;     // score bands: plan, partial sums, tickets (border_wave_kernel)
+    int *list; int *tie;          // per border: pending its rectangle (the quads rank these flags); score tie marker
     uint2 *stage; int2 *stage_hdr; long stage_cap; // one-enumeration form of the border states: staged records (a fixed slice per tile), per-word header
 };
 
@@ -2980,8 +2982,16 @@ extern "C" int ptocr_dbpost_create(ptocr_dbpost_t *out, int max_n, int max_h, in
     PT_HIP(hipMalloc(&h->word_lab, sizeof(int) * max_n * max_h * ww));
     PT_HIP(hipMalloc(&h->chunk_cnt, sizeof(int) * max_n * nch));
     PT_HIP(hipMalloc(&h->totals, sizeof(int) * max_n));
-    PT_HIP(hipMalloc(&h->zeroed, sizeof(int) * 5 * max_n));
-    PT_HIP(hipMalloc(&h->big_list, sizeof(int) * max_n * MAX_CAND));
+    PT_HIP(hipMalloc(&h->zeroed, sizeof(int) * 3 * max_n));
+    // score bands: a border's mask is cut into bands of band_rows() >= BAND_WORDS / (2 pw) rows, so it has at most 2 bh pw / BAND_WORDS + 1
+    // <= max_h / 4 + 1 of them (pw <= 32 words: wider borders go to the full-size pass)
+    h->sc_cap = (long)MAX_CAND * (max_h / 4 + 2);
+    PT_HIP(hipMalloc(&h->sc_off, sizeof(int) * max_n * MAX_CAND));
+    PT_HIP(hipMalloc(&h->sc_n, sizeof(int) * max_n));
+    PT_HIP(hipMalloc(&h->sc_item, sizeof(int) * max_n * h->sc_cap));
+    PT_HIP(hipMalloc(&h->sc_part, sizeof(ScorePart) * max_n * h->sc_cap));
+    PT_HIP(hipMalloc(&h->sc_done, sizeof(int) * max_n * MAX_CAND));
+    PT_HIP(hipMemset(h->sc_done, 0, sizeof(int) * max_n * MAX_CAND));
     PT_HIP(hipHostMalloc(&h->h_strip, sizeof(int) * max_n));
     h->strip_hint = 1;
     h->noise_hist = 0x80u;                      // the first call takes the noise route; a text-like first batch clears it at once
@@ -3022,7 +3032,8 @@ extern "C" int ptocr_dbpost_create(ptocr_dbpost_t *out, int max_n, int max_h, in
 extern "C" int ptocr_dbpost_destroy(ptocr_dbpost_t h) {
     if (!h) return 0;
     void *bufs[] = {h->bits, h->bits2, h->labels, h->word_lab, h->chunk_cnt, h->totals, h->zeroed, h->cands, h->acc, h->pool, h->hin,
-                    h->hn, h->mini, h->results, h->src_wh, h->boxes, h->counts, h->list, h->tie, h->stamps, h->big_list, h->stage, h->stage_hdr};
+                    h->hn, h->mini, h->results, h->src_wh, h->boxes, h->counts, h->list, h->tie, h->stamps, h->sc_off, h->sc_n, h->sc_item, h->sc_part, h->sc_done,
+                    h->stage, h->stage_hdr};
     for (void *b : bufs) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -3070,8 +3081,12 @@ extern "C" int ptocr_dbpost_debug_states(ptocr_dbpost_t h, int img, int k, uint3
 
 // timing experiments (PTOCR_DBPOST_STAMPS=1 at create time): the s_memtime stamps of the last call, 16 per record, max_n * 1000 records
 extern "C" int ptocr_dbpost_debug_stamps(ptocr_dbpost_t h, int64_t *h_stamps, long n_records) {
-    PT_CHECK(h && h->stamps && h_stamps && n_records <= (long)h->max_n * MAX_CAND, "ptocr_dbpost_debug_stamps: no stamp buffer (set PTOCR_DBPOST_STAMPS=1 before creating the workspace)");
+    PT_CHECK(h && h->stamps && n_records <= (long)h->max_n * MAX_CAND, "ptocr_dbpost_debug_stamps: no stamp buffer (set PTOCR_DBPOST_STAMPS=1 before creating the workspace)");
     PT_HIP(hipDeviceSynchronize());
+    if (!h_stamps) {                                            // null destination: clear the buffer (so that the next call's records stand alone)
+        PT_HIP(hipMemset(h->stamps, 0, sizeof(long long) * 16 * (size_t)h->max_n * MAX_CAND));
+        return 0;
+    }
     PT_HIP(hipMemcpy(h_stamps, h->stamps, sizeof(long long) * 16 * n_records, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -3137,7 +3152,7 @@ static void run_chain(ptocr_dbpost *h, const float *d_maps, const uint8_t *d_bit
     }
     for (int pass = strip_y ? 0 : 1; pass < 2; pass++) {
         CclPass ps;
-        ps.dbg = getenv("PTOCR_DBPOST_DBG_SKIP") ? (atoi(getenv("PTOCR_DBPOST_DBG_SKIP")) >> 13) & 3 : 0;      // 8192: merge without unions, 16384: finds only
+        ps.dbg = 0;
         ps.y_first = pass == 0 ? strip_y : 0;
         ps.skip_if_full = (pass == 1 && strip_y) ? w_strip_totals : nullptr;
         ps.skip_if_few = (pass == 0 && counted) ? w_strip_runs : nullptr;
@@ -3166,21 +3181,19 @@ static void run_chain(ptocr_dbpost *h, const float *d_maps, const uint8_t *d_bit
     }
     hipLaunchKernelGGL(select_starts_kernel, dim3(cdiv(d.nchunks, SEL_CHUNKS), N), dim3(256), 0, s, bits, w_labels, w_chunk, w_totals, w_cands, w_acc, d);
     const dim3 all_words(cdiv(cdiv(H, 8) * cdiv(d.WW, 8), 4), N);      // 8 x 8-word tiles, four per block
-    DbpostDims dk = d;
-    if (getenv("PTOCR_DBPOST_DBG_SKIP") && (atoi(getenv("PTOCR_DBPOST_DBG_SKIP")) & 32768)) dk.N = -N;     // 32768: the count pass scans but books nothing
     StageArgs2 sg;
     sg.rec = h->stage ? h->stage + (long)i0 * h->stage_cap : nullptr;
     sg.hdr = h->stage ? h->stage_hdr + (long)i0 * h->max_h * cdiv(h->max_w, 32) : nullptr; sg.cap = h->stage_cap;
     if (h->stage) {
         // ONE enumeration: count + stage, offsets, scatter (the per-image header block is indexed with this call's H x WW)
         hipLaunchKernelGGL((border_states_kernel<false, true>), all_words, dim3(256), 0, s, bits, w_labels, w_word_lab, w_strip_totals, w_acc, w_pool,
-                           w_flags, dk, sg);
-        hipLaunchKernelGGL(pool_offsets_kernel, dim3(N), dim3(1024), 0, s, w_acc, w_totals, w_flags, d);
+                           w_flags, d, sg);
+        hipLaunchKernelGGL(pool_offsets_kernel, dim3(N), dim3(1024), 0, s, w_acc, w_totals, w_flags, d, h->sc_off + (long)i0 * MAX_CAND, h->sc_n + i0, h->sc_item + (long)i0 * h->sc_cap, h->sc_cap);
         hipLaunchKernelGGL(scatter_states_kernel, all_words, dim3(256), 0, s, w_strip_totals, w_acc, w_pool, w_flags, d, sg);
     } else {
         hipLaunchKernelGGL((border_states_kernel<false, false>), all_words, dim3(256), 0, s, bits, w_labels, w_word_lab, w_strip_totals, w_acc, w_pool,
-                           w_flags, dk, sg);
-        hipLaunchKernelGGL(pool_offsets_kernel, dim3(N), dim3(1024), 0, s, w_acc, w_totals, w_flags, d);
+                           w_flags, d, sg);
+        hipLaunchKernelGGL(pool_offsets_kernel, dim3(N), dim3(1024), 0, s, w_acc, w_totals, w_flags, d, h->sc_off + (long)i0 * MAX_CAND, h->sc_n + i0, h->sc_item + (long)i0 * h->sc_cap, h->sc_cap);
         hipLaunchKernelGGL((border_states_kernel<true, false>), all_words, dim3(256), 0, s, bits, w_labels, w_word_lab, w_strip_totals, w_acc, w_pool,
                            w_flags, d, sg);
     }
@@ -3188,21 +3201,12 @@ static void run_chain(ptocr_dbpost *h, const float *d_maps, const uint8_t *d_bit
     a.maps = d_maps; a.cands = w_cands; a.totals = w_totals; a.acc = w_acc; a.pool = w_pool;
     a.results = h->results + (long)i0 * MAX_CAND; a.flags = w_flags; a.src_wh = h->src_wh + 2 * i0; a.hin = h->hin + (long)i0 * MAX_CAND * S_MH; a.hn = h->hn + (long)i0 * MAX_CAND; a.mini = h->mini + (long)i0 * MAX_CAND * 8;
     a.box_thresh = box_thresh; a.unclip_ratio = unclip_ratio; a.use_padding_resize = use_padding_resize;
-    a.dbg_skip = getenv("PTOCR_DBPOST_DBG_SKIP") ? atoi(getenv("PTOCR_DBPOST_DBG_SKIP")) : 0;
-    a.list = h->list + (long)i0 * MAX_CAND; a.list_n = h->zeroed + 3 * h->max_n + i0; a.tie = h->tie + (long)i0 * MAX_CAND;
-    a.big_list = h->big_list + (long)i0 * MAX_CAND; a.big_n = h->zeroed + 4 * h->max_n + i0;
+    a.pend = h->list + (long)i0 * MAX_CAND; a.tie = h->tie + (long)i0 * MAX_CAND;
+    a.sc_off = h->sc_off + (long)i0 * MAX_CAND; a.sc_n = h->sc_n + i0; a.sc_item = h->sc_item + (long)i0 * h->sc_cap; a.sc_part = h->sc_part + (long)i0 * h->sc_cap; a.sc_cap = h->sc_cap;
+    a.sc_done = h->sc_done + (long)i0 * MAX_CAND;
     a.stamps = h->stamps ? h->stamps + (long)i0 * MAX_CAND * 16 : nullptr;
-    static const int four_stages = getenv("PTOCR_DBPOST_STAGES") && atoi(getenv("PTOCR_DBPOST_STAGES")) == 4;
-    if (four_stages) {
-        hipLaunchKernelGGL(hull_kernel, dim3(STAGE_GRID, N), dim3(CT_THREADS), 0, s, a, d);
-        hipLaunchKernelGGL(rect_kernel, dim3(STAGE_GRID, N), dim3(64), 0, s, a, d);
-        hipLaunchKernelGGL(score_kernel, dim3(STAGE_GRID, N), dim3(CT_THREADS), 0, s, a, d);
-        hipLaunchKernelGGL(unclip_kernel, dim3(STAGE_GRID, N), dim3(64), 0, s, a, d);
-    } else {
-        hipLaunchKernelGGL(border_wave_kernel, dim3(STAGE_GRID, N), dim3(WAVE_NT), 0, s, a, d);
-        if (a.dbg_skip & 65536) hipLaunchKernelGGL(border_score_big_kernel, dim3(32, N), dim3(CT_THREADS), 0, s, a, d);
-        hipLaunchKernelGGL(border_quad_kernel, dim3(cdiv(MAX_CAND, 16), N), dim3(64), 0, s, a, d);
-    }
+    hipLaunchKernelGGL(border_wave_kernel, dim3(STAGE_GRID + SCORE_GRID, N), dim3(WAVE_NT), 0, s, a, d);
+    hipLaunchKernelGGL(border_quad_kernel, dim3(QUAD_GROUPS, N), dim3(64), 0, s, a, d);
     hipLaunchKernelGGL(contour_big_kernel, dim3(64, N), dim3(BIG_THREADS), 0, s, a, d);
     hipLaunchKernelGGL(compact_kernel, dim3(N), dim3(1024), 0, s, a.results, w_totals, h->boxes + (long)i0 * max_boxes * 8, h->counts + i0, max_boxes);
 }
@@ -3227,7 +3231,7 @@ extern "C" int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, co
     hipStream_t s = (hipStream_t)stream;
     PT_HIP(hipMemcpyAsync(h->src_wh, h_src_wh, sizeof(int) * 2 * N, hipMemcpyHostToDevice, s));
     PT_HIP(hipEventRecord(h->ev0, s));
-    PT_HIP(hipMemsetAsync(h->zeroed, 0, sizeof(int) * 5 * h->max_n, s));     // flags, strip_totals (stay 0 for an image whose strip pass is left out), strip_runs, list_n, big_n
+    PT_HIP(hipMemsetAsync(h->zeroed, 0, sizeof(int) * 3 * h->max_n, s));     // flags, strip_totals (stay 0 for an image whose strip pass is left out), strip_runs
     // Most kernels of the chain are bound by the latency of ONE image's dependent steps (label chases, per-border geometry), not by
     // the chip: 2 maps take 0.25 ms of kernel time, 32 maps 0.51.  So a batch is cut into up to four parts whose chains run on four
     // streams of the workspace at once (fork / join on events around them): one part's latency-bound kernel fills the CUs another
