@@ -983,15 +983,17 @@ __global__ __launch_bounds__(256) void scatter_states_kernel(const int *__restri
     const uint2 *rec = sg.rec + (long)img * sg.cap + hd.x;
     Acc *ac = acc + (long)img * MAX_CAND;
     unsigned *pl = pool + (long)img * d.pool_cap;
-    // round r handles the r-th record of every word of the wave's tile; the records of a round mostly belong to one or two borders,
-    // and a border's cursor is reserved once per round for all of them (per-record atomics on the cursor of a large border were
-    // the kernel's critical path: every record of the border in one chain of same-address atomics)
+    // A pass takes up to SCATTER_ROUNDS records of every word of the wave's tile into registers; then, candidate by candidate, the wave adds
+    // up what ALL those records need of the border's pool slot and reserves it with ONE returning atomic (round 3 reserved once per
+    // record round and border, and ragged tiles one lane at a time: a returning atomic on a border's cursor takes ~200 ns behind the
+    // previous one on the same address, and a large border met hundreds of them).  A tile with more records per word runs more passes.
     int rounds = hd.y;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) rounds = max(rounds, __shfl_xor(rounds, o));
     if (rounds > SCATTER_ROUNDS) {
-        // ragged borders: many records in some words, few words alive per round -- every lane walks its own records, the states that
-        // are not stretches in groups of up to eight per reservation (0.82 against 0.72 ms per call on the scene checkpoint's maps)
+        // ragged borders: many records in some words and many borders per tile -- the candidate-by-candidate loop below would wait for
+        // one atomic after the other (measured on the scene checkpoint's maps: 127 us against 71); every lane walks its own records
+        // instead, the states that are not stretches in groups of up to eight per reservation, so that the lanes' atomics are in flight together
         unsigned buf[8]; int bn = 0, bk = -1;
         auto wflush = [&]() {
             if (bn) {
@@ -1025,33 +1027,46 @@ __global__ __launch_bounds__(256) void scatter_states_kernel(const int *__restri
         wflush();
         return;
     }
-    for (int r = 0; r < rounds; r++) {
-        const bool have = r < hd.y;
-        const uint2 e = have ? rec[r] : make_uint2(0u, 0u);
-        const int k = (int)(e.y & 0xffffu), len = (int)(e.y >> 16);
-        const int n = have ? (len ? len : 1) : 0;
-        const int off = have ? ac[k].off : -1;
-        bool pend = have && off >= 0;
-        int pos = 0;
+    for (int r0 = 0; r0 < rounds; r0 += SCATTER_ROUNDS) {
+        uint2 e[SCATTER_ROUNDS];
+        unsigned pend = 0;                                      // bit r: record r0 + r exists and is not placed yet
+#pragma unroll
+        for (int r = 0; r < SCATTER_ROUNDS; r++) {
+            e[r] = make_uint2(0u, 0u);
+            if (r0 + r < hd.y) { e[r] = rec[r0 + r]; pend |= 1u << r; }
+        }
         for (;;) {
-            const unsigned long long pm = __ballot(pend);
+            const unsigned long long pm = __ballot(pend != 0u);
             if (!pm) break;
-            const int k0 = __shfl(k, __ffsll((long long)pm) - 1);
-            const bool mine = pend && k == k0;
-            int incl = mine ? n : 0;
+            // the candidate of the first pending record of the first pending lane
+            int kmine = 0;
+#pragma unroll
+            for (int r = SCATTER_ROUNDS - 1; r >= 0; r--) if ((pend >> r) & 1u) kmine = (int)(e[r].y & 0xffffu);
+            const int k0 = __shfl(kmine, __ffsll((long long)pm) - 1);
+            int n = 0;
+            unsigned sel = 0;
+#pragma unroll
+            for (int r = 0; r < SCATTER_ROUNDS; r++)
+                if (((pend >> r) & 1u) && (int)(e[r].y & 0xffffu) == k0) { const int len = (int)(e[r].y >> 16); n += len ? len : 1; sel |= 1u << r; }
+            int incl = n;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane_t >= o) incl += v; }
             const int total = __shfl(incl, 63);
-            const unsigned long long mm = __ballot(mine);
-            const int leader = __ffsll((long long)mm) - 1;
+            const int off = ac[k0].off;                          // the same address on every lane; -1: the reference drops the border
             int base = 0;
-            if (lane_t == leader) base = atomicAdd(&ac[k0].cursor, total);
-            base = __shfl(base, leader);
-            if (mine) { pos = off + base + incl - n; pend = false; }
-        }
-        if (have && off >= 0) {
-            if (len) { for (int j = 0; j < len; j++) pl[pos + j] = e.x + (unsigned)j; }
-            else pl[pos] = e.x;
+            if (off >= 0 && lane_t == 0) base = atomicAdd(&ac[k0].cursor, total);
+            base = __shfl(base, 0);
+            if (off >= 0 && sel) {
+                int pos = off + base + incl - n;
+#pragma unroll
+                for (int r = 0; r < SCATTER_ROUNDS; r++)
+                    if ((sel >> r) & 1u) {
+                        const int len = (int)(e[r].y >> 16);
+                        if (len) { for (int j = 0; j < len; j++) pl[pos + j] = e[r].x + (unsigned)j; pos += len; }
+                        else pl[pos++] = e[r].x;
+                    }
+            }
+            pend &= ~sel;
         }
     }
 }
