@@ -266,6 +266,11 @@ int ptocr_dbpost_debug_labels(ptocr_dbpost_t h, int img, int H, int W, int32_t *
  * h_stamps == NULL clears the buffer instead (the next call's records then stand alone). */
 int ptocr_dbpost_debug_stamps(ptocr_dbpost_t h, int64_t *h_stamps, long n_records);
 
+/* Labelling route of the following calls on this workspace: 0 = chosen from the workspace's last eight calls (default: a noise-like
+ * batch keeps the noise route on for eight calls), 1 = text route (LDS slabs), 2 = noise route (global union-find, bottom strip first).
+ * Boxes never depend on the route (tests/test_gpu_dbpost.py runs every case on both); only the time does. */
+int ptocr_dbpost_set_route(ptocr_dbpost_t h, int route);
+
 /* ---- pre-process next to the path --------------------------------------------------------------
  * Item descriptors live in device memory (arrays of the structs below, natural C layout). */
 typedef struct { long src_off; int sh, sw; int rh, rw; long dst_off; int dh, dw; int flip; int pad_; } ptocr_pre_item;

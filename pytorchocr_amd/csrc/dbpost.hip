@@ -2860,6 +2860,7 @@ __global__ __launch_bounds__(64) void border_quad_kernel(StageArgs a, DbpostDims
 // than 1024 px, more than 96 hull / offset points: usually none; on noise maps the one giant component) through all four stages:
 // the parallel parts on all 16 waves, the rectangles on wave 0 (cooperative forms above)
 constexpr int BIG_THREADS = 1024;
+constexpr int BIG_GRID = 8;                 // workgroups per image (they share the image's list of deferred borders; launching 64 that leave at once cost 5 us)
 __global__ __launch_bounds__(BIG_THREADS, 1) void contour_big_kernel(StageArgs a, DbpostDims d) {
     const int img = blockIdx.y;
     if (!(a.flags[img] & 8)) return;                      // internal bit 3: a small stage deferred at least one border of this image
@@ -2879,10 +2880,26 @@ __global__ __launch_bounds__(BIG_THREADS, 1) void contour_big_kernel(StageArgs a
     __shared__ double sh_tie;
     __shared__ float sh_mini[4][2];
     const int num = min(a.totals[img], MAX_CAND);
-    for (int k = blockIdx.x; k < num; k += gridDim.x) {
+    // the deferred borders of the image in candidate order (every workgroup of the image builds the same list: thread k looks at border k)
+    __shared__ int sh_list[MAX_CAND];
+    __shared__ int sh_wcnt[BIG_THREADS / 64];
+    static_assert(BIG_THREADS >= MAX_CAND, "one thread per candidate");
+    {
+        const bool def = tid < num && a.results[(long)img * MAX_CAND + tid].status == ST_DEFER;
+        const unsigned long long bal = __ballot(def);
+        if ((tid & 63) == 0) sh_wcnt[tid >> 6] = __popcll(bal);
+        __syncthreads();
+        int before = __popcll(bal & ((1ull << (tid & 63)) - 1));
+        for (int w = 0; w < (tid >> 6); w++) before += sh_wcnt[w];
+        if (def) sh_list[before] = tid;
+        __syncthreads();
+    }
+    int ndef = 0;
+    for (int w = 0; w < BIG_THREADS / 64; w++) ndef += sh_wcnt[w];
+    for (int e = blockIdx.x; e < ndef; e += gridDim.x) {
+        const int k = sh_list[e];
         const long bi = (long)img * MAX_CAND + k;
         Result *res = &a.results[bi];
-        if (res->status != ST_DEFER) continue;            // uniform over the workgroup
         __syncthreads();                                  // the LDS below is reused from the previous border
         const Acc ac = a.acc[bi];
         const unsigned *st = a.pool + (long)img * d.pool_cap + ac.off;
@@ -2932,9 +2949,17 @@ __global__ __launch_bounds__(BIG_THREADS, 1) void contour_big_kernel(StageArgs a
 }
 
 // boxes of one image in candidate order -> dense int16 list + count
+// Last kernel of a call: it also hands the image's flag word and strip count to the host copies and CLEARS the per-call block (flags,
+// strip totals, strip run counts) for the next call -- the memset that used to open every call is gone.
 __global__ __launch_bounds__(1024) void compact_kernel(const Result *__restrict__ results, const int *__restrict__ totals,
-                                                       short *__restrict__ boxes, int *__restrict__ counts, int max_boxes) {
+                                                       short *__restrict__ boxes, int *__restrict__ counts, int max_boxes,
+                                                       int *__restrict__ flags, int *__restrict__ strip_totals, int *__restrict__ strip_runs,
+                                                       int *__restrict__ flags_out, int *__restrict__ strip_out) {
     const int img = blockIdx.x, k = threadIdx.x;
+    if (k == 0) {
+        flags_out[img] = flags[img]; strip_out[img] = strip_runs[img];
+        flags[img] = 0; strip_totals[img] = 0; strip_runs[img] = 0;
+    }
     __shared__ int sh[1024];
     const int num = min(totals[img], MAX_CAND);
     const bool ok = k < num && results[(long)img * MAX_CAND + k].status == ST_OK;
@@ -2972,9 +2997,13 @@ struct ptocr_dbpost {
     int timed;
     int *strip_runs;              // per image: run starts (both polarities) in the bottom strip, counted by binarize_kernel
     int strip_hint;               // run the bottom-strip labelling pass in the next call (see run_chain)
+    int route;                    // ptocr_dbpost_set_route: 0 = from the history of this workspace's calls, 1 = text route, 2 = noise route
+    int noise_now;                // the route this call takes
+    int dirty;                    // a call did not finish: the per-call block is cleared before the next one
     unsigned noise_hist;          // bit k: the call k + 1 calls ago met a noise-like image
     int *h_strip;                 // pinned: the strip's run-start counts of the last call
-    int *zeroed;                  // ONE block cleared per call: flags | strip_totals | strip_runs (max_n ints each)
+    int *zeroed;                  // the per-call block: flags | strip_totals | strip_runs (max_n ints each); zero at creation, cleared again by compact_kernel
+    int *flags_out; int *strip_out;   // what the host copies of a call read (compact_kernel)
     long long *stamps;            // PTOCR_DBPOST_STAMPS=1: phase time stamps of the stage kernels (max_n * MAX_CAND * 16)
     int *sc_off; int *sc_n; int *sc_item; ScorePart *sc_part; long sc_cap; int *sc_done;     // score bands: plan, partial sums, tickets (border_wave_kernel)
     int *list; int *tie;          // per border: pending its rectangle (the quads rank these flags); score tie marker
@@ -2997,7 +3026,8 @@ extern "C" int ptocr_dbpost_create(ptocr_dbpost_t *out, int max_n, int max_h, in
     PT_HIP(hipMalloc(&h->word_lab, sizeof(int) * max_n * max_h * ww));
     PT_HIP(hipMalloc(&h->chunk_cnt, sizeof(int) * max_n * nch));
     PT_HIP(hipMalloc(&h->totals, sizeof(int) * max_n));
-    PT_HIP(hipMalloc(&h->zeroed, sizeof(int) * 3 * max_n));
+    PT_HIP(hipMalloc(&h->zeroed, sizeof(int) * 5 * max_n));
+    PT_HIP(hipMemset(h->zeroed, 0, sizeof(int) * 5 * max_n));
     // score bands: a border's mask is cut into bands of band_rows() >= BAND_WORDS / (2 pw) rows, so it has at most 2 bh pw / BAND_WORDS + 1
     // <= max_h / 4 + 1 of them (pw <= 32 words: wider borders go to the full-size pass)
     h->sc_cap = (long)MAX_CAND * (max_h / 4 + 2);
@@ -3011,6 +3041,7 @@ extern "C" int ptocr_dbpost_create(ptocr_dbpost_t *out, int max_n, int max_h, in
     h->strip_hint = 1;
     h->noise_hist = 0x80u;                      // the first call takes the noise route; a text-like first batch clears it at once
     h->flags = h->zeroed; h->strip_totals = h->zeroed + max_n; h->strip_runs = h->zeroed + 2 * max_n;
+    h->flags_out = h->zeroed + 3 * max_n; h->strip_out = h->zeroed + 4 * max_n;
     if (getenv("PTOCR_DBPOST_STAMPS")) {
         PT_HIP(hipMalloc(&h->stamps, sizeof(long long) * 16 * (size_t)max_n * MAX_CAND));
         PT_HIP(hipMemset(h->stamps, 0, sizeof(long long) * 16 * (size_t)max_n * MAX_CAND));
@@ -3115,6 +3146,15 @@ extern "C" int ptocr_dbpost_debug_labels(ptocr_dbpost_t h, int img, int H, int W
     return 0;
 }
 
+// Labelling route of the next calls on this workspace: 0 = chosen from the workspace's last eight calls (default), 1 = text route (LDS
+// slabs), 2 = noise route (global union-find, four threads per word, bottom strip first).  Results never depend on it; tests pin it so
+// that a case exercises the same kernels whatever ran before.
+extern "C" int ptocr_dbpost_set_route(ptocr_dbpost_t h, int route) {
+    PT_CHECK(h && route >= 0 && route <= 2, "ptocr_dbpost_set_route: route must be 0 (auto), 1 (text) or 2 (noise)");
+    h->route = route;
+    return 0;
+}
+
 // device time (HIP events on the call's stream) from the first to the last kernel of the last call on this workspace
 extern "C" int ptocr_dbpost_last_device_ms(ptocr_dbpost_t h, float *ms) {
     PT_CHECK(h && ms && h->timed, "ptocr_dbpost_last_device_ms: no completed call on this workspace");
@@ -3145,7 +3185,7 @@ static void run_chain(ptocr_dbpost *h, const float *d_maps, const uint8_t *d_bit
     // (Also tried: the 5-us single-block kernels -- chunk suffix sums, pool offsets, box compaction -- as "last block of the image"
     // tails of their predecessors: the ticket atomics and the lone tail block cost more than the launches saved, 0.504 against 0.490 ms.)
     const bool counted = !d_bitmap && !use_dilation;
-    const int strip_y = (H > 2 * STRIP_ROWS && (h->strip_hint || !counted)) ? H - STRIP_ROWS : 0;      // small maps: one pass over everything
+    const int strip_y = (H > 2 * STRIP_ROWS && (h->noise_now || !counted)) ? H - STRIP_ROWS : 0;      // small maps: one pass over everything
     d.strip_y = strip_y;
     // run starts in the strip, counted while binarizing: an upper bound of the strip's components.  Below MAX_CAND the strip pass cannot
     // be enough and is left out for that image (its four kernels return at once); a caller's own bitmap or the dilation is not counted
@@ -3175,7 +3215,7 @@ static void run_chain(ptocr_dbpost *h, const float *d_maps, const uint8_t *d_bit
         const dim3 word_grid(cdiv(words > d.nchunks ? words : d.nchunks, 256), N);
         ps.row_step = 0;
         static const int global_ccl = getenv("PTOCR_DBPOST_GLOBAL_CCL") && atoi(getenv("PTOCR_DBPOST_GLOBAL_CCL")) == 1;
-        if (h->strip_hint || !counted) {                            // noise route (or no count): the global union-find, four threads per word
+        if (h->noise_now || !counted) {                             // noise route (or no count): the global union-find, four threads per word
             hipLaunchKernelGGL(ccl_init_kernel, word_grid, dim3(256), 0, s, bits, w_labels, w_chunk, d, ps);
             hipLaunchKernelGGL(ccl_merge_kernel<4>, dim3(cdiv(4 * words, 256), N), dim3(256), 0, s, bits, w_labels, d, ps);
         } else if (global_ccl) {                                    // rounds 2-3: global union-find, one thread per word
@@ -3222,8 +3262,9 @@ static void run_chain(ptocr_dbpost *h, const float *d_maps, const uint8_t *d_bit
     a.stamps = h->stamps ? h->stamps + (long)i0 * MAX_CAND * 16 : nullptr;
     hipLaunchKernelGGL(border_wave_kernel, dim3(STAGE_GRID + SCORE_GRID, N), dim3(WAVE_NT), 0, s, a, d);
     hipLaunchKernelGGL(border_quad_kernel, dim3(QUAD_GROUPS, N), dim3(64), 0, s, a, d);
-    hipLaunchKernelGGL(contour_big_kernel, dim3(64, N), dim3(BIG_THREADS), 0, s, a, d);
-    hipLaunchKernelGGL(compact_kernel, dim3(N), dim3(1024), 0, s, a.results, w_totals, h->boxes + (long)i0 * max_boxes * 8, h->counts + i0, max_boxes);
+    hipLaunchKernelGGL(contour_big_kernel, dim3(BIG_GRID, N), dim3(BIG_THREADS), 0, s, a, d);
+    hipLaunchKernelGGL(compact_kernel, dim3(N), dim3(1024), 0, s, a.results, w_totals, h->boxes + (long)i0 * max_boxes * 8, h->counts + i0, max_boxes,
+                       w_flags, w_strip_totals, w_strip_runs, h->flags_out + i0, h->strip_out + i0);
 }
 
 extern "C" int ptocr_db_postprocess(ptocr_dbpost_t h, const float *d_maps, const uint8_t *d_bitmap, int N, int H, int W,
@@ -3245,8 +3286,10 @@ extern "C" int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, co
     PT_CHECK(max_boxes >= 1 && max_boxes <= MAX_CAND, "ptocr_db_postprocess: max_boxes must be in [1, %d]", MAX_CAND);
     hipStream_t s = (hipStream_t)stream;
     PT_HIP(hipMemcpyAsync(h->src_wh, h_src_wh, sizeof(int) * 2 * N, hipMemcpyHostToDevice, s));
+    if (h->dirty) PT_HIP(hipMemsetAsync(h->zeroed, 0, sizeof(int) * 3 * h->max_n, s));      // (compact_kernel of a finished call leaves the block clear)
+    h->dirty = 1;
+    h->noise_now = h->route == 1 ? 0 : (h->route == 2 ? 1 : h->strip_hint);
     PT_HIP(hipEventRecord(h->ev0, s));
-    PT_HIP(hipMemsetAsync(h->zeroed, 0, sizeof(int) * 3 * h->max_n, s));     // flags, strip_totals (stay 0 for an image whose strip pass is left out), strip_runs
     // Most kernels of the chain are bound by the latency of ONE image's dependent steps (label chases, per-border geometry), not by
     // the chip: 2 maps take 0.25 ms of kernel time, 32 maps 0.51.  So a batch is cut into up to four parts whose chains run on four
     // streams of the workspace at once (fork / join on events around them): one part's latency-bound kernel fills the CUs another
@@ -3270,10 +3313,11 @@ extern "C" int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, co
     PT_HIP(hipEventRecord(h->ev1, s));
     h->timed = 1;
     PT_HIP(hipMemcpyAsync(h_counts, h->counts, sizeof(int) * N, hipMemcpyDeviceToHost, s));
-    PT_HIP(hipMemcpyAsync(h_flags, h->flags, sizeof(int) * N, hipMemcpyDeviceToHost, s));
-    PT_HIP(hipMemcpyAsync(h->h_strip, h->strip_runs, sizeof(int) * N, hipMemcpyDeviceToHost, s));
+    PT_HIP(hipMemcpyAsync(h_flags, h->flags_out, sizeof(int) * N, hipMemcpyDeviceToHost, s));
+    PT_HIP(hipMemcpyAsync(h->h_strip, h->strip_out, sizeof(int) * N, hipMemcpyDeviceToHost, s));
     PT_HIP(hipMemcpyAsync(h_boxes, h->boxes, sizeof(short) * 8 * (size_t)N * max_boxes, hipMemcpyDeviceToHost, s));
     PT_HIP(hipStreamSynchronize(s));
+    h->dirty = 0;
     for (int i = 0; i < N; i++) h_flags[i] &= 7;           // bit 3 is internal (deferred borders)
     if (!d_bitmap && !use_dilation) {
         // the noise route stays on for eight calls after the last noise-like image: a workspace fed text-like and noise-like batches in

@@ -23,6 +23,14 @@ class _Workspace:
     def __init__(self):
         self.handle = None
         self.dims = (0, 0, 0)
+        self.route = 0
+
+    def set_route(self, route):
+        """labelling route of the following calls: 0 = from the workspace's call history (default), 1 = text route, 2 = noise route
+        (boxes never depend on it; kept across a regrowth of the workspace)"""
+        self.route = int(route)
+        if self.handle is not None:
+            _lib.check(_lib.lib().ptocr_dbpost_set_route(self.handle, self.route), "ptocr_dbpost_set_route")
 
     def get(self, n, h, w):
         mn, mh, mw = self.dims
@@ -32,6 +40,8 @@ class _Workspace:
             hd = C.c_void_p()
             _lib.check(_lib.lib().ptocr_dbpost_create(C.byref(hd), *dims), "ptocr_dbpost_create")
             self.handle, self.dims = hd, dims
+            if self.route:
+                _lib.check(_lib.lib().ptocr_dbpost_set_route(hd, self.route), "ptocr_dbpost_set_route")
         return self.handle
 
     def host_buffers(self, n):

@@ -30,9 +30,17 @@ class Info(C.Structure):
     _fields_ = [("npts", C.c_int), ("off", C.c_int), ("xmin", C.c_short), ("xmax", C.c_short), ("ymin", C.c_short), ("ymax", C.c_short)]
 
 
-def _gpu(maps, src_wh, thresh=0.3, box_thresh=0.5, ratio=1.7):
-    from pytorchocr_amd.postprocess.db_postprocess import device_boxes
-    return device_boxes(torch.from_numpy(maps).cuda(), src_wh, thresh, box_thresh, ratio)
+ROUTES = {1: "text route (LDS slabs)", 2: "noise route (global union-find, strip first)"}
+
+
+def _gpu(maps, src_wh, thresh=0.3, box_thresh=0.5, ratio=1.7, route=0):
+    """route: 0 = whatever the workspace's call history says, 1 / 2 = pinned (ptocr_dbpost_set_route) for this call"""
+    from pytorchocr_amd.postprocess import db_postprocess as m
+    m._ws.set_route(route)
+    try:
+        return m.device_boxes(torch.from_numpy(maps).cuda(), src_wh, thresh, box_thresh, ratio)
+    finally:
+        m._ws.set_route(0)
 
 
 def _debug(img, W):
@@ -47,14 +55,11 @@ def _debug(img, W):
 SLIVER_STATS = {"borders": 0, "thin": 0, "thin_differs_from_real_clipper": 0}
 
 
-def _compare(maps, src_wh, thresh=0.3, box_thresh=0.5, ratio=1.7, strict=True):
-    """GPU against the oracle WITH THE REFERENCE'S OWN CLIPPER (oracle/_ref, compiled from the reference's clipper.cpp) in its
-    unclip step, border by border, every border; the oracle with the RESTATED offset + union must agree with it as well."""
-    n, H, W = maps.shape
-    got, flags = _gpu(maps, src_wh, thresh, box_thresh, ratio)
+def _oracle(maps, src_wh, thresh, box_thresh, ratio):
+    """per image: boxes + per-border records of the oracle with the RESTATED offset / union and with THE REFERENCE'S OWN CLIPPER"""
     have_ref = dbpost.ref_lib() is not None
-    nthin = 0
-    for i in range(n):
+    out = []
+    for i in range(maps.shape[0]):
         bm = dbpost.binarize(maps[i], thresh)
         dbpost.use_reference_clipper(False)
         exp_r, dbg_r, ncont = dbpost.boxes_from_bitmap(maps[i], bm, box_thresh, ratio, src_wh[i][0], src_wh[i][1], True)
@@ -64,36 +69,55 @@ def _compare(maps, src_wh, thresh=0.3, box_thresh=0.5, ratio=1.7, strict=True):
             dbpost.use_reference_clipper(False)
         else:
             exp, dbg = exp_r, dbg_r
-        tot, res, cands, info = _debug(i, W)
-        msg = ""
-        # the GPU stops counting once the bottom strip alone holds the 1000 borders the reference keeps
-        if (tot != ncont) if ncont < 1000 else (tot < 1000 or tot > ncont):
-            msg = "image %d: %d borders on the GPU, %d in the oracle" % (i, tot, ncont)
-        else:
-            for k in range(min(tot, 1000)):
-                d, r, dr = dbg[k], res[k], dbg_r[k]
-                trig = d.trig_y * W + d.trig_x
-                if cands[k].p != trig or cands[k].is_hole != d.is_hole or info[k].npts != d.npts:
-                    msg = "image %d border %d: start/kind/npts (%d,%d,%d) vs oracle (%d,%d,%d)" % (
-                        i, k, cands[k].p, cands[k].is_hole, info[k].npts, trig, d.is_hole, d.npts)
+        out.append((exp_r, dbg_r, ncont, exp, dbg))
+    return out
+
+
+def _compare(maps, src_wh, thresh=0.3, box_thresh=0.5, ratio=1.7, strict=True, routes=(1, 2)):
+    """GPU against the oracle WITH THE REFERENCE'S OWN CLIPPER (oracle/_ref, compiled from the reference's clipper.cpp) in its
+    unclip step, border by border, every border; the oracle with the RESTATED offset + union must agree with it as well.  Every case
+    runs on BOTH labelling routes, pinned with ptocr_dbpost_set_route, so that what a case exercises does not depend on what ran on
+    the module's workspace before it (the route is named in every message)."""
+    n, H, W = maps.shape
+    oracle = _oracle(maps, src_wh, thresh, box_thresh, ratio)
+    nthin = 0
+    got = flags = None
+    for route in routes:
+        where = ROUTES.get(route, "route from the call history")
+        got, flags = _gpu(maps, src_wh, thresh, box_thresh, ratio, route=route)
+        for i in range(n):
+            exp_r, dbg_r, ncont, exp, dbg = oracle[i]
+            tot, res, cands, info = _debug(i, W)
+            msg = ""
+            # the GPU stops counting once the bottom strip alone holds the 1000 borders the reference keeps
+            if (tot != ncont) if ncont < 1000 else (tot < 1000 or tot > ncont):
+                msg = "image %d: %d borders on the GPU, %d in the oracle" % (i, tot, ncont)
+            else:
+                for k in range(min(tot, 1000)):
+                    d, r, dr = dbg[k], res[k], dbg_r[k]
+                    trig = d.trig_y * W + d.trig_x
+                    if cands[k].p != trig or cands[k].is_hole != d.is_hole or info[k].npts != d.npts:
+                        msg = "image %d border %d: start/kind/npts (%d,%d,%d) vs oracle (%d,%d,%d)" % (
+                            i, k, cands[k].p, cands[k].is_hole, info[k].npts, trig, d.is_hole, d.npts)
+                        break
+                    thin = dr.status in (0, 4, 5) and dr.distance < 0.75
+                    if route == routes[0]:
+                        SLIVER_STATS["borders"] += 1
+                        nthin += thin
+                        SLIVER_STATS["thin"] += thin
+                    same_real = r.status == d.status and (d.status != 0 or list(r.box) == list(d.box))
+                    same_rest = dr.status == d.status and (d.status != 0 or list(dr.box) == list(d.box))
+                    if same_real and same_rest:
+                        continue
+                    SLIVER_STATS["thin_differs_from_real_clipper"] += thin
+                    msg = "image %d border %d: status %d box %r vs oracle (real Clipper) %d %r; restated oracle %d %r (score %r vs %r, rect %r vs %r, distance %r)" % (
+                        i, k, r.status, list(r.box), d.status, list(d.box), dr.status, list(dr.box), r.score, d.score, list(r.rect), list(d.rect), d.distance)
                     break
-                SLIVER_STATS["borders"] += 1
-                thin = dr.status in (0, 4, 5) and dr.distance < 0.75
-                nthin += thin
-                SLIVER_STATS["thin"] += thin
-                same_real = r.status == d.status and (d.status != 0 or list(r.box) == list(d.box))
-                same_rest = dr.status == d.status and (d.status != 0 or list(dr.box) == list(d.box))
-                if same_real and same_rest:
-                    continue
-                SLIVER_STATS["thin_differs_from_real_clipper"] += thin
-                msg = "image %d border %d: status %d box %r vs oracle (real Clipper) %d %r; restated oracle %d %r (score %r vs %r, rect %r vs %r, distance %r)" % (
-                    i, k, r.status, list(r.box), d.status, list(d.box), dr.status, list(dr.box), r.score, d.score, list(r.rect), list(d.rect), d.distance)
-                break
-        assert not msg, msg
-        assert got[i].dtype == np.int16 and got[i].shape == (len(exp), 4, 2)
-        assert np.array_equal(got[i].astype(np.int32), exp), "image %d: boxes differ" % i
-        assert np.array_equal(exp_r, exp), "image %d: restated oracle differs from the oracle with the reference's Clipper" % i
-        assert not (flags[i] & 1)                               # bit 0 (sub-pixel sliver exception) no longer exists
+            assert not msg, "%s [%s]" % (msg, where)
+            assert got[i].dtype == np.int16 and got[i].shape == (len(exp), 4, 2), where
+            assert np.array_equal(got[i].astype(np.int32), exp), "image %d: boxes differ [%s]" % (i, where)
+            assert np.array_equal(exp_r, exp), "image %d: restated oracle differs from the oracle with the reference's Clipper" % i
+            assert not (flags[i] & 1)                           # bit 0 (sub-pixel sliver exception) no longer exists
     return got, flags, nthin
 
 
@@ -117,18 +141,29 @@ def test_noisy_maps_many_tiny_borders():
         _compare(m, [[w, h]], thresh=0.3 + 0.2 * seed, box_thresh=0.5)
 
 
-def test_speckle_after_text_like_batches_goes_through_the_slab_kernel():
-    """the labelling route follows the previous calls: after nine text-like calls the workspace is on the text route (LDS slabs), and a
-    speckle batch then meets slabs with far more runs than the LDS tables hold -- each such slab falls back to the global union-find
-    inside the slab kernel; borders and boxes must still be the oracle's.  (The next call is back on the noise route.)"""
+def test_speckle_on_the_text_route_goes_through_the_slab_kernels_fallback():
+    """_compare pins both routes for every case; on the TEXT route (LDS slabs) a speckle batch meets slabs with far more runs than the
+    LDS tables hold -- each such slab falls back to the global union-find inside the slab kernel; borders and boxes must still be the
+    oracle's."""
     clean = synth_prob_maps(1, 192, 1280, seed=3)
-    for _ in range(9):
-        _gpu(clean, [[1280, 192]])
     rng = np.random.default_rng(77)
     noisy = (rng.uniform(size=(2, 192, 1280)) < 0.5).astype(np.float32) * 0.9 + 0.05       # ~640 runs per row: 5 100 per 8-row slab (tables: 4 096)
     noisy[1, :96] = clean[0, :96]                                  # second image: clean top half, speckle bottom half
     _compare(noisy, [[1280, 192], [2560, 384]])
     _compare(clean, [[1280, 192]])
+
+
+def test_route_from_the_call_history_matches_the_pinned_routes():
+    """route 0 (the default of the product): text-like calls move the workspace to the text route, one noise-like batch brings the noise
+    route back for eight calls; the boxes of every call equal the pinned routes' (which _compare holds to the oracle)."""
+    clean = synth_prob_maps(1, 192, 1280, seed=3)
+    rng = np.random.default_rng(5)
+    noisy = (rng.uniform(size=(1, 192, 1280)) < 0.5).astype(np.float32) * 0.9 + 0.05
+    ref_clean, _, _ = _compare(clean, [[1280, 192]])
+    ref_noisy, _, _ = _compare(noisy, [[1280, 192]])
+    for maps, ref in [(clean, ref_clean)] * 10 + [(noisy, ref_noisy), (clean, ref_clean), (noisy, ref_noisy)] + [(clean, ref_clean)] * 9:
+        got, _ = _gpu(maps, [[1280, 192]], route=0)
+        assert np.array_equal(got[0], ref[0])
 
 
 def test_strip_pass_is_chosen_per_image_and_never_changes_the_result():
