@@ -725,7 +725,11 @@ __global__ __launch_bounds__(256) void border_states_kernel(const unsigned *__re
     unsigned *pl = pool + (long)img * d.pool_cap;
     int f_key = -2, F = FRAME, S = -3, kF = -1;                 // cached: run of the current pixel -> its component, its surround, its candidate
     int n_key = -2, BN = FRAME, kN = -1, s_key = -2, BS = FRAME, kS = -1;   // cached: background run above / below -> component, candidate
-    int ak = -1, an = 0, ap = 0, ax0 = 0x7fffffff, ax1 = -1;    // count mode: pending totals of candidate ak
+    // count mode: pending totals of TWO candidates per thread (a word mostly meets a text line's outer border and at most one hole or
+    // neighbour; every total a thread books alone instead of through the wave's combination below is six atomics on a border's
+    // record, and those were a third of this kernel: 22 of 63 us)
+    int ak = -1, an = 0, ap = 0, ax0 = 0x7fffffff, ax1 = -1;
+    int bk2 = -1, bn2 = 0, bp2 = 0, bx0 = 0x7fffffff, bx1 = -1;
     unsigned buf[8]; int bn = 0, bk = -1;                       // write mode: pending states of candidate bk (one slot reservation per 8)
     auto wflush = [&]() {
         if (bn) {
@@ -738,12 +742,23 @@ __global__ __launch_bounds__(256) void border_states_kernel(const unsigned *__re
             bn = 0;
         }
     };
-    auto flush = [&]() {
-        if (ak >= 0) {
-            atomicAdd(&ac[ak].nstates, an); atomicAdd(&ac[ak].npts, ap);
-            atomicMin(&ac[ak].xmin, ax0); atomicMax(&ac[ak].xmax, ax1);
-            atomicMin(&ac[ak].ymin, y); atomicMax(&ac[ak].ymax, y);
+    // states and contour points of a border go out as ONE 64-bit add (the two counters are neighbours in Acc)
+    auto book = [&](int k, int n, int np, int x0, int x1, int y0, int y1) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(&ac[k].nstates), (unsigned long long)(unsigned)n | ((unsigned long long)(unsigned)np << 32));
+        atomicMin(&ac[k].xmin, x0); atomicMax(&ac[k].xmax, x1);
+        atomicMin(&ac[k].ymin, y0); atomicMax(&ac[k].ymax, y1);
+    };
+    // make candidate k the current one (slot a): it may be waiting in slot b; a third candidate pushes the older one out
+    auto select_k = [&](int k) {
+        if (k == ak) return;
+        if (k == bk2) {
+            int t;
+            t = ak; ak = bk2; bk2 = t; t = an; an = bn2; bn2 = t; t = ap; ap = bp2; bp2 = t; t = ax0; ax0 = bx0; bx0 = t; t = ax1; ax1 = bx1; bx1 = t;
+            return;
         }
+        if (bk2 >= 0) book(bk2, bn2, bp2, bx0, bx1, y, y);
+        bk2 = ak; bn2 = an; bp2 = ap; bx0 = ax0; bx1 = ax1;
+        ak = k; an = 0; ap = 0; ax0 = 0x7fffffff; ax1 = -1;
     };
     // component of pixel i of this word (cached per run), the background component that surrounds it, its candidate
     auto look_f = [&](int i) {
@@ -831,7 +846,7 @@ __global__ __launch_bounds__(256) void border_states_kernel(const unsigned *__re
                     for (int j = 0; j < len; j++) pl[pos + j] = base + (unsigned)j;
                 }
             } else {
-                if (k != ak) { flush(); ak = k; an = 0; ap = 0; ax0 = 0x7fffffff; ax1 = -1; }
+                select_k(k);
                 an += len; ax0 = min(ax0, x0); ax1 = max(ax1, x0 + len - 1);
                 if (STAGE && sok) sg.rec[spos++] = make_uint2((unsigned)x0 | ((unsigned)y << 11) | code, (unsigned)k | ((unsigned)len << 16));
             }
@@ -887,7 +902,7 @@ __global__ __launch_bounds__(256) void border_states_kernel(const unsigned *__re
                 buf[0] = (unsigned)x | ((unsigned)y << 11) | ((unsigned)s_out << 26) | ((unsigned)s_in << 29);
                 bn++;
             } else {
-                if (k != ak) { flush(); ak = k; an = 0; ap = 0; ax0 = 0x7fffffff; ax1 = -1; }
+                select_k(k);
                 an++; ap += emit; ax0 = min(ax0, x); ax1 = max(ax1, x);
                 if (STAGE && sok) sg.rec[spos++] = make_uint2((unsigned)x | ((unsigned)y << 11) | ((unsigned)s_out << 26) | ((unsigned)s_in << 29), (unsigned)k);
             }
@@ -896,28 +911,30 @@ __global__ __launch_bounds__(256) void border_states_kernel(const unsigned *__re
     if (WRITE) { wflush(); return; }
     if (STAGE && in_range) sg.hdr[((long)img * d.H + y) * d.WW + wi] = make_int2((int)(sbase - (long)img * sg.cap), (int)(spos - sbase));
     // count mode: the totals still pending are combined across the wave first -- the 64 words of a wave mostly belong to one or
-    // two borders, and the six atomics of a border are all-to-one (every thread of a border hits the same words)
-    for (;;) {
-        const unsigned long long pend = __ballot(ak >= 0);
+    // two borders, and the atomics of a border are all-to-one (every thread of a border hits the same record); both slots of a thread
+    // take part (a thread's two candidates differ, so one round never has to add a thread twice)
+    for (int round = 0;; round++) {
+        const unsigned long long pend = __ballot(ak >= 0 || bk2 >= 0);
         if (!pend) break;
-        const int k0 = __shfl(ak, __ffsll((long long)pend) - 1);
-        const bool mine = ak == k0;
-        int vn = mine ? an : 0, vp = mine ? ap : 0;
-        int v0 = mine ? ax0 : 0x7fffffff, v1 = mine ? ax1 : -1, y0 = mine ? y : 0x7fffffff, y1 = mine ? y : -1;
+        if (round == 6) {                                       // a tile of many small borders (ragged edges, speckle): the rest one by one
+            if (ak >= 0) book(ak, an, ap, ax0, ax1, y, y);
+            if (bk2 >= 0) book(bk2, bn2, bp2, bx0, bx1, y, y);
+            break;
+        }
+        const int src = __ffsll((long long)pend) - 1;
+        const int k0 = __shfl(ak >= 0 ? ak : bk2, src);
+        const bool ma = ak == k0, mb = !ma && bk2 == k0, mine = ma || mb;
+        int vn = ma ? an : (mb ? bn2 : 0), vp = ma ? ap : (mb ? bp2 : 0);
+        int v0 = ma ? ax0 : (mb ? bx0 : 0x7fffffff), v1 = ma ? ax1 : (mb ? bx1 : -1), y0 = mine ? y : 0x7fffffff, y1 = mine ? y : -1;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {
             vn += __shfl_xor(vn, o); vp += __shfl_xor(vp, o);
             v0 = min(v0, __shfl_xor(v0, o)); v1 = max(v1, __shfl_xor(v1, o));
             y0 = min(y0, __shfl_xor(y0, o)); y1 = max(y1, __shfl_xor(y1, o));
         }
-        if (mine) {
-            if ((__ballot(true) & ((1ull << (threadIdx.x & 63)) - 1)) == 0) {      // first lane of the group books the sums
-                atomicAdd(&ac[k0].nstates, vn); atomicAdd(&ac[k0].npts, vp);
-                atomicMin(&ac[k0].xmin, v0); atomicMax(&ac[k0].xmax, v1);
-                atomicMin(&ac[k0].ymin, y0); atomicMax(&ac[k0].ymax, y1);
-            }
-            ak = -1;
-        }
+        if ((threadIdx.x & 63) == src) book(k0, vn, vp, v0, v1, y0, y1);
+        if (ma) ak = -1;
+        if (mb) bk2 = -1;
     }
 }
 
