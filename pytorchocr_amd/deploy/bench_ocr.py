@@ -38,6 +38,14 @@ def make_ocrer(device_index, rank=0, world=1):
     return ocr
 
 
+def _lstm_stats():
+    import ctypes as C
+    from .. import _lib
+    a, b = C.c_int(0), C.c_int(0)
+    _lib.check(_lib.lib().ptocr_lstm_stats(C.byref(a), C.byref(b)), "ptocr_lstm_stats")
+    return a.value, b.value
+
+
 def run_ocr_bench(args, rank, local, world, device, roofline_fn=None, cpu_fn=None, parallelism_fn=None):
     """roofline_fn(prof, labels, steps) -> the line's roofline from the HIP-event durations of the conv launches of the timed region
     (bench.py's accounting: executed MFMA FLOPs per launch); cpu_fn() -> the cpu_baseline object (rank 0, after the timed region)"""
@@ -60,6 +68,7 @@ def run_ocr_bench(args, rank, local, world, device, roofline_fn=None, cpu_fn=Non
         dist.barrier()
         torch.cuda.synchronize()
     step_ms = []
+    lstm0 = _lstm_stats()
     ops.PROFILE = [] if rank == 0 and roofline_fn is not None else None
     ops.PROFILE_LABELS = [] if rank == 0 and roofline_fn is not None else None
     t0 = time.perf_counter()
@@ -74,12 +83,18 @@ def run_ocr_bench(args, rank, local, world, device, roofline_fn=None, cpu_fn=Non
     dt = time.perf_counter() - t0
     prof, labels = ops.PROFILE, ops.PROFILE_LABELS
     ops.PROFILE = ops.PROFILE_LABELS = None
+    per_rank = [round((hi - lo) * args.steps / dt, 3)]
     if world > 1:
+        pr = torch.zeros(world, dtype=torch.float64, device=device)
+        pr[rank] = (hi - lo) * args.steps / dt
+        dist.all_reduce(pr, op=dist.ReduceOp.SUM)
+        per_rank = [round(float(v), 3) for v in pr.tolist()]
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank != 0:
         return None
+    lstm1 = _lstm_stats()
     step_ms.sort()
     n_local = hi - lo
     boxes_img = stats.get("boxes", 0) / max(args.steps * n_local, 1)
@@ -92,7 +107,11 @@ def run_ocr_bench(args, rank, local, world, device, roofline_fn=None, cpu_fn=Non
                                "perspective crops -> CRNN in 512-line chunks -> CTC decode; %d images total (BASELINE.json configs[4])" % total,
                    "global_batch": total, "images_per_gpu": n_local, "boxes_per_image": round(boxes_img, 1),
                    "lines_per_sec": round(stats.get("lines", 0) * world / dt, 1),
-                   "parallelism": parallelism_fn("image-sharded", world) if parallelism_fn else "image-sharded x%d" % world},
+                   "parallelism": parallelism_fn("image-sharded", world) if parallelism_fn else "image-sharded x%d" % world,
+                   "per_rank_images_per_sec": per_rank},
+        # split-form LSTM calls of the timed region and how many of them the on-stream repair pass had to recompute (detector work of the
+        # next sub-group is queued beside the CRNN here: a lost co-residency would show as repaired > 0)
+        "lstm": {"split_calls": lstm1[0] - lstm0[0], "repaired": lstm1[1] - lstm0[1]},
         "roofline": roofline_fn(prof, labels, args.steps) if roofline_fn is not None else None,
         "whole_pipeline_algorithmic_tflops": round((101.98 * n_local * args.steps + 4.98 * stats.get("lines", 0)) * 1e9 / dt / 1e12, 2),
         "cpu_baseline": cpu_fn() if cpu_fn is not None else None,

@@ -23,3 +23,13 @@ for name, mp in (("model", maps), ("text-like", text)):
     for _ in range(8):
         r = post({"maps": mp}, sl)
     print(name, "device ms", [round(v, 3) for v in post.device_ms_log], "boxes/img", sum(len(i["points"]) for i in r) / 32.0)
+    if os.environ.get("TOTALS"):
+        import ctypes as C
+        from pytorchocr_amd import _lib
+        tots = []
+        for i in range(0, 32, 4):
+            tot = C.c_int(0); res = (C.c_char * (68 * 1000))(); cands = (C.c_char * 8000)(); info = (C.c_char * 16000)()
+            _lib.check(_lib.lib().ptocr_dbpost_debug_results(post._ws.handle, i, C.byref(tot), res, cands, info), "dbg")
+            st = np.frombuffer(res, np.int32).reshape(1000, 17)[:, 0][:min(tot.value, 1000)]
+            tots.append((tot.value, np.bincount(st, minlength=8)[:8].tolist()))
+        print(name, "borders per image and their statuses (OK, npts<=2, ssid<3, score, unclip, ssid2, none, defer):", tots)
