@@ -130,9 +130,32 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args p) {
     }
     // Loads past the last channel block / chunk are not predicated: they read the neighbouring pixel's channels or the next
     // weight block (or zeros beyond the buffer) into buffers / registers that are never consumed.
+    // The refill slots of the LAST super-step have nothing left to fetch for this patch (round 3 let them read the neighbouring pixel's
+    // channels into a buffer nobody consumes).  They now fetch the first 16 channels of the patch 256 ids ahead -- the one a workgroup
+    // dispatched to this XCD (ids go round the eight XCDs) will open with, most likely on this very CU once this one retires: its cold
+    // HBM misses, the bulk of a workgroup's ~10 k-cycle head, turn into L2 hits.  The other patch's pieces are this patch's shifted by
+    // one uniform byte offset (same geometry); where that lands outside the tensor the buffer check returns zeros, where it lands on a
+    // pixel the other patch does not need it is a wasted line -- either way the data goes where it always went: nowhere.
+#ifndef W4_WARM
+#define W4_WARM 256
+#endif
+    unsigned warm_delta = 0;
+    {
+        const int id2 = (int)blockIdx.x + W4_WARM;
+        if (W4_WARM > 0 && id2 < p.total) {
+            const int rem2 = id2 % per_cb;
+            const int nb2 = (rem2 / patches) * TN, pr2 = rem2 % patches;
+            const int pty2 = pr2 / p.tiles_x, ptx2 = pr2 - pty2 * p.tiles_x;
+            const int rem1 = (int)blockIdx.x % per_cb, pr1 = rem1 % patches;
+            const int d_n = nb2 - (rem1 / patches) * TN, d_y = (pty2 - pr1 / p.tiles_x) * (4 * TYN), d_x = (ptx2 - pr1 % p.tiles_x) * (4 * TXN);
+            warm_delta = (unsigned)(((d_n * p.H + d_y) * p.W + d_x) * p.Cin * 4);
+        }
+    }
+    const int nS_ = p.Cin >> 4;
     f32x4 rreg[NPIECE];
     auto raw_gload1 = [&](int S, int r) {
-        rreg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, r_off[r] + (unsigned)(S * 64), 0, 0));
+        const unsigned so = S < nS_ ? (unsigned)(S * 64) : warm_delta;           // uniform
+        rreg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, r_off[r] + so, 0, 0));
     };
     float *const r_l0 = Rb + (tid >> 2) * W4_PX + (tid & 3) * 4;                   // piece r: 192 pixels further
     auto raw_lstore1 = [&](int buf, int r) {
