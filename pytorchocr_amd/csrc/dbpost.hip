@@ -2354,7 +2354,17 @@ __device__ float border_score(const unsigned *st, int n, int xmin, int ymin, int
 // steepest successor.  Exact integer arithmetic, O(m^2 / 256).  Survivors come out in (x, y) order, the order
 // cv::convexHull sorts to.  arena: 3 * MW ints of LDS.  Returns the number of survivors (may exceed cap: nothing beyond
 // cap is stored).
-template <int MW, int NT>
+// a hull candidate goes out as one 8-byte store; THROUGH = true: as a device-scope atomic store (written through the XCD's L2, so that
+// a wave on another XCD that polls the border's ready flag in the same launch reads it: border_stage_kernel)
+template <bool THROUGH>
+__device__ __forceinline__ void put_point(F2 *out, int pos, float x, float y) {
+    if (THROUGH) {
+        const unsigned long long v = (unsigned long long)__float_as_uint(x) | ((unsigned long long)__float_as_uint(y) << 32);
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(out + pos), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else { out[pos].x = x; out[pos].y = y; }
+}
+
+template <int MW, int NT, bool THROUGH = false>
 __device__ int hull_candidates(const unsigned *st, int n, int xmin, int bw, unsigned *arena, F2 *out, int cap, int *wave_cnt, int *sh_n) {
     const int tid = threadIdx.x;
     int *col_lo = reinterpret_cast<int *>(arena);               // [MW] min y of the border pixels per column
@@ -2474,7 +2484,7 @@ __device__ int hull_candidates(const unsigned *st, int n, int xmin, int bw, unsi
                 int d = 0;
                 for (int t = 0; t < k; t++) { const int u = col_hi[t]; const int kk = lower(col_lo, L0, u & 0x7ff); d += (kk < L0 && col_lo[kk] == u) ? 1 : 0; }
                 const int pos = j + k - d;
-                if (pos < cap) { out[pos].x = (float)(x + xmin); out[pos].y = (float)(v >> 11); }
+                if (pos < cap) put_point<THROUGH>(out, pos, (float)(x + xmin), (float)(v >> 11));
             }
         }
         for (int r = 0; r * 64 < L1; r++) {
@@ -2491,7 +2501,7 @@ __device__ int hull_candidates(const unsigned *st, int n, int xmin, int bw, unsi
             const int d = dup_before + __popcll(bal & ((1ull << tid) - 1));
             if (j < L1 && !dup) {
                 const int pos = kle + j - d;
-                if (pos < cap) { out[pos].x = (float)(x + xmin); out[pos].y = (float)(v >> 11); }
+                if (pos < cap) put_point<THROUGH>(out, pos, (float)(x + xmin), (float)(v >> 11));
             }
             dup_before += __popcll(bal);
         }
@@ -2530,8 +2540,8 @@ __device__ int hull_candidates(const unsigned *st, int n, int xmin, int bw, unsi
         __syncthreads();
         int pos = *sh_n + incl - mine;
         for (int w = 0; w < wave; w++) pos += wave_cnt[w];
-        if (keep_lo) { if (pos < cap) { out[pos].x = (float)(xi + xmin); out[pos].y = (float)ylo; } pos++; }
-        if (keep_hi) { if (pos < cap) { out[pos].x = (float)(xi + xmin); out[pos].y = (float)yhi; } pos++; }
+        if (keep_lo) { if (pos < cap) put_point<THROUGH>(out, pos, (float)(xi + xmin), (float)(ylo)); pos++; }
+        if (keep_hi) { if (pos < cap) put_point<THROUGH>(out, pos, (float)(xi + xmin), (float)(yhi)); pos++; }
         __syncthreads();
         if (tid == NT - 1) *sh_n = pos;
         __syncthreads();
@@ -2609,7 +2619,7 @@ struct StageArgs {
     const float *maps; const Cand *cands; const int *totals; const Acc *acc; const unsigned *pool;
     Result *results; int *flags; const int *src_wh; F2 *hin; int *hn; float *mini;
     long long *stamps;                      // timing experiments: s_memtime stamps of the stage kernels' phases, 16 per record (null: none)
-    int *pend; int *tie;                    // per border: 1 = pending its rectangle (hull role -> quad kernel); the score's tie marker
+    int *ready; int epoch; int *tie;        // per border: the hull role's ready word (epoch << 2 | state) for the quad role; the score's tie marker
     const int *sc_off; const int *sc_n; const int *sc_item;   // score bands: first item of every border, items per image, item -> border | band << 10
     ScorePart *sc_part; long sc_cap;        // partial sums per item (a fixed slice of sc_cap items per image)
     int *sc_done;                           // per border: bands finished (returns to zero by itself)
@@ -2619,12 +2629,23 @@ struct StageArgs {
 
 // ---- the per-border stages (round 4).  Rounds 2-3 gave a border ONE wave for its hull candidates and then its BoxScore mask
 // (db_postprocess.cpp:194-229): 78 us per call = the 160 KB masked sum of the LARGEST border (a merged blob 900 x 45 pixels) by one wave,
-// while the median border took 18 us.  The score needs only the border's states and its bounding box -- not the hull -- and a mask's rows
-// are independent (the crossing parity never leaves a row).  So border_wave_kernel now has two roles in ONE launch: its first blocks
-// compute hull candidates (one wave per border), the others score the masks as BANDS of rows of at most BAND_WORDS words, one band per
-// wave, planned by pool_offsets_kernel from the bounding boxes: the merged blob is six waves' work instead of one's.  The last band of a
-// border to finish (a ticket per border) adds the partial sums in band order -- a fixed order, whoever finishes last.  No block waits
-// for another one.  border_quad_kernel (four lanes per border: rectangle, filters, unclip, second rectangle, final box) follows.
+// and then a second launch of 54 us for the geometry (four lanes per border).  What a border needs splits into independent chains:
+//   * hull candidates (one wave per border) -> geometry: rectangle, size filter, Clipper offset, second rectangle, final box
+//     (four lanes per border, ~100 k cycles of dependent float / double code whatever the border's size);
+//   * score: needs only the border's states and its bounding box, and its result enters the reference's control flow in ONE place, the
+//     `score < box_thresh` filter (db_postprocess.cpp:272); a mask's rows are independent (the crossing parity never leaves a row).
+// border_stage_kernel runs all three as ROLES of one launch, in grid order: hull blocks, quad blocks, score blocks.
+//   * hull role: one wave per border; the candidates go out as device-scope stores, then the border's ready word.
+//   * quad role: four lanes per border, four borders per wave; a quad polls its border's ready word (written by a block that was
+//     dispatched BEFORE it -- workgroups are dispatched in grid order, so what a quad waits for is running or done; the wait is
+//     bounded all the same: a quad that gives up defers its border to the full-size pass) and starts while other hulls and the
+//     scores are still being computed: the launch lasts about as long as hull + geometry of one border, not hull of all, then score
+//     of all, then geometry.  The geometry assumes that the score passes; compact_kernel applies the filter where the reference does
+//     (after the size filter, before the unclip filters) when it writes the boxes out.
+//   * score role: a mask as BANDS of rows of at most BAND_WORDS words, one band per wave, planned by pool_offsets_kernel from the
+//     bounding boxes: the merged blob is six waves' work.  The last band of a border to finish (a ticket per border) adds the partial
+//     sums in band order -- a fixed order, whoever finishes last.
+// Ready words carry the call's epoch, so nothing is cleared between calls and a word left over by a call that was cut short is ignored.
 constexpr int WAVE_NT = 64;               // threads per border in the hull kernel
 #ifndef PT_STAGE_GRID
 #define PT_STAGE_GRID 256
@@ -2633,32 +2654,47 @@ constexpr int WAVE_NT = 64;               // threads per border in the hull kern
 #define PT_SCORE_GRID 256
 #endif
 constexpr int STAGE_GRID = PT_STAGE_GRID;           // hull-role blocks per image (a text-like map has ~150-300 borders of the 1000 slots)
-constexpr int SCORE_GRID = PT_SCORE_GRID;           // score-role blocks per image (each walks the image's band items with this stride)
+constexpr int SCORE_GRID = PT_SCORE_GRID;
+constexpr int QUADS = 4;                   // borders per wave of the quad role (LDS: one QuadArena each)
+constexpr int QUAD_BLOCKS = (MAX_CAND + QUADS - 1) / QUADS;      // quad-role blocks per image
+constexpr int READY_SPINS = 1 << 16;       // polls (with s_sleep) before a quad gives up: ~50 ms, a thousand times the launch           // score-role blocks per image (each walks the image's band items with this stride)
 
-__device__ __forceinline__ bool border_hull_body(const StageArgs &a, const DbpostDims &d, int img, int k, unsigned *arena) {
+// hull role.  Terminal statuses are written here; a border that goes on to the geometry gets no status from this role (the quad
+// role, or the full-size pass if the quad gave up, writes it).  The border's ready word = epoch << 2 | 1 (go on) or 2 (done here).
+__device__ __forceinline__ void border_hull_body(const StageArgs &a, const DbpostDims &d, int img, int k, unsigned *arena) {
     const int tid = threadIdx.x;
     const long bi = (long)img * MAX_CAND + k;
     Result *res = &a.results[bi];
     const Acc ac = a.acc[bi];
-    if (a.flags[img] & 4) { if (tid == 0) res->status = ST_NONE; return false; }
-    if (ac.npts <= 2) { if (tid == 0) res->status = ST_SKIP_NPTS; return false; }     // db_postprocess.cpp:255
-    const int bw = ac.xmax - ac.xmin + 1, bh = ac.ymax - ac.ymin + 1;
-    // Speckle: both sides of a min-area rectangle are projections of the point set, so neither exceeds its diameter, which is at most
-    // the diagonal of the bounding box; a diagonal <= sqrt(8) means ssid < 3 (db_postprocess.cpp:265) without computing the rectangle.
-    if (border_is_tiny(bw, bh)) { if (tid == 0) res->status = ST_SKIP_SSID; return false; }
-    if (bw > W_MW) { if (tid == 0) { res->status = ST_DEFER; atomicOr(&a.flags[img], 8); } return false; }
-    __shared__ int wave_cnt[WAVE_NT / 64];
-    __shared__ int sh_n;
-    const unsigned *st = a.pool + (long)img * d.pool_cap + ac.off;
-    long long *ts = a.stamps ? a.stamps + ((long)img * MAX_CAND + k) * 16 + 12 : nullptr;   // slots 12..13 of the border's record
-    stamp_rt(ts, 0);
-    const int n = hull_candidates<W_MW, WAVE_NT>(st, ac.nstates, ac.xmin, bw, arena, a.hin + bi * S_MH, Q_PTS, wave_cnt, &sh_n);
-    stamp_rt(ts, 1);
-    if (tid == 0) {
-        if (n > Q_PTS) { res->status = ST_DEFER; atomicOr(&a.flags[img], 8); }
-        else { a.hn[bi] = n; res->status = ST_PEND_RECT; }
+    int state = 2;
+    if (a.flags[img] & 4) { if (tid == 0) res->status = ST_NONE; }
+    else if (ac.npts <= 2) { if (tid == 0) res->status = ST_SKIP_NPTS; }     // db_postprocess.cpp:255
+    else {
+        const int bw = ac.xmax - ac.xmin + 1, bh = ac.ymax - ac.ymin + 1;
+        // Speckle: both sides of a min-area rectangle are projections of the point set, so neither exceeds its diameter, which is at most
+        // the diagonal of the bounding box; a diagonal <= sqrt(8) means ssid < 3 (db_postprocess.cpp:265) without computing the rectangle.
+        if (border_is_tiny(bw, bh)) { if (tid == 0) res->status = ST_SKIP_SSID; }
+        else if (bw > W_MW) { if (tid == 0) { res->status = ST_DEFER; atomicOr(&a.flags[img], 8); } }
+        else {
+            __shared__ int wave_cnt[WAVE_NT / 64];
+            __shared__ int sh_n;
+            const unsigned *st = a.pool + (long)img * d.pool_cap + ac.off;
+            long long *ts = a.stamps ? a.stamps + ((long)img * MAX_CAND + k) * 16 + 12 : nullptr;   // slots 12..13 of the border's record
+            stamp_rt(ts, 0);
+            const int n = hull_candidates<W_MW, WAVE_NT, true>(st, ac.nstates, ac.xmin, bw, arena, a.hin + bi * S_MH, Q_PTS, wave_cnt, &sh_n);
+            stamp_rt(ts, 1);
+            if (n > Q_PTS) { if (tid == 0) { res->status = ST_DEFER; atomicOr(&a.flags[img], 8); } }
+            else {
+                if (tid == 0) __hip_atomic_store(&a.hn[bi], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                state = 1;
+            }
+        }
     }
-    return n <= Q_PTS;
+    // the candidates and their count are out (every lane waits for its own stores), then the ready word
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&a.ready[bi], (a.epoch << 2) | state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- score role: one band of one border (one wave)
@@ -2725,74 +2761,36 @@ __device__ __forceinline__ void score_band_item(const StageArgs &a, const Dbpost
     if (band == 0 || nb > 1) stamp_rt(ts, 1);
 }
 
-// One launch, two roles: blocks [0, STAGE_GRID) of an image walk its borders (hull candidates), the other SCORE_GRID blocks its band items.
-// (the hull role needs 32 VGPRs and the 8 KB column tables, the score role 2 KB and as many registers as it is given for loads in
-// flight: one LDS block for both, and a register budget of five waves per SIMD -- the LDS admits 4.75)
-#ifndef PT_WAVE_OCC
-#define PT_WAVE_OCC 4
-#endif
-__global__ __launch_bounds__(WAVE_NT, PT_WAVE_OCC) void border_wave_kernel(StageArgs a, DbpostDims d) {
-    const int img = blockIdx.y;
-    static_assert(2 * W_MW >= 2 * BAND_WORDS, "the column tables hold the two mask planes of a band");
-    __shared__ __attribute__((aligned(16))) unsigned arena[2 * W_MW];          // hull role: column tables (no x table in the one-wave form); score role: mask planes
-    if (blockIdx.x < STAGE_GRID) {
-#if defined(SC_DBG) && (SC_DBG & 8)
-        return;
-#endif
-        const int num = min(a.totals[img], MAX_CAND);
-        for (int k = blockIdx.x; k < num; k += STAGE_GRID) {
-            // pend[k] = 1: the border goes on to the quads.  (Rounds 2-3 appended k to a per-image list with an atomicAdd: ~170 returning
-            // atomics on ONE address per image, ~200 ns each behind one another, were 35 us of this kernel.)
-            const bool pend = border_hull_body(a, d, img, k, arena);
-            if (threadIdx.x == 0) a.pend[(long)img * MAX_CAND + k] = pend ? 1 : 0;
-            __syncthreads();
-        }
-        return;
-    }
-#if defined(SC_DBG) && (SC_DBG & 16)
-    return;
-#endif
-    const int items = a.sc_n[img];
-    for (int item = blockIdx.x - STAGE_GRID; item < items; item += SCORE_GRID) {
-        score_band_item(a, d, img, item, arena);
-        __syncthreads();
-    }
-}
-
-// ---- geometry: FOUR LANES per border, sixteen borders per wave (quad-lane primitives above)
-constexpr int QUAD_GROUPS = (MAX_CAND + 15) / 16;
-__global__ __launch_bounds__(64) void border_quad_kernel(StageArgs a, DbpostDims d) {
-    const int img = blockIdx.y, group = blockIdx.x;
-    __shared__ QuadArena arena[16];
-    // the (16 group + j)-th pending border of the image, j = 0 .. 15: every lane reads sixteen of the image's flags, ballots rank them
+// ---- quad role: FOUR LANES per border, QUADS borders per wave (quad-lane primitives above); lanes beyond the quads leave at once
+__device__ __forceinline__ void border_quad_body(const StageArgs &a, const DbpostDims &d, int img, int group, QuadArena *arena) {
     const int num = min(a.totals[img], MAX_CAND);
-    if (group * 16 >= num) return;
-    __shared__ int sh_k[16];
-    const int lane = threadIdx.x;
-    const int *pend = a.pend + (long)img * MAX_CAND;
-    int fl[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) { const int kk = r * 64 + lane; fl[r] = kk < num ? pend[kk] : 0; }
-    int cnt = 0;
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const unsigned long long bal = __ballot(fl[r] != 0);
-        const int rank = cnt + __popcll(bal & ((1ull << lane) - 1)) - group * 16;
-        if (fl[r] && rank >= 0 && rank < 16) sh_k[rank] = r * 64 + lane;
-        cnt += __popcll(bal);
-    }
-    wave_sync();
-    if (group * 16 >= cnt) return;
-    const int c = threadIdx.x & 3, slot = group * 16 + (threadIdx.x >> 2);
-    if (slot >= cnt) return;                                    // whole quads leave; nothing below spans quads
-    QuadArena &A = arena[threadIdx.x >> 2];
-    long long *st = a.stamps ? a.stamps + ((long)img * QUAD_GROUPS + group) * 16 : nullptr;
-    stamp(st, 0);
-    const int k = sh_k[threadIdx.x >> 2];
+    const int c = threadIdx.x & 3, qi = threadIdx.x >> 2;
+    const int k = group * QUADS + qi;
+    if (qi >= QUADS || k >= num) return;                        // whole quads leave; nothing below spans quads
     const long bi = (long)img * MAX_CAND + k;
+    // wait for the hull role's word of this call (epoch): 1 = candidates are out, 2 = the border ended there
+    int word = 0, spins = 0;
+    for (;;) {
+        if (c == 0) word = __hip_atomic_load(&a.ready[bi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        word = __shfl(word, 0, 4);
+        if ((word >> 2) == a.epoch) break;
+        if (++spins > READY_SPINS) break;
+        __builtin_amdgcn_s_sleep(32);
+    }
     Result *res = &a.results[bi];
-    const int n = a.hn[bi];
-    for (int i = c; i < n; i += 4) A.pts[i] = a.hin[bi * S_MH + i];
+    if ((word >> 2) != a.epoch) {                               // gave up (never seen): the full-size pass takes the border from its states
+        if (c == 0) { res->status = ST_DEFER; atomicOr(&a.flags[img], 8); }
+        return;
+    }
+    if ((word & 3) != 1) return;
+    QuadArena &A = arena[qi];
+    long long *st = (a.stamps && group < 4 * 63 && (group & 3) == 0) ? a.stamps + ((long)img * 63 + (group >> 2)) * 16 : nullptr;
+    stamp(st, 0);
+    const int n = __hip_atomic_load(&a.hn[bi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = c; i < n; i += 4) {
+        const unsigned long long v = __hip_atomic_load(reinterpret_cast<unsigned long long *>(a.hin + bi * S_MH + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        A.pts[i].x = __uint_as_float((unsigned)v); A.pts[i].y = __uint_as_float((unsigned)(v >> 32));
+    }
     wave_sync();
     // minAreaRect of the border, mini-box, first size filter (db_postprocess.cpp:259-265)
     stamp(st, 1);
@@ -2805,10 +2803,7 @@ __global__ __launch_bounds__(64) void border_quad_kernel(StageArgs a, DbpostDims
     int status;
     if (ssid < 3) status = ST_SKIP_SSID;                        // min_size
     else {
-        if (c == 0 && a.tie[bi]) atomicOr(&a.flags[img], 2);    // the score was within rounding of box_thresh and was re-summed in raster order
-        status = res->score < a.box_thresh ? ST_SKIP_SCORE : ST_PEND_UNCLIP;          // db_postprocess.cpp:272
-    }
-    if (status == ST_PEND_UNCLIP) {
+        // (the score filter of db_postprocess.cpp:272 sits here in the reference: compact_kernel applies it)
         // UnClip (db_postprocess.cpp:16-49): distance from the float mini-box, Clipper's round offset of its truncated vertices
         float area = 0.0f, dist = 0.0f;
         for (int i = 0; i < 4; i++) {
@@ -2873,6 +2868,37 @@ __global__ __launch_bounds__(64) void border_quad_kernel(StageArgs a, DbpostDims
     if (c == 0) res->status = status;
 }
 
+// One launch, three roles, in grid order: N * STAGE_GRID hull blocks, N * QUAD_BLOCKS quad blocks, N * SCORE_GRID score blocks.
+// (the hull role needs 32 VGPRs and the 8 KB column tables, the score role 2 KB and registers for loads in flight, the quad role
+// 13 KB and ~150 VGPRs: one LDS block and three waves per SIMD for all)
+__global__ __launch_bounds__(WAVE_NT) void border_stage_kernel(StageArgs a, DbpostDims d) {
+    constexpr int ARENA_BYTES = (int)(QUADS * sizeof(QuadArena)) > 8 * W_MW ? (int)(QUADS * sizeof(QuadArena)) : 8 * W_MW;
+    static_assert(8 * W_MW >= 8 * BAND_WORDS, "the column tables hold the two mask planes of a band");
+    __shared__ __attribute__((aligned(16))) unsigned char arena_raw[ARENA_BYTES];
+    unsigned *arena = reinterpret_cast<unsigned *>(arena_raw);     // hull role: column tables; score role: mask planes; quad role: the quads' arenas
+    const int nh = d.N * STAGE_GRID, nq = d.N * QUAD_BLOCKS;
+    int b = blockIdx.x;
+    if (b < nh) {
+        const int img = b / STAGE_GRID, num = min(a.totals[img], MAX_CAND);
+        for (int k = b % STAGE_GRID; k < num; k += STAGE_GRID) {
+            border_hull_body(a, d, img, k, arena);
+            __syncthreads();
+        }
+        return;
+    }
+    b -= nh;
+    if (b < nq) {
+        border_quad_body(a, d, b / QUAD_BLOCKS, b % QUAD_BLOCKS, reinterpret_cast<QuadArena *>(arena_raw));
+        return;
+    }
+    b -= nq;
+    const int img = b / SCORE_GRID, items = a.sc_n[img];
+    for (int item = b % SCORE_GRID; item < items; item += SCORE_GRID) {
+        score_band_item(a, d, img, item, arena);
+        __syncthreads();
+    }
+}
+
 // ---- full-size pass: a few workgroups of 1024 threads per image walk the borders the small-footprint stages deferred (borders wider
 // than 1024 px, more than 96 hull / offset points: usually none; on noise maps the one giant component) through all four stages:
 // the parallel parts on all 16 waves, the rectangles on wave 0 (cooperative forms above)
@@ -2917,6 +2943,7 @@ __global__ __launch_bounds__(BIG_THREADS, 1) void contour_big_kernel(StageArgs a
         const int k = sh_list[e];
         const long bi = (long)img * MAX_CAND + k;
         Result *res = &a.results[bi];
+        if (tid == 0) a.tie[bi] = 0;                      // (this pass raises the tie flag itself; the marker may be a band score's, or stale)
         __syncthreads();                                  // the LDS below is reused from the previous border
         const Acc ac = a.acc[bi];
         const unsigned *st = a.pool + (long)img * d.pool_cap + ac.off;
@@ -2966,20 +2993,32 @@ __global__ __launch_bounds__(BIG_THREADS, 1) void contour_big_kernel(StageArgs a
 }
 
 // boxes of one image in candidate order -> dense int16 list + count
-// Last kernel of a call: it also hands the image's flag word and strip count to the host copies and CLEARS the per-call block (flags,
-// strip totals, strip run counts) for the next call -- the memset that used to open every call is gone.
-__global__ __launch_bounds__(1024) void compact_kernel(const Result *__restrict__ results, const int *__restrict__ totals,
+// Last kernel of a call.  It applies the score filter the quad role left out -- a border whose geometry went through the size filter
+// (status OK, or one of the two unclip filters) is dropped when its score is below box_thresh, as db_postprocess.cpp:272 does before the
+// unclip -- and raises the tie flag for borders whose score the reference would have computed; writes the boxes out densely; hands the
+// image's flag word and strip count to the host copies and CLEARS the per-call block (flags, strip totals, strip run counts) for the
+// next call -- the memset that used to open every call is gone.
+__global__ __launch_bounds__(1024) void compact_kernel(Result *__restrict__ results, const int *__restrict__ totals,
                                                        short *__restrict__ boxes, int *__restrict__ counts, int max_boxes,
                                                        int *__restrict__ flags, int *__restrict__ strip_totals, int *__restrict__ strip_runs,
-                                                       int *__restrict__ flags_out, int *__restrict__ strip_out) {
+                                                       int *__restrict__ flags_out, int *__restrict__ strip_out,
+                                                       const int *__restrict__ tie, float box_thresh) {
     const int img = blockIdx.x, k = threadIdx.x;
-    if (k == 0) {
-        flags_out[img] = flags[img]; strip_out[img] = strip_runs[img];
-        flags[img] = 0; strip_totals[img] = 0; strip_runs[img] = 0;
-    }
     __shared__ int sh[1024];
+    __shared__ int sh_tie;
+    if (k == 0) sh_tie = 0;
+    __syncthreads();
     const int num = min(totals[img], MAX_CAND);
-    const bool ok = k < num && results[(long)img * MAX_CAND + k].status == ST_OK;
+    bool ok = false;
+    if (k < num) {
+        Result *r = &results[(long)img * MAX_CAND + k];
+        int st = r->status;
+        if (st == ST_OK || st == ST_SKIP_UNCLIP || st == ST_SKIP_SSID2) {
+            if (tie[(long)img * MAX_CAND + k]) sh_tie = 2;       // within rounding of box_thresh: re-summed in raster order (flag bit 1)
+            if (r->score < box_thresh) { st = ST_SKIP_SCORE; r->status = st; }
+        }
+        ok = st == ST_OK;
+    }
     sh[k] = ok;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
@@ -2994,6 +3033,10 @@ __global__ __launch_bounds__(1024) void compact_kernel(const Result *__restrict_
             for (int j = 0; j < 8; j++) boxes[((long)img * max_boxes + pos) * 8 + j] = (short)results[(long)img * MAX_CAND + k].box[j];
     }
     if (k == 1023) counts[img] = sh[1023];
+    if (k == 0) {
+        flags_out[img] = flags[img] | sh_tie; strip_out[img] = strip_runs[img];
+        flags[img] = 0; strip_totals[img] = 0; strip_runs[img] = 0;
+    }
 }
 
 }  // namespace ptocr
@@ -3023,7 +3066,8 @@ struct ptocr_dbpost {
     int *flags_out; int *strip_out;   // what the host copies of a call read (compact_kernel)
     long long *stamps;            // PTOCR_DBPOST_STAMPS=1: phase time stamps of the stage kernels (max_n * MAX_CAND * 16)
     int *sc_off; int *sc_n; int *sc_item; ScorePart *sc_part; long sc_cap; int *sc_done;     // score bands: plan, partial sums, tickets (border_wave_kernel)
-    int *list; int *tie;          // per border: pending its rectangle (the quads rank these flags); score tie marker
+    int *list; int *tie;          // per border: the hull role's ready word; score tie marker
+    int epoch;                    // number of the current call (ready words of other calls are ignored); never 0
     uint2 *stage; int2 *stage_hdr; long stage_cap; // one-enumeration form of the border states: staged records (a fixed slice per tile), per-word header
 };
 
@@ -3064,6 +3108,7 @@ extern "C" int ptocr_dbpost_create(ptocr_dbpost_t *out, int max_n, int max_h, in
         PT_HIP(hipMemset(h->stamps, 0, sizeof(long long) * 16 * (size_t)max_n * MAX_CAND));
     }
     PT_HIP(hipMalloc(&h->list, sizeof(int) * max_n * MAX_CAND));
+    PT_HIP(hipMemset(h->list, 0, sizeof(int) * max_n * MAX_CAND));
     PT_HIP(hipMalloc(&h->tie, sizeof(int) * max_n * MAX_CAND));
     PT_HIP(hipMalloc(&h->cands, sizeof(Cand) * max_n * MAX_CAND));
     PT_HIP(hipMalloc(&h->acc, sizeof(Acc) * max_n * MAX_CAND));
@@ -3273,15 +3318,14 @@ static void run_chain(ptocr_dbpost *h, const float *d_maps, const uint8_t *d_bit
     a.maps = d_maps; a.cands = w_cands; a.totals = w_totals; a.acc = w_acc; a.pool = w_pool;
     a.results = h->results + (long)i0 * MAX_CAND; a.flags = w_flags; a.src_wh = h->src_wh + 2 * i0; a.hin = h->hin + (long)i0 * MAX_CAND * S_MH; a.hn = h->hn + (long)i0 * MAX_CAND; a.mini = h->mini + (long)i0 * MAX_CAND * 8;
     a.box_thresh = box_thresh; a.unclip_ratio = unclip_ratio; a.use_padding_resize = use_padding_resize;
-    a.pend = h->list + (long)i0 * MAX_CAND; a.tie = h->tie + (long)i0 * MAX_CAND;
+    a.ready = h->list + (long)i0 * MAX_CAND; a.epoch = h->epoch; a.tie = h->tie + (long)i0 * MAX_CAND;
     a.sc_off = h->sc_off + (long)i0 * MAX_CAND; a.sc_n = h->sc_n + i0; a.sc_item = h->sc_item + (long)i0 * h->sc_cap; a.sc_part = h->sc_part + (long)i0 * h->sc_cap; a.sc_cap = h->sc_cap;
     a.sc_done = h->sc_done + (long)i0 * MAX_CAND;
     a.stamps = h->stamps ? h->stamps + (long)i0 * MAX_CAND * 16 : nullptr;
-    hipLaunchKernelGGL(border_wave_kernel, dim3(STAGE_GRID + SCORE_GRID, N), dim3(WAVE_NT), 0, s, a, d);
-    hipLaunchKernelGGL(border_quad_kernel, dim3(QUAD_GROUPS, N), dim3(64), 0, s, a, d);
+    hipLaunchKernelGGL(border_stage_kernel, dim3((unsigned)N * (STAGE_GRID + QUAD_BLOCKS + SCORE_GRID)), dim3(WAVE_NT), 0, s, a, d);
     hipLaunchKernelGGL(contour_big_kernel, dim3(BIG_GRID, N), dim3(BIG_THREADS), 0, s, a, d);
     hipLaunchKernelGGL(compact_kernel, dim3(N), dim3(1024), 0, s, a.results, w_totals, h->boxes + (long)i0 * max_boxes * 8, h->counts + i0, max_boxes,
-                       w_flags, w_strip_totals, w_strip_runs, h->flags_out + i0, h->strip_out + i0);
+                       w_flags, w_strip_totals, w_strip_runs, h->flags_out + i0, h->strip_out + i0, a.tie, box_thresh);
 }
 
 extern "C" int ptocr_db_postprocess(ptocr_dbpost_t h, const float *d_maps, const uint8_t *d_bitmap, int N, int H, int W,
@@ -3306,6 +3350,7 @@ extern "C" int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, co
     if (h->dirty) PT_HIP(hipMemsetAsync(h->zeroed, 0, sizeof(int) * 3 * h->max_n, s));      // (compact_kernel of a finished call leaves the block clear)
     h->dirty = 1;
     h->noise_now = h->route == 1 ? 0 : (h->route == 2 ? 1 : h->strip_hint);
+    h->epoch = (h->epoch % 0x1fffffff) + 1;
     PT_HIP(hipEventRecord(h->ev0, s));
     // Most kernels of the chain are bound by the latency of ONE image's dependent steps (label chases, per-border geometry), not by
     // the chip: 2 maps take 0.25 ms of kernel time, 32 maps 0.51.  So a batch is cut into up to four parts whose chains run on four
