@@ -45,6 +45,9 @@ extern "C" {
 
 const char *ptocr_last_error(void);
 int ptocr_version(void);
+/* digest of the compile flags the library was built with (pytorchocr_amd/build.py); the Python binding refuses a library whose tag is
+ * not the default build's unless PTOCR_EXTRA_HIPCC_FLAGS names the experiment flags it carries */
+const char *ptocr_build_tag(void);
 /* fills name (<=255 chars) with the gcnArchName of device `dev`, returns 0 or error */
 int ptocr_device_arch(int dev, char *name);
 

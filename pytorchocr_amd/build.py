@@ -24,9 +24,9 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
-def _flags_tag():
+def _flags_tag(flags=None):
     """Digest of the compile flags: an object built with other flags (a -D knock-out of tools/dbg) is stale."""
-    return hashlib.sha256(" ".join([HIPCC] + FLAGS).encode()).hexdigest()[:16]
+    return hashlib.sha256(" ".join([HIPCC] + (FLAGS if flags is None else flags)).encode()).hexdigest()[:16]
 
 
 def _stale(obj, src):
@@ -48,15 +48,24 @@ def build(force=False, verbose=True):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
         if force or _stale(obj, src):
-            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+            # the library says which flags it was built with (ptocr_build_tag): a knock-out build left behind by tools/dbg is refused at load
+            cmd = [HIPCC] + FLAGS + ['-DPTOCR_BUILD_TAG="%s"' % _flags_tag(), "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
+            flagfile = obj + ".flags"
+            if os.path.exists(flagfile):
+                os.remove(flagfile)                            # stale until THIS compile has finished
             procs.append((src, subprocess.Popen(cmd)))
+    failed = []
     for src, p in procs:
         if p.wait() != 0:
-            raise RuntimeError("hipcc failed on " + src)
+            failed.append(src)
+            continue
+        # written as each compile finishes, also when another one fails: an object never keeps a tag that is not its own
         with open(os.path.join(objdir, os.path.basename(src) + ".o.flags"), "w") as f:
             f.write(_flags_tag())
+    if failed:
+        raise RuntimeError("hipcc failed on " + ", ".join(failed))
     if procs or not os.path.exists(LIB):
         cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:

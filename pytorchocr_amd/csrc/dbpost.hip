@@ -3071,11 +3071,22 @@ struct ptocr_dbpost {
     uint2 *stage; int2 *stage_hdr; long stage_cap; // one-enumeration form of the border states: staged records (a fixed slice per tile), per-word header
 };
 
+static int dbpost_alloc(ptocr_dbpost *h, int max_n, int max_h, int max_w);
+
 extern "C" int ptocr_dbpost_create(ptocr_dbpost_t *out, int max_n, int max_h, int max_w) {
     PT_CHECK(out && max_n > 0 && max_h > 0 && max_w > 0, "ptocr_dbpost_create: bad arguments");
     PT_CHECK(max_w <= MAXW && max_h < 32768 && (long)max_h * max_w < (1L << 29), "ptocr_dbpost_create: map larger than %d wide / 32767 high / 2^29 pixels", MAXW);
     ptocr_dbpost *h = new ptocr_dbpost();
     memset(h, 0, sizeof *h);
+    if (int e = dbpost_alloc(h, max_n, max_h, max_w)) {        // an allocation failed part-way: give back what the others took
+        (void)ptocr_dbpost_destroy(h);
+        return e;
+    }
+    *out = h;
+    return 0;
+}
+
+static int dbpost_alloc(ptocr_dbpost *h, int max_n, int max_h, int max_w) {
     h->max_n = max_n; h->max_h = max_h; h->max_w = max_w;
     const long hw = (long)max_h * max_w, ww = cdiv(max_w, 32);
     h->pool_cap = 4 * hw + 64;                  // a pixel has at most 4 gaps: no map can overflow this
@@ -3133,7 +3144,6 @@ extern "C" int ptocr_dbpost_create(ptocr_dbpost_t *out, int max_n, int max_h, in
         PT_HIP(hipStreamCreateWithFlags(&h->sub[p], hipStreamNonBlocking));
         PT_HIP(hipEventCreateWithFlags(&h->ev_join[p], hipEventDisableTiming));
     }
-    *out = h;
     return 0;
 }
 

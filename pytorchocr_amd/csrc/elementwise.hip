@@ -122,6 +122,10 @@ using namespace ptocr;
 
 extern "C" const char *ptocr_last_error(void) { return g_err; }
 extern "C" int ptocr_version(void) { return 1; }
+#ifndef PTOCR_BUILD_TAG
+#define PTOCR_BUILD_TAG "untagged"
+#endif
+extern "C" const char *ptocr_build_tag(void) { return PTOCR_BUILD_TAG; }
 extern "C" int ptocr_device_arch(int dev, char *name) {
     hipDeviceProp_t prop;
     PT_HIP(hipGetDeviceProperties(&prop, dev));

@@ -79,9 +79,13 @@ class ResNet(ops.PackedModule):
                  101: ([3, 4, 23, 3], Bottleneck), 152: ([3, 8, 36, 3], Bottleneck)}
         if layers not in table:
             raise ValueError("ResNet layers must be one of %s, got %r" % (sorted(table), layers))
-        for k in ("groups", "width_per_group", "replace_stride_with_dilation", "norm_layer"):
-            if kwargs.get(k) not in (None, 1, 64, [False, False, False]):
-                raise NotImplementedError("pytorchocr_amd ResNet: %s=%r is not built (plain ResNet only)" % (k, kwargs[k]))
+        # every option against ITS OWN default (reference det_resnet.py:143-150): a grouped, wide or dilated ResNet is not built, and a
+        # value that belongs to another key (groups=64, width_per_group=1) must not slip through as "some default"
+        defaults = {"groups": (None, 1), "width_per_group": (None, 64), "norm_layer": (None,),
+                    "replace_stride_with_dilation": (None, [False, False, False], (False, False, False)), "zero_init_residual": (None, False)}
+        for k, allowed in defaults.items():
+            if k in kwargs and not any(kwargs[k] is v or kwargs[k] == v for v in allowed):
+                raise NotImplementedError("pytorchocr_amd ResNet: %s=%r is not built (plain ResNet with the reference's default initialisation only)" % (k, kwargs[k]))
         depth, self.block = table[layers]
         self.mode_3x3 = bool(mode_3x3)
         if not self.mode_3x3:                                  # 7x7 kernel

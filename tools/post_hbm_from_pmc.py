@@ -14,7 +14,7 @@ def parse(path, key):
     return out
 f, w = parse(sys.argv[1], "FETCH_SIZE"), parse(sys.argv[2], "WRITE_SIZE")
 mode = sys.argv[4] if len(sys.argv) > 4 else "post"
-POST = ("binarize", "ccl_", "select_starts", "border_states", "scatter_states", "border_wave", "border_quad", "border_score_big", "hull_k", "rect_k", "score_k", "unclip_k", "contour", "compact", "suffix", "pool_off", "pack_u8", "dilate")
+POST = ("binarize", "ccl_", "select_starts", "border_states", "scatter_states", "border_stage", "border_wave", "border_quad", "contour", "compact", "suffix", "pool_off", "pack_u8", "dilate")
 BF16 = ("bf16", "se_fc")
 print("%-34s %-10s %6s %9s %11s %11s %9s" % ("kernel", "grid", "n", "dur us", "read MB", "write MB", "GB/s"))
 total_b, calls, per = 0.0, None, {}
