@@ -3062,6 +3062,7 @@ struct ptocr_dbpost {
     int dirty;                    // a call did not finish: the per-call block is cleared before the next one
     unsigned noise_hist;          // bit k: the call k + 1 calls ago met a noise-like image
     int *h_strip;                 // pinned: the strip's run-start counts of the last call
+    int *h_meta;                  // pinned: flags | strip counts | box counts of the last call, as one copy delivers them
     int *zeroed;                  // the per-call block: flags | strip_totals | strip_runs (max_n ints each); zero at creation, cleared again by compact_kernel
     int *flags_out; int *strip_out;   // what the host copies of a call read (compact_kernel)
     long long *stamps;            // PTOCR_DBPOST_STAMPS=1: phase time stamps of the stage kernels (max_n * MAX_CAND * 16)
@@ -3098,8 +3099,8 @@ static int dbpost_alloc(ptocr_dbpost *h, int max_n, int max_h, int max_w) {
     PT_HIP(hipMalloc(&h->word_lab, sizeof(int) * max_n * max_h * ww));
     PT_HIP(hipMalloc(&h->chunk_cnt, sizeof(int) * max_n * nch));
     PT_HIP(hipMalloc(&h->totals, sizeof(int) * max_n));
-    PT_HIP(hipMalloc(&h->zeroed, sizeof(int) * 5 * max_n));
-    PT_HIP(hipMemset(h->zeroed, 0, sizeof(int) * 5 * max_n));
+    PT_HIP(hipMalloc(&h->zeroed, sizeof(int) * 6 * max_n));
+    PT_HIP(hipMemset(h->zeroed, 0, sizeof(int) * 6 * max_n));
     // score bands: a border's mask is cut into bands of band_rows() >= BAND_WORDS / (2 pw) rows, so it has at most 2 bh pw / BAND_WORDS + 1
     // <= max_h / 4 + 1 of them (pw <= 32 words: wider borders go to the full-size pass)
     h->sc_cap = (long)MAX_CAND * (max_h / 4 + 2);
@@ -3113,7 +3114,8 @@ static int dbpost_alloc(ptocr_dbpost *h, int max_n, int max_h, int max_w) {
     h->strip_hint = 1;
     h->noise_hist = 0x80u;                      // the first call takes the noise route; a text-like first batch clears it at once
     h->flags = h->zeroed; h->strip_totals = h->zeroed + max_n; h->strip_runs = h->zeroed + 2 * max_n;
-    h->flags_out = h->zeroed + 3 * max_n; h->strip_out = h->zeroed + 4 * max_n;
+    h->flags_out = h->zeroed + 3 * max_n; h->strip_out = h->zeroed + 4 * max_n; h->counts = h->zeroed + 5 * max_n;      // one block: ONE copy to the host per call
+    PT_HIP(hipHostMalloc(&h->h_meta, sizeof(int) * 3 * max_n));
     if (getenv("PTOCR_DBPOST_STAMPS")) {
         PT_HIP(hipMalloc(&h->stamps, sizeof(long long) * 16 * (size_t)max_n * MAX_CAND));
         PT_HIP(hipMemset(h->stamps, 0, sizeof(long long) * 16 * (size_t)max_n * MAX_CAND));
@@ -3136,7 +3138,6 @@ static int dbpost_alloc(ptocr_dbpost *h, int max_n, int max_h, int max_w) {
     PT_HIP(hipMalloc(&h->results, sizeof(Result) * max_n * MAX_CAND));
     PT_HIP(hipMalloc(&h->src_wh, sizeof(int) * 2 * max_n));
     PT_HIP(hipMalloc(&h->boxes, sizeof(short) * 8 * max_n * MAX_CAND));
-    PT_HIP(hipMalloc(&h->counts, sizeof(int) * max_n));
     PT_HIP(hipEventCreate(&h->ev0));
     PT_HIP(hipEventCreate(&h->ev1));
     PT_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -3150,12 +3151,13 @@ static int dbpost_alloc(ptocr_dbpost *h, int max_n, int max_h, int max_w) {
 extern "C" int ptocr_dbpost_destroy(ptocr_dbpost_t h) {
     if (!h) return 0;
     void *bufs[] = {h->bits, h->bits2, h->labels, h->word_lab, h->chunk_cnt, h->totals, h->zeroed, h->cands, h->acc, h->pool, h->hin,
-                    h->hn, h->mini, h->results, h->src_wh, h->boxes, h->counts, h->list, h->tie, h->stamps, h->sc_off, h->sc_n, h->sc_item, h->sc_part, h->sc_done,
+                    h->hn, h->mini, h->results, h->src_wh, h->boxes, h->list, h->tie, h->stamps, h->sc_off, h->sc_n, h->sc_item, h->sc_part, h->sc_done,
                     h->stage, h->stage_hdr};
     for (void *b : bufs) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->h_strip) (void)hipHostFree(h->h_strip);
+    if (h->h_meta) (void)hipHostFree(h->h_meta);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (int p = 0; p < DBPOST_STREAMS; p++) {
         if (h->ev_join[p]) (void)hipEventDestroy(h->ev_join[p]);
@@ -3384,13 +3386,15 @@ extern "C" int ptocr_db_postprocess_ex(ptocr_dbpost_t h, const float *d_maps, co
     if (int e = launch_ok("dbpost kernels")) return e;
     PT_HIP(hipEventRecord(h->ev1, s));
     h->timed = 1;
-    PT_HIP(hipMemcpyAsync(h_counts, h->counts, sizeof(int) * N, hipMemcpyDeviceToHost, s));
-    PT_HIP(hipMemcpyAsync(h_flags, h->flags_out, sizeof(int) * N, hipMemcpyDeviceToHost, s));
-    PT_HIP(hipMemcpyAsync(h->h_strip, h->strip_out, sizeof(int) * N, hipMemcpyDeviceToHost, s));
+    PT_HIP(hipMemcpyAsync(h->h_meta, h->flags_out, sizeof(int) * 3 * h->max_n, hipMemcpyDeviceToHost, s));      // flags, strip counts, box counts: one copy (three cost 5 us each on the stream)
     PT_HIP(hipMemcpyAsync(h_boxes, h->boxes, sizeof(short) * 8 * (size_t)N * max_boxes, hipMemcpyDeviceToHost, s));
     PT_HIP(hipStreamSynchronize(s));
     h->dirty = 0;
-    for (int i = 0; i < N; i++) h_flags[i] &= 7;           // bit 3 is internal (deferred borders)
+    for (int i = 0; i < N; i++) {
+        h_flags[i] = h->h_meta[i] & 7;                      // bit 3 is internal (deferred borders)
+        h->h_strip[i] = h->h_meta[h->max_n + i];
+        h_counts[i] = h->h_meta[2 * h->max_n + i];
+    }
     if (!d_bitmap && !use_dilation) {
         // the noise route stays on for eight calls after the last noise-like image: a workspace fed text-like and noise-like batches in
         // turn (bench.py's two passes per step did exactly that) would otherwise take the wrong route every time -- one thread per word

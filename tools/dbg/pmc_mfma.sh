@@ -5,5 +5,5 @@ cd /tmp && export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/pmc_mfma
 rm -rf $O
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $O.log 2>&1
-python3 $GRAFT_REPO_ROOT/tools/pmc_analyze.py $O > $GRAFT_REPO_ROOT/gpurun_out/r03_pmc_${WL}_mfma_busy.txt
-grep -A3 "wino4\|stem_pool\|conv_mfma_v2\|pw64\|pw128\|head_tail" $GRAFT_REPO_ROOT/gpurun_out/r03_pmc_${WL}_mfma_busy.txt | head -80
+python3 $GRAFT_REPO_ROOT/tools/pmc_analyze.py $O > $GRAFT_REPO_ROOT/gpurun_out/r04_pmc_${WL}_mfma_busy.txt
+grep -A3 "wino4\|stem_pool\|conv_mfma_v2\|pw64\|pw128\|head_tail" $GRAFT_REPO_ROOT/gpurun_out/r04_pmc_${WL}_mfma_busy.txt | head -80
