@@ -674,41 +674,59 @@ __device__ __forceinline__ int st_y(unsigned s) { return (int)((s >> 11) & 0x7ff
 __device__ __forceinline__ int st_out(unsigned s) { return (int)((s >> 26) & 7u); }
 __device__ __forceinline__ int st_in(unsigned s) { return (int)(s >> 29); }
 
-// staging list of the one-enumeration form: a record is (state word, candidate | length << 16) -- length > 0: a stretch of straight
-// horizontal states starting at that word, 0: one state; a word's records lie behind each other from its header's base
-struct StageArgs2 { uint2 *rec; int2 *hdr; long cap; };
-constexpr int STAGE_TILE = 8192;                // record slots per 8-row x 8-word tile
-constexpr int SCATTER_ROUNDS = 6;               // scatter_states_kernel: tiles whose words hold more records than this take the per-lane walk
+// staging list of the border states: a record is (state word, candidate | length << 16) -- length > 0: a stretch of straight
+// horizontal states starting at that word, 0: one state; the records of an 8-row x 8-word tile lie behind each other in the tile's
+// fixed slice, their number in the tile's header word
+struct StageArgs2 { uint2 *rec; int *hdr; long cap; };
+// LDS hand-off between the lanes of ONE wave (a wave's LDS operations execute in order; the fences keep the compiler from moving accesses)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+constexpr int STAGE_TILE = 8192;                // record slots per tile (a pixel has at most four gaps: no reservation, no overflow)
 
-// One thread per bitmap word lists the border states of its foreground pixels (see the file header) and books each one to
-// its border's candidate.  WRITE = false: counts (states, CHAIN_APPROX_SIMPLE points, bounding box) into acc[];
-// WRITE = true: stores the states into the border's slot of the pool (acc[].off, sized by the count pass).
-// STAGE (with WRITE = false): the ONE enumeration -- while counting, every state is also appended, with its candidate, to the
-// image's staging list (a fixed slice per wave tile; a word's position in it from a bit-plane count of the gaps of the wave's 64
-// words); scatter_states_kernel then moves the records to their borders'
-// pool slots without any neighbour load or label look-up (the second enumeration of rounds 2-3: PTOCR_DBPOST_TWO_PASS=1).
-template <bool WRITE, bool STAGE = false>
+// A wave's table of the borders it met (LDS): candidate -> slot by k & 63 with linear probing; what is booked there goes to the border's
+// record in global memory ONCE per wave (every direct booking is atomics on one line that all the waves of that border share).
+constexpr int WT_SLOTS = 64;
+struct WaveTable { int tag[WT_SLOTS], n[WT_SLOTS], np[WT_SLOTS], x0[WT_SLOTS], x1[WT_SLOTS], y0[WT_SLOTS], y1[WT_SLOTS]; };
+// slot of candidate k (claiming a free one), or -1 when the table is full of other candidates (a tile of speckle: more than 64 borders)
+__device__ __forceinline__ int wt_slot(int *tag, int k) {
+    int slot = k & (WT_SLOTS - 1);
+    for (int probe = 0; probe < WT_SLOTS; probe++) {
+        const int t = atomicCAS(&tag[slot], -1, k);
+        if (t == -1 || t == k) return slot;
+        slot = (slot + 1) & (WT_SLOTS - 1);
+    }
+    return -1;
+}
+
+// One WAVE per tile of 8 rows x 8 bitmap words lists the border states of the tile's foreground pixels (see the file header), finds each
+// one's border (F, B -> candidate) and stages a (state, candidate) record; counts, contour points and bounding boxes per border go
+// through the wave's table.  Two phases:
+//  * the straight horizontal states (most of a text line's border) per word, a contiguous stretch per record;
+//  * every other state ("generic" pixels: turns, ends, single pixels), ONE PIXEL PER LANE whatever word it sits in -- until round 3 a
+//    lane walked the pixels of its own word one after the other, so a ragged edge (twenty such pixels in a word, each a hundred
+//    dependent instructions and a look-up) kept one lane busy and sixty-three waiting: the stage's time on the scene checkpoint's maps.
 __global__ __launch_bounds__(256) void border_states_kernel(const unsigned *__restrict__ bits, const int *__restrict__ labels,
                                                             const int *__restrict__ word_lab, const int *__restrict__ strip_totals,
-                                                            Acc *__restrict__ acc, unsigned *__restrict__ pool,
-                                                            int *__restrict__ flags, DbpostDims d, StageArgs2 sg) {
+                                                            Acc *__restrict__ acc, DbpostDims d, StageArgs2 sg) {
     const int img = blockIdx.y;
     const int y_first = (d.strip_y && strip_totals[img] >= MAX_CAND) ? d.strip_y : 0;     // rows above carry no labels (and no candidate)
-    // a wave owns a TILE of 8 rows x 8 words (256 x 8 pixels), not 64 consecutive words of a row: a border's words then fall into
-    // few waves, and the per-wave combination at the end leaves few atomics per border
     const int tiles_x = cdiv(d.WW, 8);
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane_t = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6, lane_t = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + wv;
     const int ty0 = (tile / tiles_x) * 8 + (lane_t >> 3), tx0 = (tile % tiles_x) * 8 + (lane_t & 7);
     // strip mode: the row straight ABOVE the strip is listed too -- a hole in the strip's first row has border states on the foreground
-    // pixels above it (found by the fuzz sweep of round 3: such a hole among the first 1000 borders lost its upper points).  Those
-    // pixels carry no labels; only their gaps that reach the pixel below (direction S) can belong to a strip border, and that border
-    // is the hole's whatever the pixel's own component is (it reaches above the strip, so it is no candidate).
+    // pixels above it.  Those pixels carry no labels; only their gaps that reach the pixel below (direction S) can belong to a strip
+    // border, and that border is the hole's whatever the pixel's own component is (it reaches above the strip, so it is no candidate).
     const int y_lo = y_first ? y_first - 1 : 0;
-    const bool in_range = ty0 < d.H - y_lo && tx0 < d.WW && !(WRITE && (flags[img] & 4));
-    const int y = in_range ? y_lo + ty0 : y_lo, wi = in_range ? tx0 : 0;   // out-of-range lanes idle along (the wave reduction wants all lanes)
-    const bool above = y < y_first;
+    const int tiles_y = cdiv(d.H - y_lo, 8);
+    if (tile >= tiles_x * tiles_y) return;                      // whole waves (nothing below spans waves)
+    const bool in_range = ty0 < d.H - y_lo && tx0 < d.WW;
+    const int y = in_range ? y_lo + ty0 : y_lo, wi = in_range ? tx0 : 0;
     const unsigned *bimg = bits + (long)img * d.H * d.WW;
-    unsigned w = in_range ? bimg[(long)y * d.WW + wi] : 0u;
+    const unsigned w = in_range ? bimg[(long)y * d.WW + wi] : 0u;
     auto ld = [&](int yy, int ww) -> unsigned {                  // (an all-background word has no border point: no neighbour loads)
         return (w && (unsigned)yy < (unsigned)d.H && (unsigned)ww < (unsigned)d.WW) ? bimg[(long)yy * d.WW + ww] : 0u;
     };
@@ -722,219 +740,178 @@ __global__ __launch_bounds__(256) void border_states_kernel(const unsigned *__re
     const int *lab = labels + (long)img * d.HW;
     const int *wl = word_lab + (long)img * d.H * d.WW;
     Acc *ac = acc + (long)img * MAX_CAND;
-    unsigned *pl = pool + (long)img * d.pool_cap;
-    int f_key = -2, F = FRAME, S = -3, kF = -1;                 // cached: run of the current pixel -> its component, its surround, its candidate
-    int n_key = -2, BN = FRAME, kN = -1, s_key = -2, BS = FRAME, kS = -1;   // cached: background run above / below -> component, candidate
-    // count mode: pending totals of TWO candidates per thread (a word mostly meets a text line's outer border and at most one hole or
-    // neighbour; every total a thread books alone instead of through the wave's combination below is six atomics on a border's
-    // record, and those were a third of this kernel: 22 of 63 us)
-    int ak = -1, an = 0, ap = 0, ax0 = 0x7fffffff, ax1 = -1;
-    int bk2 = -1, bn2 = 0, bp2 = 0, bx0 = 0x7fffffff, bx1 = -1;
-    unsigned buf[8]; int bn = 0, bk = -1;                       // write mode: pending states of candidate bk (one slot reservation per 8)
-    auto wflush = [&]() {
-        if (bn) {
-            const int off = ac[bk].off;
-            if (off >= 0) {
-                const int pos = off + atomicAdd(&ac[bk].cursor, bn);
-#pragma unroll
-                for (int j = 0; j < 8; j++) if (j < bn) pl[pos + j] = buf[j];
-            }
-            bn = 0;
-        }
-    };
-    // states and contour points of a border go out as ONE 64-bit add (the two counters are neighbours in Acc)
-    auto book = [&](int k, int n, int np, int x0, int x1, int y0, int y1) {
-        atomicAdd(reinterpret_cast<unsigned long long *>(&ac[k].nstates), (unsigned long long)(unsigned)n | ((unsigned long long)(unsigned)np << 32));
-        atomicMin(&ac[k].xmin, x0); atomicMax(&ac[k].xmax, x1);
-        atomicMin(&ac[k].ymin, y0); atomicMax(&ac[k].ymax, y1);
-    };
-    // make candidate k the current one (slot a): it may be waiting in slot b; a third candidate pushes the older one out
-    auto select_k = [&](int k) {
-        if (k == ak) return;
-        if (k == bk2) {
-            int t;
-            t = ak; ak = bk2; bk2 = t; t = an; an = bn2; bn2 = t; t = ap; ap = bp2; bp2 = t; t = ax0; ax0 = bx0; bx0 = t; t = ax1; ax1 = bx1; bx1 = t;
-            return;
-        }
-        if (bk2 >= 0) book(bk2, bn2, bp2, bx0, bx1, y, y);
-        bk2 = ak; bn2 = an; bp2 = ap; bx0 = ax0; bx1 = ax1;
-        ak = k; an = 0; ap = 0; ax0 = 0x7fffffff; ax1 = -1;
-    };
-    // component of pixel i of this word (cached per run), the background component that surrounds it, its candidate
-    auto look_f = [&](int i) {
-        const unsigned m = ~w & ((1u << i) - 1u);
-        const int key = m ? 32 - __clz(m) : -1;
-        if (key != f_key) {
-            f_key = key;
-            if (above) F = -1;
-            else if (m) { const int rs = y * d.W + wi * 32 + key; F = canon_root(lab[rs], rs); }
-            else F = wl[(long)y * d.WW + wi];
-            if (F < 0) { S = -3; kF = -1; }                      // (strip mode) component reaches above the strip: never a candidate
-            else {
-                const int fy = F / d.W, fx = F - fy * d.W;
-                S = fx == 0 ? FRAME : root_of_pixel(bimg, lab, wl, d, fx - 1, fy);
-                kF = cand_of_root(lab, F);
+    __shared__ WaveTable tabs[4];
+    __shared__ unsigned s_pl[4][8][64];                         // the tile's neighbour planes (E NE N NW W SW S SE), word by word
+    __shared__ unsigned s_w[4][64];
+    __shared__ int s_pre[4][65];                                // exclusive prefix of the words' generic-pixel counts
+    WaveTable &T = tabs[wv];
+    T.tag[lane_t] = -1; T.n[lane_t] = 0; T.np[lane_t] = 0; T.x0[lane_t] = 0x7fffffff; T.x1[lane_t] = -1; T.y0[lane_t] = 0x7fffffff; T.y1[lane_t] = -1;
+    uint2 *rec = sg.rec + (long)img * sg.cap + (long)tile * STAGE_TILE;
+    int tile_n = 0;                                             // records of the tile so far (wave-uniform)
+    // books a state (or a stretch of n states) of border k and stages its record; every lane of the wave calls it together
+    auto emit = [&](bool on, int k, unsigned state, int n, int np, int x0, int x1, int yy) {
+        const unsigned long long bal = __ballot(on);
+        if (on) {
+            rec[tile_n + __popcll(bal & ((1ull << lane_t) - 1))] = make_uint2(state, (unsigned)k | ((unsigned)(n > 1 || np < 0 ? n : 0) << 16));
+            const int slot = wt_slot(T.tag, k);
+            const int pts = np < 0 ? 0 : np;
+            if (slot >= 0) {
+                atomicAdd(&T.n[slot], n); if (pts) atomicAdd(&T.np[slot], pts);
+                atomicMin(&T.x0[slot], x0); atomicMax(&T.x1[slot], x1); atomicMin(&T.y0[slot], yy); atomicMax(&T.y1[slot], yy);
+            } else {                                            // table full (speckle): straight to the border's record
+                atomicAdd(reinterpret_cast<unsigned long long *>(&ac[k].nstates), (unsigned long long)(unsigned)n | ((unsigned long long)(unsigned)pts << 32));
+                atomicMin(&ac[k].xmin, x0); atomicMax(&ac[k].xmax, x1); atomicMin(&ac[k].ymin, yy); atomicMax(&ac[k].ymax, yy);
             }
         }
+        tile_n += __popcll(bal);
     };
-    // the background run straight above (g4 == 2) / below (g4 == 6) pixel i: found in the row word this thread already holds,
-    // cached per run (the states along the top or the bottom edge of a text line share it)
-    auto look_ns = [&](int i, int g4, int &B, int &kB) {
-        const int zy = g4 == 2 ? y - 1 : y + 1;
-        if (!((unsigned)zy < (unsigned)d.H && zy >= y_first)) { B = FRAME; kB = -1; return; }
-        const unsigned rw = g4 == 2 ? up : dn;
-        const unsigned m = rw & ((1u << i) - 1u);
-        const int key = m ? 32 - __clz(m) : -1;
-        int &ck = g4 == 2 ? n_key : s_key;
-        int &cb = g4 == 2 ? BN : BS;
-        int &cc = g4 == 2 ? kN : kS;
-        if (key != ck) {
-            ck = key;
-            if (m) { const int rs = zy * d.W + wi * 32 + key; cb = canon_root(lab[rs], rs); }
-            else cb = wl[(long)zy * d.WW + wi];
-            cc = cand_of_root(lab, cb);
-        }
-        B = cb; kB = cc;
+    // component of the run of row yy that holds bit i of word (yy, ww) with bits wbits -> root (FRAME = -1); the run start inside the word
+    // or the word's own label
+    auto run_root = [&](int yy, int ww, unsigned wbits, int i) -> int {
+        const unsigned mo = (((wbits >> i) & 1u) ? ~wbits : wbits) & ((1u << i) - 1u);     // pixels of the other class left of i
+        if (mo) { const int rs = yy * d.W + ww * 32 + (32 - __clz(mo)); return canon_root(lab[rs], rs); }
+        return wl[(long)yy * d.WW + ww];
     };
-    // ---- bulk: the straight horizontal states.  Along the top edge of a blob the walk runs west through pixels whose gap is
-    // exactly {NE, N, NW} (s_in = E, s_out = W), along the bottom edge east through {SW, S, SE}; such states are most of a text
-    // line's border, they never turn, and a contiguous stretch of them shares F, B and the candidate: one look-up, one
-    // reservation, then a store per state.
+    // (surround, candidate) of foreground component F
+    auto comp_info = [&](int F, int &S, int &kF) {
+        if (F < 0) { S = -3; kF = -1; return; }                  // (strip mode) component reaches above the strip: never a candidate
+        const int fy = F / d.W, fx = F - fy * d.W;
+        S = fx == 0 ? FRAME : root_of_pixel(bimg, lab, wl, d, fx - 1, fy);
+        kF = cand_of_root(lab, F);
+    };
     const unsigned straight_t = w & pE & pW & ~pNE & ~up & ~pNW;
     const unsigned straight_b = w & pE & pW & ~pSW & ~dn & ~pSE;
-    unsigned generic = w & (((pE & ~pNE) & ~straight_t) | (pNE & ~up) | (up & ~pNW) | (pNW & ~pW) | ((pW & ~pSW) & ~straight_b) |
-                            (pSW & ~dn) | (dn & ~pSE) | (pSE & ~pE) | ~(pE | pNE | up | pNW | pW | pSW | dn | pSE));
-    long spos = 0, sbase = 0;                                   // STAGE: next record slot of this word, its first slot
-    bool sok = false;
-    if (STAGE) {
-        // records this word can emit at most: its stretches + the gaps of its generic pixels (a gap starts at a foreground neighbour
-        // whose counter-clockwise successor is background; an isolated pixel has one) -- counted on the bit planes
-        int u = __popc(straight_t & ~(straight_t << 1)) + __popc(straight_b & ~(straight_b << 1));
-        u += __popc(generic & pE & ~pNE) + __popc(generic & pNE & ~up) + __popc(generic & up & ~pNW) + __popc(generic & pNW & ~pW) +
-             __popc(generic & pW & ~pSW) + __popc(generic & pSW & ~dn) + __popc(generic & dn & ~pSE) + __popc(generic & pSE & ~pE) +
-             __popc(generic & ~(pE | pNE | up | pNW | pW | pSW | dn | pSE));
-        int incl = u;
+    const unsigned generic = w & (((pE & ~pNE) & ~straight_t) | (pNE & ~up) | (up & ~pNW) | (pNW & ~pW) | ((pW & ~pSW) & ~straight_b) |
+                                  (pSW & ~dn) | (dn & ~pSE) | (pSE & ~pE) | ~(pE | pNE | up | pNW | pW | pSW | dn | pSE));
+    s_w[wv][lane_t] = w;
+    s_pl[wv][0][lane_t] = pE; s_pl[wv][1][lane_t] = pNE; s_pl[wv][2][lane_t] = up; s_pl[wv][3][lane_t] = pNW;
+    s_pl[wv][4][lane_t] = pW; s_pl[wv][5][lane_t] = pSW; s_pl[wv][6][lane_t] = dn; s_pl[wv][7][lane_t] = pSE;
+    {
+        const int g = in_range ? __popc(generic) : 0;
+        int incl = g;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane_t >= o) incl += v; }
-        // a pixel contributes at most four records (its gaps; a stretch start stands for the straight gap of its pixel): a tile of
-        // 8 x 256 pixels owns a fixed slice of STAGE_TILE = 8192 slots -- no reservation atomic (460 waves of an image adding to one
-        // counter measured 0.1 ms), no overflow
-        sok = true;
-        sbase = spos = (long)img * sg.cap + (long)tile * STAGE_TILE + (incl - u);
+        s_pre[wv][lane_t + 1] = incl;
+        if (lane_t == 0) s_pre[wv][0] = 0;
+        // (keep the generic mask where the pixel phase finds it: plane slot of the word's own lane)
     }
+    __shared__ unsigned s_gen[4][64];
+    s_gen[wv][lane_t] = in_range ? generic : 0u;
+    wave_lds_sync();
+    // ---- phase 1: the straight horizontal states.  Along the top edge of a blob the walk runs west through pixels whose gap is
+    // exactly {NE, N, NW} (s_in = E, s_out = W), along the bottom edge east through {SW, S, SE}; such states never turn, and a
+    // contiguous stretch of them shares F, B and the candidate: one look-up, one record.
+    {
+        const bool above = y < y_first;
+        int f_key = -2, S = -3, kF = -1;                        // cached per lane: run of the current pixel -> surround, candidate
 #pragma unroll
-    for (int side = 0; side < 2; side++) {
-        unsigned M = side ? straight_b : (above ? 0u : straight_t);
-        const int g4 = side ? 6 : 2;
-        const unsigned code = side ? ((0u << 26) | (4u << 29)) : ((4u << 26) | (0u << 29));        // s_out << 26 | s_in << 29
-        while (M) {
-            const int i0 = __ffs(M) - 1;
-            const unsigned rest = ~(M >> i0);
-            const int len = rest ? __ffs(rest) - 1 : 32 - i0;
-            M &= ~((len == 32 ? 0xffffffffu : ((1u << len) - 1u)) << i0);
-            look_f(i0);
-            int B, kB;
-            look_ns(i0, g4, B, kB);
-            const int k = (B == S) ? kF : kB;
-            if (k < 0) continue;
-            const int x0 = wi * 32 + i0;
-            if (WRITE) {
-                const int off = ac[k].off;
-                if (off >= 0) {
-                    const int pos = off + atomicAdd(&ac[k].cursor, len);
-                    const unsigned base = (unsigned)x0 | ((unsigned)y << 11) | code;
-                    for (int j = 0; j < len; j++) pl[pos + j] = base + (unsigned)j;
+        for (int side = 0; side < 2; side++) {
+            unsigned M = in_range ? (side ? straight_b : (above ? 0u : straight_t)) : 0u;
+            const int zy = side ? y + 1 : y - 1;
+            const unsigned rw = side ? dn : up;
+            const unsigned code = side ? ((0u << 26) | (4u << 29)) : ((4u << 26) | (0u << 29));        // s_out << 26 | s_in << 29
+            while (__ballot(M != 0u)) {
+                bool on = M != 0u;
+                int i0 = 0, len = 0, k = -1;
+                if (on) {
+                    i0 = __ffs(M) - 1;
+                    const unsigned rest = ~(M >> i0);
+                    len = rest ? __ffs(rest) - 1 : 32 - i0;
+                    M &= ~((len == 32 ? 0xffffffffu : ((1u << len) - 1u)) << i0);
+                    const unsigned m = ~w & ((1u << i0) - 1u);
+                    const int key = m ? 32 - __clz(m) : -1;
+                    if (key != f_key) { f_key = key; comp_info(above ? -1 : run_root(y, wi, w, i0), S, kF); }
+                    int B = FRAME, kB = -1;
+                    if ((unsigned)zy < (unsigned)d.H && zy >= y_first) { B = run_root(zy, wi, rw, i0); kB = cand_of_root(lab, B); }
+                    k = (B == S) ? kF : kB;
+                    on = k >= 0;
                 }
-            } else {
-                select_k(k);
-                an += len; ax0 = min(ax0, x0); ax1 = max(ax1, x0 + len - 1);
-                if (STAGE && sok) sg.rec[spos++] = make_uint2((unsigned)x0 | ((unsigned)y << 11) | code, (unsigned)k | ((unsigned)len << 16));
+                const int x0 = wi * 32 + i0;
+                emit(on, k, (unsigned)x0 | ((unsigned)y << 11) | code, len, -1, x0, x0 + len - 1, y);
             }
         }
     }
-    // ---- the other states, pixel by pixel: pixels with a gap that starts after some other neighbour, or isolated pixels
-    while (generic) {
-        const int i = __ffs(generic) - 1;
-        generic &= generic - 1;
-        const int x = wi * 32 + i;
-        const unsigned nb = ((pE >> i) & 1u) | (((pNE >> i) & 1u) << 1) | (((up >> i) & 1u) << 2) | (((pNW >> i) & 1u) << 3) |
-                            (((pW >> i) & 1u) << 4) | (((pSW >> i) & 1u) << 5) | (((dn >> i) & 1u) << 6) | (((pSE >> i) & 1u) << 7);
-        look_f(i);
+    // ---- phase 2: the other states, one pixel per lane: pixels with a gap that starts after some other neighbour, or isolated pixels
+    const int G = s_pre[wv][64];
+    for (int base = 0; __builtin_amdgcn_readfirstlane(base) < G; base += 64) {
+        const int it = base + lane_t;
+        const bool have = it < G;
+        // the word that holds item `it` (last lane L with pre[L] <= it) and the (it - pre[L])-th set bit of its generic mask
+        int L = 0;
+        if (have) {
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) if (L + step < 64 && s_pre[wv][L + step] <= it) L += step;
+        }
+        unsigned gm = have ? s_gen[wv][L] : 1u;
+        int nth = have ? it - s_pre[wv][L] : 0;
+        int i = 0;
+        {   // n-th set bit by halving
+            unsigned mm = gm;
+#pragma unroll
+            for (int sh = 16; sh >= 1; sh >>= 1) {
+                const int c = __popc(mm & ((1u << sh) - 1u));
+                if (nth >= c) { nth -= c; i += sh; mm >>= sh; } else mm &= (1u << sh) - 1u;
+            }
+        }
+        const int yL = y_lo + (tile / tiles_x) * 8 + (L >> 3), wiL = (tile % tiles_x) * 8 + (L & 7);
+        const bool aboveL = yL < y_first;
+        const unsigned wL = s_w[wv][L];
+        const unsigned nb = ((s_pl[wv][0][L] >> i) & 1u) | (((s_pl[wv][1][L] >> i) & 1u) << 1) | (((s_pl[wv][2][L] >> i) & 1u) << 2) |
+                            (((s_pl[wv][3][L] >> i) & 1u) << 3) | (((s_pl[wv][4][L] >> i) & 1u) << 4) | (((s_pl[wv][5][L] >> i) & 1u) << 5) |
+                            (((s_pl[wv][6][L] >> i) & 1u) << 6) | (((s_pl[wv][7][L] >> i) & 1u) << 7);
+        const int x = wiL * 32 + i;
+        int S = -3, kF = -1;
+        if (have) comp_info(aboveL ? -1 : run_root(yL, wiL, wL, i), S, kF);
         // gaps: for every foreground neighbour s_in whose counter-clockwise successor direction is background
         unsigned starts = nb & ~((nb >> 1) | (nb << 7)) & 0xffu;   // bit s set: neighbour s foreground, neighbour s+1 background
         const bool lone = nb == 0;
         if (lone) starts = 1u;                                  // isolated pixel: one state (a one-point contour)
-        while (starts) {
-            const int s_in = __ffs(starts) - 1;
-            starts &= starts - 1;
-            int s_out, g4;
-            bool has4;
-            if (lone) { s_out = 0; g4 = 4; has4 = true; }
-            else {
+        if (!have) starts = 0u;
+        while (__ballot(starts != 0u)) {
+            bool on = starts != 0u;
+            int k = -1, s_in = 0, s_out = 0;
+            if (on) {
+                s_in = __ffs(starts) - 1;
+                starts &= starts - 1;
+                int g4;
+                bool has4;
                 const unsigned rot = ((nb | (nb << 8)) >> (s_in + 1)) & 0xffu;    // bit j = direction s_in + 1 + j
-                const int L = __ffs(rot) - 1;                    // background neighbours in the gap
-                if (L == 3 && (s_in & 3) == 0) continue;          // a straight horizontal state: booked in bulk above
-                s_out = (s_in + 1 + L) & 7;
-                g4 = ((s_in + 1) & 1) ? ((s_in + 2) & 7) : ((s_in + 1) & 7);      // first 4-direction at or after s_in + 1
-                has4 = L >= 2 || (L == 1 && ((s_in + 1) & 1) == 0);
+                if (lone) { s_out = 0; g4 = 4; has4 = true; }
+                else {
+                    const int Lg = __ffs(rot) - 1;               // background neighbours in the gap
+                    s_out = (s_in + 1 + Lg) & 7;
+                    g4 = ((s_in + 1) & 1) ? ((s_in + 2) & 7) : ((s_in + 1) & 7);      // first 4-direction at or after s_in + 1
+                    has4 = Lg >= 2 || (Lg == 1 && ((s_in + 1) & 1) == 0);
+                    if (Lg == 3 && (s_in & 3) == 0) has4 = false;    // a straight horizontal state: booked in phase 1
+                }
+                on = has4;                                      // (a lone diagonal background pixel: the walk passes by)
+                if (on && aboveL) {                             // only a gap that holds the pixel below can be a strip border's
+                    if (lone || (unsigned)((6 - (s_in + 1)) & 7) >= (unsigned)(__ffs(rot) - 1)) on = false;
+                    g4 = 6;
+                }
+                if (on) {
+                    int B = FRAME, kB = -1;
+                    const int zx = x + dir_dx(g4), zy = yL + dir_dy(g4);
+                    if ((unsigned)zx < (unsigned)d.W && (unsigned)zy < (unsigned)d.H && zy >= y_first) {
+                        B = root_of_pixel(bimg, lab, wl, d, zx, zy);
+                        kB = cand_of_root(lab, B);
+                    }
+                    k = (B == S) ? kF : kB;
+                    on = k >= 0;
+                }
             }
-            if (!has4) continue;                                // a lone diagonal background pixel: the walk passes by
-            int B, kB;
-            if (above) {                                        // only a gap that holds the pixel below can be a strip border's
-                if (lone) continue;
-                const unsigned rot = ((nb | (nb << 8)) >> (s_in + 1)) & 0xffu;
-                if ((unsigned)((6 - (s_in + 1)) & 7) >= (unsigned)(__ffs(rot) - 1)) continue;
-                look_ns(i, 6, B, kB);
-            } else if (g4 == 2 || g4 == 6) look_ns(i, g4, B, kB);
-            else {
-                const int zx = x + dir_dx(g4);
-                if ((unsigned)zx < (unsigned)d.W) { B = root_of_pixel(bimg, lab, wl, d, zx, y); kB = cand_of_root(lab, B); }
-                else { B = FRAME; kB = -1; }
-            }
-            const int k = (B == S) ? kF : kB;
-            if (k < 0) continue;
-            const int emit = lone || s_out != (s_in ^ 4);       // the chain turns here: a CHAIN_APPROX_SIMPLE point
-            if (WRITE) {
-                if (k != bk || bn == 8) wflush();
-                bk = k;
-#pragma unroll
-                for (int j = 7; j > 0; j--) buf[j] = buf[j - 1];
-                buf[0] = (unsigned)x | ((unsigned)y << 11) | ((unsigned)s_out << 26) | ((unsigned)s_in << 29);
-                bn++;
-            } else {
-                select_k(k);
-                an++; ap += emit; ax0 = min(ax0, x); ax1 = max(ax1, x);
-                if (STAGE && sok) sg.rec[spos++] = make_uint2((unsigned)x | ((unsigned)y << 11) | ((unsigned)s_out << 26) | ((unsigned)s_in << 29), (unsigned)k);
-            }
+            const int np = (lone || s_out != (s_in ^ 4)) ? 1 : 0;    // the chain turns here: a CHAIN_APPROX_SIMPLE point
+            emit(on, k, (unsigned)x | ((unsigned)yL << 11) | ((unsigned)s_out << 26) | ((unsigned)s_in << 29), 1, np, x, x, yL);
         }
     }
-    if (WRITE) { wflush(); return; }
-    if (STAGE && in_range) sg.hdr[((long)img * d.H + y) * d.WW + wi] = make_int2((int)(sbase - (long)img * sg.cap), (int)(spos - sbase));
-    // count mode: the totals still pending are combined across the wave first -- the 64 words of a wave mostly belong to one or
-    // two borders, and the atomics of a border are all-to-one (every thread of a border hits the same record); both slots of a thread
-    // take part (a thread's two candidates differ, so one round never has to add a thread twice)
-    for (int round = 0;; round++) {
-        const unsigned long long pend = __ballot(ak >= 0 || bk2 >= 0);
-        if (!pend) break;
-        if (round == 6) {                                       // a tile of many small borders (ragged edges, speckle): the rest one by one
-            if (ak >= 0) book(ak, an, ap, ax0, ax1, y, y);
-            if (bk2 >= 0) book(bk2, bn2, bp2, bx0, bx1, y, y);
-            break;
-        }
-        const int src = __ffsll((long long)pend) - 1;
-        const int k0 = __shfl(ak >= 0 ? ak : bk2, src);
-        const bool ma = ak == k0, mb = !ma && bk2 == k0, mine = ma || mb;
-        int vn = ma ? an : (mb ? bn2 : 0), vp = ma ? ap : (mb ? bp2 : 0);
-        int v0 = ma ? ax0 : (mb ? bx0 : 0x7fffffff), v1 = ma ? ax1 : (mb ? bx1 : -1), y0 = mine ? y : 0x7fffffff, y1 = mine ? y : -1;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            vn += __shfl_xor(vn, o); vp += __shfl_xor(vp, o);
-            v0 = min(v0, __shfl_xor(v0, o)); v1 = max(v1, __shfl_xor(v1, o));
-            y0 = min(y0, __shfl_xor(y0, o)); y1 = max(y1, __shfl_xor(y1, o));
-        }
-        if ((threadIdx.x & 63) == src) book(k0, vn, vp, v0, v1, y0, y1);
-        if (ma) ak = -1;
-        if (mb) bk2 = -1;
+    wave_lds_sync();
+    if (lane_t == 0) sg.hdr[(long)img * sg.cap / STAGE_TILE + tile] = tile_n;
+    // the wave's table goes to the borders' records: one lane per slot
+    const int k = T.tag[lane_t];
+    if (k >= 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(&ac[k].nstates), (unsigned long long)(unsigned)T.n[lane_t] | ((unsigned long long)(unsigned)T.np[lane_t] << 32));
+        atomicMin(&ac[k].xmin, T.x0[lane_t]); atomicMax(&ac[k].xmax, T.x1[lane_t]);
+        atomicMin(&ac[k].ymin, T.y0[lane_t]); atomicMax(&ac[k].ymax, T.y1[lane_t]);
     }
 }
 
@@ -983,8 +960,11 @@ __global__ __launch_bounds__(1024) void pool_offsets_kernel(Acc *__restrict__ ac
     if (k == 1023) { sc_n[img] = fits ? shb[1023] : 0; if (!fits) atomicOr(&flags[img], 4); }
 }
 
-// One-enumeration form: moves the staged records of every word to their borders' pool slots (acc[].off, set by pool_offsets_kernel;
-// -1: the reference drops the border).  Same thread -> word mapping as the enumeration; no neighbour word, no label is read.
+// Moves the staged records of a tile to their borders' pool slots (acc[].off, set by pool_offsets_kernel; -1: the reference drops the
+// border).  One wave per tile, one RECORD per lane.  Pass 1 adds up in the wave's table what each border needs; then ONE returning
+// atomic per border of the tile reserves it -- one lane per table slot, so the reservations of a tile are in flight together (a returning
+// atomic on a border's cursor takes ~200 ns behind the previous one on the same address; round 3 reserved per record round, ragged tiles
+// per lane and record); pass 2 places every record behind its border's base with an LDS cursor.  No neighbour word, no label is read.
 __global__ __launch_bounds__(256) void scatter_states_kernel(const int *__restrict__ strip_totals, Acc *__restrict__ acc,
                                                              unsigned *__restrict__ pool, const int *__restrict__ flags, DbpostDims d,
                                                              StageArgs2 sg) {
@@ -992,98 +972,48 @@ __global__ __launch_bounds__(256) void scatter_states_kernel(const int *__restri
     if (flags[img] & 4) return;
     const int y_first = (d.strip_y && strip_totals[img] >= MAX_CAND) ? d.strip_y : 0;
     const int tiles_x = cdiv(d.WW, 8);
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane_t = threadIdx.x & 63;
-    const int ty0 = (tile / tiles_x) * 8 + (lane_t >> 3), tx0 = (tile % tiles_x) * 8 + (lane_t & 7);
+    const int wv = threadIdx.x >> 6, lane_t = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + wv;
     const int y_lo = y_first ? y_first - 1 : 0;                   // the row above the strip is listed too (border_states_kernel)
-    const bool in_range = ty0 < d.H - y_lo && tx0 < d.WW;
-    const int2 hd = in_range ? sg.hdr[((long)img * d.H + y_lo + ty0) * d.WW + tx0] : make_int2(0, 0);
-    const uint2 *rec = sg.rec + (long)img * sg.cap + hd.x;
+    if (tile >= tiles_x * cdiv(d.H - y_lo, 8)) return;
+    const int count = sg.hdr[(long)img * sg.cap / STAGE_TILE + tile];
+    if (count == 0) return;                                     // (uniform over the wave)
+    const uint2 *rec = sg.rec + (long)img * sg.cap + (long)tile * STAGE_TILE;
     Acc *ac = acc + (long)img * MAX_CAND;
     unsigned *pl = pool + (long)img * d.pool_cap;
-    // A pass takes up to SCATTER_ROUNDS records of every word of the wave's tile into registers; then, candidate by candidate, the wave adds
-    // up what ALL those records need of the border's pool slot and reserves it with ONE returning atomic (round 3 reserved once per
-    // record round and border, and ragged tiles one lane at a time: a returning atomic on a border's cursor takes ~200 ns behind the
-    // previous one on the same address, and a large border met hundreds of them).  A tile with more records per word runs more passes.
-    int rounds = hd.y;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) rounds = max(rounds, __shfl_xor(rounds, o));
-    if (rounds > SCATTER_ROUNDS) {
-        // ragged borders: many records in some words and many borders per tile -- the candidate-by-candidate loop below would wait for
-        // one atomic after the other (measured on the scene checkpoint's maps: 127 us against 71); every lane walks its own records
-        // instead, the states that are not stretches in groups of up to eight per reservation, so that the lanes' atomics are in flight together
-        unsigned buf[8]; int bn = 0, bk = -1;
-        auto wflush = [&]() {
-            if (bn) {
-                const int off = ac[bk].off;
-                if (off >= 0) {
-                    const int pos = off + atomicAdd(&ac[bk].cursor, bn);
-#pragma unroll
-                    for (int j = 0; j < 8; j++) if (j < bn) pl[pos + j] = buf[j];
-                }
-                bn = 0;
-            }
-        };
-        for (int r = 0; r < hd.y; r++) {
-            const uint2 e = rec[r];
-            const int k = (int)(e.y & 0xffffu), len = (int)(e.y >> 16);
-            if (len) {
-                const int off = ac[k].off;
-                if (off >= 0) {
-                    const int pos = off + atomicAdd(&ac[k].cursor, len);
-                    for (int j = 0; j < len; j++) pl[pos + j] = e.x + (unsigned)j;
-                }
-            } else {
-                if (k != bk || bn == 8) wflush();
-                bk = k;
-#pragma unroll
-                for (int j = 7; j > 0; j--) buf[j] = buf[j - 1];
-                buf[0] = e.x;
-                bn++;
-            }
-        }
-        wflush();
-        return;
+    __shared__ int s_tag[4][WT_SLOTS], s_cnt[4][WT_SLOTS], s_base[4][WT_SLOTS];
+    int *tag = s_tag[wv], *cnt = s_cnt[wv], *bs = s_base[wv];
+    tag[lane_t] = -1; cnt[lane_t] = 0;
+    wave_lds_sync();
+    for (int i = lane_t; i < count; i += 64) {
+        const uint2 e = rec[i];
+        const int k = (int)(e.y & 0xffffu), len = (int)(e.y >> 16);
+        const int slot = wt_slot(tag, k);
+        if (slot >= 0) atomicAdd(&cnt[slot], len ? len : 1);
     }
-    for (int r0 = 0; r0 < rounds; r0 += SCATTER_ROUNDS) {
-        uint2 e[SCATTER_ROUNDS];
-        unsigned pend = 0;                                      // bit r: record r0 + r exists and is not placed yet
-#pragma unroll
-        for (int r = 0; r < SCATTER_ROUNDS; r++) {
-            e[r] = make_uint2(0u, 0u);
-            if (r0 + r < hd.y) { e[r] = rec[r0 + r]; pend |= 1u << r; }
+    wave_lds_sync();
+    {
+        const int k = tag[lane_t];
+        int base = -1;
+        if (k >= 0) { const int off = ac[k].off; if (off >= 0) base = off + atomicAdd(&ac[k].cursor, cnt[lane_t]); }
+        bs[lane_t] = base;
+        cnt[lane_t] = 0;                                        // now the border's cursor inside this tile's share
+    }
+    wave_lds_sync();
+    for (int i = lane_t; i < count; i += 64) {
+        const uint2 e = rec[i];
+        const int k = (int)(e.y & 0xffffu), len = (int)(e.y >> 16), n = len ? len : 1;
+        int slot = k & (WT_SLOTS - 1), pos = -1;
+        bool found = false;
+        for (int probe = 0; probe < WT_SLOTS; probe++) {         // (read-only now: the table is complete)
+            if (tag[slot] == k) { found = true; break; }
+            slot = (slot + 1) & (WT_SLOTS - 1);
         }
-        for (;;) {
-            const unsigned long long pm = __ballot(pend != 0u);
-            if (!pm) break;
-            // the candidate of the first pending record of the first pending lane
-            int kmine = 0;
-#pragma unroll
-            for (int r = SCATTER_ROUNDS - 1; r >= 0; r--) if ((pend >> r) & 1u) kmine = (int)(e[r].y & 0xffffu);
-            const int k0 = __shfl(kmine, __ffsll((long long)pm) - 1);
-            int n = 0;
-            unsigned sel = 0;
-#pragma unroll
-            for (int r = 0; r < SCATTER_ROUNDS; r++)
-                if (((pend >> r) & 1u) && (int)(e[r].y & 0xffffu) == k0) { const int len = (int)(e[r].y >> 16); n += len ? len : 1; sel |= 1u << r; }
-            int incl = n;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane_t >= o) incl += v; }
-            const int total = __shfl(incl, 63);
-            const int off = ac[k0].off;                          // the same address on every lane; -1: the reference drops the border
-            int base = 0;
-            if (off >= 0 && lane_t == 0) base = atomicAdd(&ac[k0].cursor, total);
-            base = __shfl(base, 0);
-            if (off >= 0 && sel) {
-                int pos = off + base + incl - n;
-#pragma unroll
-                for (int r = 0; r < SCATTER_ROUNDS; r++)
-                    if ((sel >> r) & 1u) {
-                        const int len = (int)(e[r].y >> 16);
-                        if (len) { for (int j = 0; j < len; j++) pl[pos + j] = e[r].x + (unsigned)j; pos += len; }
-                        else pl[pos++] = e[r].x;
-                    }
-            }
-            pend &= ~sel;
+        if (found) { if (bs[slot] >= 0) pos = bs[slot] + atomicAdd(&cnt[slot], n); }
+        else { const int off = ac[k].off; if (off >= 0) pos = off + atomicAdd(&ac[k].cursor, n); }      // table was full (speckle): on its own
+        if (pos >= 0) {
+            if (len) { for (int j = 0; j < len; j++) pl[pos + j] = e.x + (unsigned)j; }
+            else pl[pos] = e.x;
         }
     }
 }
@@ -3069,7 +2999,7 @@ struct ptocr_dbpost {
     int *sc_off; int *sc_n; int *sc_item; ScorePart *sc_part; long sc_cap; int *sc_done;     // score bands: plan, partial sums, tickets (border_wave_kernel)
     int *list; int *tie;          // per border: the hull role's ready word; score tie marker
     int epoch;                    // number of the current call (ready words of other calls are ignored); never 0
-    uint2 *stage; int2 *stage_hdr; long stage_cap; // one-enumeration form of the border states: staged records (a fixed slice per tile), per-word header
+    uint2 *stage; int *stage_hdr; long stage_cap; // border states: staged records (a fixed slice per tile), record count per tile
 };
 
 static int dbpost_alloc(ptocr_dbpost *h, int max_n, int max_h, int max_w);
@@ -3126,11 +3056,10 @@ static int dbpost_alloc(ptocr_dbpost *h, int max_n, int max_h, int max_w) {
     PT_HIP(hipMalloc(&h->cands, sizeof(Cand) * max_n * MAX_CAND));
     PT_HIP(hipMalloc(&h->acc, sizeof(Acc) * max_n * MAX_CAND));
     PT_HIP(hipMalloc(&h->pool, sizeof(unsigned) * max_n * h->pool_cap));
-    static const int two_pass = getenv("PTOCR_DBPOST_TWO_PASS") && atoi(getenv("PTOCR_DBPOST_TWO_PASS")) == 1;
-    if (!two_pass) {
+    {
         h->stage_cap = ((long)cdiv(max_h, 8) * cdiv(max_w, 256) + cdiv(max_h, 8) + cdiv(max_w, 256) + 1) * STAGE_TILE;      // any H x W within the workspace: cdiv(H,8) cdiv(WW,8) tiles
         PT_HIP(hipMalloc(&h->stage, sizeof(uint2) * max_n * h->stage_cap));
-        PT_HIP(hipMalloc(&h->stage_hdr, sizeof(int2) * max_n * max_h * ww));
+        PT_HIP(hipMalloc(&h->stage_hdr, sizeof(int) * max_n * (h->stage_cap / STAGE_TILE)));
     }
     PT_HIP(hipMalloc(&h->hin, sizeof(F2) * (size_t)max_n * MAX_CAND * S_MH));
     PT_HIP(hipMalloc(&h->hn, sizeof(int) * max_n * MAX_CAND));
@@ -3311,21 +3240,12 @@ static void run_chain(ptocr_dbpost *h, const float *d_maps, const uint8_t *d_bit
     hipLaunchKernelGGL(select_starts_kernel, dim3(cdiv(d.nchunks, SEL_CHUNKS), N), dim3(256), 0, s, bits, w_labels, w_chunk, w_totals, w_cands, w_acc, d);
     const dim3 all_words(cdiv(cdiv(H, 8) * cdiv(d.WW, 8), 4), N);      // 8 x 8-word tiles, four per block
     StageArgs2 sg;
-    sg.rec = h->stage ? h->stage + (long)i0 * h->stage_cap : nullptr;
-    sg.hdr = h->stage ? h->stage_hdr + (long)i0 * h->max_h * cdiv(h->max_w, 32) : nullptr; sg.cap = h->stage_cap;
-    if (h->stage) {
-        // ONE enumeration: count + stage, offsets, scatter (the per-image header block is indexed with this call's H x WW)
-        hipLaunchKernelGGL((border_states_kernel<false, true>), all_words, dim3(256), 0, s, bits, w_labels, w_word_lab, w_strip_totals, w_acc, w_pool,
-                           w_flags, d, sg);
-        hipLaunchKernelGGL(pool_offsets_kernel, dim3(N), dim3(1024), 0, s, w_acc, w_totals, w_flags, d, h->sc_off + (long)i0 * MAX_CAND, h->sc_n + i0, h->sc_item + (long)i0 * h->sc_cap, h->sc_cap);
-        hipLaunchKernelGGL(scatter_states_kernel, all_words, dim3(256), 0, s, w_strip_totals, w_acc, w_pool, w_flags, d, sg);
-    } else {
-        hipLaunchKernelGGL((border_states_kernel<false, false>), all_words, dim3(256), 0, s, bits, w_labels, w_word_lab, w_strip_totals, w_acc, w_pool,
-                           w_flags, d, sg);
-        hipLaunchKernelGGL(pool_offsets_kernel, dim3(N), dim3(1024), 0, s, w_acc, w_totals, w_flags, d, h->sc_off + (long)i0 * MAX_CAND, h->sc_n + i0, h->sc_item + (long)i0 * h->sc_cap, h->sc_cap);
-        hipLaunchKernelGGL((border_states_kernel<true, false>), all_words, dim3(256), 0, s, bits, w_labels, w_word_lab, w_strip_totals, w_acc, w_pool,
-                           w_flags, d, sg);
-    }
+    sg.rec = h->stage + (long)i0 * h->stage_cap;
+    sg.hdr = h->stage_hdr + (long)i0 * (h->stage_cap / STAGE_TILE); sg.cap = h->stage_cap;
+    // ONE enumeration of the border states (count + stage), offsets (+ the score plan), scatter
+    hipLaunchKernelGGL(border_states_kernel, all_words, dim3(256), 0, s, bits, w_labels, w_word_lab, w_strip_totals, w_acc, d, sg);
+    hipLaunchKernelGGL(pool_offsets_kernel, dim3(N), dim3(1024), 0, s, w_acc, w_totals, w_flags, d, h->sc_off + (long)i0 * MAX_CAND, h->sc_n + i0, h->sc_item + (long)i0 * h->sc_cap, h->sc_cap);
+    hipLaunchKernelGGL(scatter_states_kernel, all_words, dim3(256), 0, s, w_strip_totals, w_acc, w_pool, w_flags, d, sg);
     StageArgs a;
     a.maps = d_maps; a.cands = w_cands; a.totals = w_totals; a.acc = w_acc; a.pool = w_pool;
     a.results = h->results + (long)i0 * MAX_CAND; a.flags = w_flags; a.src_wh = h->src_wh + 2 * i0; a.hin = h->hin + (long)i0 * MAX_CAND * S_MH; a.hn = h->hn + (long)i0 * MAX_CAND; a.mini = h->mini + (long)i0 * MAX_CAND * 8;
