@@ -170,6 +170,45 @@ __global__ __launch_bounds__(256) void dilate2x2_kernel(const unsigned *__restri
     out[((long)img * d.H + y) * d.WW + wi] = v;
 }
 
+// LDS hand-off between the lanes of ONE wave (a wave's LDS operations execute in order; the fences keep the compiler from moving accesses)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- work items of a wave, one per lane.  Most kernels below give a lane one 32-pixel bitmap word and let it walk the word's items (run
+// starts, run boundaries with a link, border pixels) one after the other; on ragged maps a few words hold twenty items, each a chain of
+// dependent loads, while the other lanes of the wave wait (round 4: that, not bytes, was the stage's time on the scene checkpoint's maps).
+// With these helpers a lane publishes the bit mask of its items; the wave then walks ALL items of its 64 words, item `it` going to lane
+// it % 64 whatever word it sits in: (word lane, bit) from a prefix sum over the words' item counts.
+struct WaveItems { int pre[65]; unsigned mask[64]; };
+__device__ __forceinline__ int wave_items_publish(WaveItems &wi, unsigned mymask) {
+    const int lane = threadIdx.x & 63;
+    int incl = __popc(mymask);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    wi.pre[lane + 1] = incl;
+    if (lane == 0) wi.pre[0] = 0;
+    wi.mask[lane] = mymask;
+    wave_lds_sync();
+    return wi.pre[64];
+}
+// item `it` (< the published total): the lane L whose word holds it and its bit i in that word
+__device__ __forceinline__ void wave_item(const WaveItems &wi, int it, int &L, int &i) {
+    L = 0;
+#pragma unroll
+    for (int step = 32; step >= 1; step >>= 1) if (L + step < 64 && wi.pre[L + step] <= it) L += step;
+    unsigned mm = wi.mask[L];
+    int nth = it - wi.pre[L];
+    i = 0;
+#pragma unroll
+    for (int sh = 16; sh >= 1; sh >>= 1) {                       // the nth set bit, by halving
+        const int c = __popc(mm & ((1u << sh) - 1u));
+        if (nth >= c) { nth -= c; i += sh; mm >>= sh; } else mm &= (1u << sh) - 1u;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ CC labelling
 __device__ __forceinline__ int pix(const unsigned *rowbits, int x) { return (rowbits[x >> 5] >> (x & 31)) & 1; }
 
@@ -363,6 +402,66 @@ __global__ __launch_bounds__(256) void ccl_merge_kernel(const unsigned *__restri
     merge_word(bits, labels, d, img, y, wi, y == ps.y_first && y > 0, part, ps.dbg);
 }
 
+// The slab-boundary pass of the text route, one LINK per lane (round 4): a wave takes 64 words of the boundary rows, publishes per kind
+// (frame, vertical, north-west, north-east) the bits that carry a link, and walks all links of its 64 words together -- a union is two
+// root chases and an atomic in global memory, and the ragged edges of the scene checkpoint's maps put a dozen of them into a word
+// (one thread per word: 69 us).  Same rules as merge_word.
+__global__ __launch_bounds__(256) void ccl_merge_rows_kernel(const unsigned *__restrict__ bits, int *__restrict__ labels, DbpostDims d, CclPass ps) {
+    const int img = blockIdx.y;
+    if (ccl_skip(ps, img)) return;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nrows = (d.H - 1 - ps.y_first) / ps.row_step;      // boundary rows y_first + k row_step, k = 1 .. nrows
+    const int idx0 = blockIdx.x * 256 + wv * 64, nwords = nrows * d.WW;
+    if (idx0 >= nwords) return;                                  // whole waves
+    const int idx = idx0 + lane;
+    const bool on = idx < nwords;
+    const int y = ps.y_first + ((on ? idx : idx0) / d.WW + 1) * ps.row_step, wi = (on ? idx : idx0) % d.WW;
+    const unsigned *bimg = bits + (long)img * d.H * d.WW;
+    int *lab = labels + (long)img * d.HW;
+    __shared__ WaveItems items[4];
+    __shared__ unsigned s_cs[4][64], s_us[4][64];
+    const unsigned *row = bimg + (long)y * d.WW, *up = row - d.WW;   // y >= row_step > 0
+    WordCtx c = {0u, 0u, 0u, 0u}, u = {0u, 0u, 0u, 0u};
+    if (on) { c = word_ctx(row, wi, d); u = word_ctx(up, wi, d); }
+    s_cs[wv][lane] = c.starts; s_us[wv][lane] = u.starts;
+    const int x0 = wi * 32;
+    // the four kinds of links of this word (merge_word's masks)
+    unsigned m_f = 0, m_v = 0, m_nw = 0, m_ne = 0;
+    if (on) {
+        const unsigned bg = ~c.w & c.valid;
+        m_f = (y == d.H - 1) ? (bg & c.starts) : 0u;
+        if (wi == 0) m_f |= bg & 1u;
+        if (x0 + 32 >= d.W) m_f |= bg & (1u << (d.W - 1 - x0));
+        m_v = ~(c.w ^ u.w) & c.valid & (c.starts | u.starts);
+        const unsigned fgbg = c.w & ~u.w & c.valid;
+        const unsigned ucarry = wi ? up[wi - 1] >> 31 : 0u;
+        m_nw = fgbg & c.starts & ((u.w << 1) | ucarry);
+        const unsigned unext = (wi + 1 < d.WW) ? (up[wi + 1] & 1u) : 0u;
+        m_ne = fgbg & c.ends & ((u.w >> 1) | (unext << 31));
+    }
+#pragma unroll
+    for (int kind = 0; kind < 4; kind++) {
+        const int G = wave_items_publish(items[wv], kind == 0 ? m_f : kind == 1 ? m_v : kind == 2 ? m_nw : m_ne);
+        for (int base = 0; base < G; base += 64) {
+            const int it = base + lane;
+            if (it < G) {
+                int L, i;
+                wave_item(items[wv], it, L, i);
+                const int idxL = idx0 + L;
+                const int yL = ps.y_first + (idxL / d.WW + 1) * ps.row_step, wL = idxL % d.WW, xL = wL * 32;
+                const unsigned *rowL = bimg + (long)yL * d.WW, *upL = rowL - d.WW;
+                const unsigned cs = s_cs[wv][L], us = s_us[wv][L];
+                const int cur = (cs >> i) & 1u ? yL * d.W + xL + i : yL * d.W + run_start(rowL, xL + i);      // run start of the current row at bit i
+                if (kind == 0) uf_union(lab, cur, FRAME);
+                else if (kind == 1) uf_union(lab, cur, (us >> i) & 1u ? (yL - 1) * d.W + xL + i : (yL - 1) * d.W + run_start(upL, xL + i));
+                else if (kind == 2) uf_union(lab, yL * d.W + xL + i, (yL - 1) * d.W + run_start(upL, xL + i - 1));
+                else uf_union(lab, cur, (yL - 1) * d.W + xL + i + 1);      // up(x) = 0, up(x + 1) = 1: a run start
+            }
+        }
+        wave_lds_sync();                                        // the item table is reused by the next kind
+    }
+}
+
 // Slab labelling (text route, late round 3): one workgroup labels SLAB_ROWS rows in LDS -- its runs numbered in raster order by a
 // prefix sum over the words' run starts, the same union rules as ccl_merge_kernel on LDS union-find nodes (node 0 = FRAME) -- and
 // writes label[run start] = the slab-local root's pixel (or FRAME).  ccl_merge_kernel then links only the slab boundary rows in global
@@ -522,26 +621,37 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(const unsigned *__rest
                                                           int *__restrict__ word_lab, int *__restrict__ chunk_cnt, DbpostDims d, CclPass ps) {
     const int img = blockIdx.y;
     if (ccl_skip(ps, img)) return;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (d.H - ps.y_first) * d.WW) return;
-    const int y = ps.y_first + idx / d.WW, wi = idx % d.WW;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int idx0 = blockIdx.x * 256 + wv * 64, nwords = (d.H - ps.y_first) * d.WW;
+    if (idx0 >= nwords) return;                                  // whole waves
+    const int idx = idx0 + lane;
+    const bool on = idx < nwords;
+    const int y = ps.y_first + (on ? idx : idx0) / d.WW, wi = (on ? idx : idx0) % d.WW;
     const unsigned *row = bits + ((long)img * d.H + y) * d.WW;
     int *lab = labels + (long)img * d.HW;
-    const unsigned starts = word_ctx(row, wi, d).starts;
-    unsigned m = starts;
-    const int base = y * d.W + wi * 32;
-    int r0 = 0;
-    while (m) {
-        const int i = __ffs(m) - 1;
-        m &= m - 1;
-        const int s = base + i;
-        const int r = uf_root(lab, s);
-        lab[s] = r;
-        if (i == 0) r0 = r;
-        if (r == s) atomicAdd(&chunk_cnt[(long)img * d.nchunks + s / CHUNK], 1);
+    const unsigned starts = on ? word_ctx(row, wi, d).starts : 0u;
+    __shared__ WaveItems items[4];
+    __shared__ int s_r0[4][64];
+    const int G = wave_items_publish(items[wv], starts);
+    // one run start per lane (a word of a ragged edge holds a dozen, each a chase to its root)
+    for (int base = 0; base < G; base += 64) {
+        const int it = base + lane;
+        if (it < G) {
+            int L, i;
+            wave_item(items[wv], it, L, i);
+            const int idxL = idx0 + L, yL = ps.y_first + idxL / d.WW, wL = idxL - (idxL / d.WW) * d.WW;
+            const int s = yL * d.W + wL * 32 + i;
+            const int r = uf_root(lab, s);
+            lab[s] = r;
+            if (i == 0) s_r0[wv][L] = r;
+            if (r == s) atomicAdd(&chunk_cnt[(long)img * d.nchunks + s / CHUNK], 1);
+        }
     }
-    if (!(starts & 1u)) r0 = uf_root(lab, y * d.W + run_start(row, wi * 32));       // the run reaches in from the left
-    word_lab[((long)img * d.H + y) * d.WW + wi] = r0;
+    wave_lds_sync();
+    if (on) {
+        const int r0 = (starts & 1u) ? s_r0[wv][lane] : uf_root(lab, y * d.W + run_start(row, wi * 32));       // the run reaches in from the left
+        word_lab[((long)img * d.H + y) * d.WW + wi] = r0;
+    }
 }
 
 // suffix sums over chunks (one block per image): chunk_cnt[c] := number of starts in chunks > c; total per image
@@ -678,12 +788,7 @@ __device__ __forceinline__ int st_in(unsigned s) { return (int)(s >> 29); }
 // horizontal states starting at that word, 0: one state; the records of an 8-row x 8-word tile lie behind each other in the tile's
 // fixed slice, their number in the tile's header word
 struct StageArgs2 { uint2 *rec; int *hdr; long cap; };
-// LDS hand-off between the lanes of ONE wave (a wave's LDS operations execute in order; the fences keep the compiler from moving accesses)
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
+
 constexpr int STAGE_TILE = 8192;                // record slots per tile (a pixel has at most four gaps: no reservation, no overflow)
 
 // A wave's table of the borders it met (LDS): candidate -> slot by k & 63 with linear probing; what is booked there goes to the border's
@@ -3231,7 +3336,7 @@ static void run_chain(ptocr_dbpost *h, const float *d_maps, const uint8_t *d_bit
             if (nslab > 1) {
                 CclPass pb = ps;
                 pb.row_step = SLAB_ROWS;
-                hipLaunchKernelGGL(ccl_merge_kernel<1>, dim3(cdiv((nslab - 1) * d.WW, 256), N), dim3(256), 0, s, bits, w_labels, d, pb);
+                hipLaunchKernelGGL(ccl_merge_rows_kernel, dim3(cdiv((nslab - 1) * d.WW, 256), N), dim3(256), 0, s, bits, w_labels, d, pb);
             }
         }
         hipLaunchKernelGGL(ccl_flatten_kernel, word_grid, dim3(256), 0, s, bits, w_labels, w_word_lab, w_chunk, d, ps);
