@@ -617,8 +617,10 @@ __global__ __launch_bounds__(SLAB_ROWS * 64) void ccl_slab_kernel(const unsigned
 // label[s] = root for every run start s; word_lab[word] = root of the run that covers bit 0 of the word (so that the root of
 // ANY pixel is two loads away: the run start inside its word, or the word's entry); counts border starts (roots) per
 // 1024-pixel chunk (chunk_cnt zeroed by the host)
+constexpr int ROOT_K = 16;               // roots of a 1024-pixel chunk the flatten pass lists for rank_starts_kernel (more: the chunk is re-scanned)
 __global__ __launch_bounds__(256) void ccl_flatten_kernel(const unsigned *__restrict__ bits, int *__restrict__ labels,
-                                                          int *__restrict__ word_lab, int *__restrict__ chunk_cnt, DbpostDims d, CclPass ps) {
+                                                          int *__restrict__ word_lab, int *__restrict__ chunk_cnt, int *__restrict__ chunk_roots,
+                                                          DbpostDims d, CclPass ps) {
     const int img = blockIdx.y;
     if (ccl_skip(ps, img)) return;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -644,7 +646,11 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(const unsigned *__rest
             const int r = uf_root(lab, s);
             lab[s] = r;
             if (i == 0) s_r0[wv][L] = r;
-            if (r == s) atomicAdd(&chunk_cnt[(long)img * d.nchunks + s / CHUNK], 1);
+            if (r == s) {                                        // a border start: counted and listed per chunk
+                const long ch = (long)img * d.nchunks + s / CHUNK;
+                const int pos = atomicAdd(&chunk_cnt[ch], 1);
+                if (pos < ROOT_K) chunk_roots[ch * ROOT_K + pos] = s;
+            }
         }
     }
     wave_lds_sync();
@@ -750,6 +756,90 @@ __global__ __launch_bounds__(256) void select_starts_kernel(const unsigned *__re
         }
     }
     __syncthreads();                                           // wave_cnt is reused by the next chunk
+    }
+}
+
+// Text route (one labelling pass): chunk_suffix_kernel + select_starts_kernel as ONE launch of one block per image (round 4: the pair
+// was 5 + 19 us of dependent launches, the second one 15 000 small workgroups of which a few hundred had work).  The flatten pass has
+// listed the roots of every chunk (up to ROOT_K): a thread owns a slice of chunks, takes the suffix sums and ranks the listed roots of its
+// chunks itself; a chunk with more roots than the list holds (speckle) is re-scanned by the whole block.  Same results as the pair:
+// candidate k = the root with the k-th largest pixel index, lab[root] = -2 - k, acc[k] initialised, totals.
+__global__ __launch_bounds__(1024) void rank_starts_kernel(const unsigned *__restrict__ bits, int *__restrict__ labels,
+                                                           const int *__restrict__ chunk_cnt, const int *__restrict__ chunk_roots,
+                                                           int *__restrict__ totals, int *__restrict__ strip_totals,
+                                                           Cand *__restrict__ cands, Acc *__restrict__ acc, DbpostDims d) {
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const int *cc = chunk_cnt + (long)img * d.nchunks;
+    int *lab = labels + (long)img * d.HW;
+    __shared__ int part[1024];
+    __shared__ int big[128][2], big_n;                           // chunks to re-scan: (chunk, starts in higher chunks)
+    __shared__ int wcnt[16];
+    if (tid == 0) big_n = 0;
+    const int per = cdiv(d.nchunks, 1024);
+    const int hi = d.nchunks - tid * per;                        // exclusive upper bound of my slice (thread 0: the highest chunks)
+    const int lo = hi - per > 0 ? hi - per : 0;
+    int s = 0;
+    for (int c = hi - 1; c >= lo && c >= 0; c--) s += cc[c];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    if (tid == 1023) { totals[img] = part[1023]; strip_totals[img] = part[1023]; }
+    auto take = [&](int p, int rank) {                           // root p is candidate `rank`
+        const int y = p / d.W, x = p - y * d.W;
+        Cand c; c.p = p; c.is_hole = !pix(bits + ((long)img * d.H + y) * d.WW, x);
+        cands[(long)img * MAX_CAND + rank] = c;
+        Acc a; a.nstates = 0; a.npts = 0; a.xmin = 0x7fffffff; a.xmax = -1; a.ymin = 0x7fffffff; a.ymax = -1; a.cursor = 0; a.off = -1;
+        acc[(long)img * MAX_CAND + rank] = a;
+        lab[p] = -2 - rank;
+    };
+    int after = part[tid] - s;                                  // starts in all higher slices
+    for (int c = hi - 1; c >= lo && c >= 0 && after < MAX_CAND; c--) {
+        const int cnt = cc[c];
+        if (cnt > ROOT_K) {
+            const int e = atomicAdd(&big_n, 1);
+            if (e < 128) { big[e][0] = c; big[e][1] = after; }  // (at most MAX_CAND / ROOT_K + 1 = 63 such chunks can matter)
+        } else if (cnt > 0) {
+            // the chunk's roots into registers in one go (a ragged map lists ten in a chunk: ranking them with a load per comparison was
+            // a hundred dependent loads), then rank = roots of the chunk with a larger index
+            const int *roots = chunk_roots + ((long)img * d.nchunks + c) * ROOT_K;
+            int rt[ROOT_K];
+#pragma unroll
+            for (int j = 0; j < ROOT_K; j++) rt[j] = j < cnt ? roots[j] : -1;
+#pragma unroll
+            for (int j = 0; j < ROOT_K; j++) {
+                int before = 0;
+#pragma unroll
+                for (int i = 0; i < ROOT_K; i++) before += rt[i] > rt[j] ? 1 : 0;
+                if (j < cnt && after + before < MAX_CAND) take(rt[j], after + before);
+            }
+        }
+        after += cnt;
+    }
+    __syncthreads();
+    const int nbig = big_n < 128 ? big_n : 128;
+    for (int e = 0; e < nbig; e++) {                             // the block scans the chunk's 1024 pixels, highest pixel first
+        const int chunk = big[e][0], aft = big[e][1];
+        const long p = (long)chunk * CHUNK + (1023 - tid);
+        bool is = false;
+        if (p < d.HW) {
+            const int y = (int)(p / d.W), x = (int)(p - (long)y * d.W);
+            const unsigned *row = bits + ((long)img * d.H + y) * d.WW;
+            is = (x == 0 || pix(row, x) != pix(row, x - 1)) && lab[p] == (int)p;      // only run starts carry labels
+        }
+        const unsigned long long m = __ballot(is);
+        if ((tid & 63) == 0) wcnt[tid >> 6] = __popcll(m);
+        __syncthreads();
+        if (is) {
+            int before = __popcll(m & ((1ull << (tid & 63)) - 1));
+            for (int w = 0; w < (tid >> 6); w++) before += wcnt[w];
+            if (aft + before < MAX_CAND) take((int)p, aft + before);
+        }
+        __syncthreads();
     }
 }
 
@@ -1022,7 +1112,10 @@ __global__ __launch_bounds__(256) void border_states_kernel(const unsigned *__re
 
 // per-border stage limits the planner below shares with the stage kernels
 constexpr int W_MW = 1024;                // border width a wave takes (wider: the full-size pass)
-constexpr int BAND_WORDS = 256;           // mask words per score band (two LDS planes of this size per wave)
+#ifndef PT_BAND_WORDS
+#define PT_BAND_WORDS 256
+#endif
+constexpr int BAND_WORDS = PT_BAND_WORDS;           // mask words per score band (two LDS planes of this size per wave)
 #ifndef PT_SCORE_UF
 #define PT_SCORE_UF 16
 #endif
@@ -3081,7 +3174,7 @@ using namespace ptocr;
 constexpr int DBPOST_STREAMS = 4;
 struct ptocr_dbpost {
     int max_n, max_h, max_w;
-    unsigned *bits; unsigned *bits2; int *labels; int *word_lab; int *chunk_cnt; int *totals; int *strip_totals; Cand *cands; Acc *acc;
+    unsigned *bits; unsigned *bits2; int *labels; int *word_lab; int *chunk_cnt; int *chunk_roots; int *totals; int *strip_totals; Cand *cands; Acc *acc;
     unsigned *pool; F2 *hin; int *hn; float *mini;
     Result *results; int *flags; int *src_wh; short *boxes; int *counts;
     int boxes_cap;
@@ -3133,6 +3226,7 @@ static int dbpost_alloc(ptocr_dbpost *h, int max_n, int max_h, int max_w) {
     PT_HIP(hipMalloc(&h->labels, sizeof(int) * max_n * hw));
     PT_HIP(hipMalloc(&h->word_lab, sizeof(int) * max_n * max_h * ww));
     PT_HIP(hipMalloc(&h->chunk_cnt, sizeof(int) * max_n * nch));
+    PT_HIP(hipMalloc(&h->chunk_roots, sizeof(int) * max_n * nch * ROOT_K));
     PT_HIP(hipMalloc(&h->totals, sizeof(int) * max_n));
     PT_HIP(hipMalloc(&h->zeroed, sizeof(int) * 6 * max_n));
     PT_HIP(hipMemset(h->zeroed, 0, sizeof(int) * 6 * max_n));
@@ -3184,7 +3278,7 @@ static int dbpost_alloc(ptocr_dbpost *h, int max_n, int max_h, int max_w) {
 
 extern "C" int ptocr_dbpost_destroy(ptocr_dbpost_t h) {
     if (!h) return 0;
-    void *bufs[] = {h->bits, h->bits2, h->labels, h->word_lab, h->chunk_cnt, h->totals, h->zeroed, h->cands, h->acc, h->pool, h->hin,
+    void *bufs[] = {h->bits, h->bits2, h->labels, h->word_lab, h->chunk_cnt, h->chunk_roots, h->totals, h->zeroed, h->cands, h->acc, h->pool, h->hin,
                     h->hn, h->mini, h->results, h->src_wh, h->boxes, h->list, h->tie, h->stamps, h->sc_off, h->sc_n, h->sc_item, h->sc_part, h->sc_done,
                     h->stage, h->stage_hdr};
     for (void *b : bufs) (void)hipFree(b);
@@ -3339,10 +3433,14 @@ static void run_chain(ptocr_dbpost *h, const float *d_maps, const uint8_t *d_bit
                 hipLaunchKernelGGL(ccl_merge_rows_kernel, dim3(cdiv((nslab - 1) * d.WW, 256), N), dim3(256), 0, s, bits, w_labels, d, pb);
             }
         }
-        hipLaunchKernelGGL(ccl_flatten_kernel, word_grid, dim3(256), 0, s, bits, w_labels, w_word_lab, w_chunk, d, ps);
-        hipLaunchKernelGGL(chunk_suffix_kernel, dim3(N), dim3(1024), 0, s, w_chunk, w_totals, d, ps, w_strip_totals);
+        hipLaunchKernelGGL(ccl_flatten_kernel, word_grid, dim3(256), 0, s, bits, w_labels, w_word_lab, w_chunk, h->chunk_roots + (long)i0 * d.nchunks * ROOT_K, d, ps);
+        if (strip_y) hipLaunchKernelGGL(chunk_suffix_kernel, dim3(N), dim3(1024), 0, s, w_chunk, w_totals, d, ps, w_strip_totals);
     }
-    hipLaunchKernelGGL(select_starts_kernel, dim3(cdiv(d.nchunks, SEL_CHUNKS), N), dim3(256), 0, s, bits, w_labels, w_chunk, w_totals, w_cands, w_acc, d);
+    if (strip_y)         // two labelling passes (bottom strip first): suffix sums per pass, then the selection over whichever pass stands
+        hipLaunchKernelGGL(select_starts_kernel, dim3(cdiv(d.nchunks, SEL_CHUNKS), N), dim3(256), 0, s, bits, w_labels, w_chunk, w_totals, w_cands, w_acc, d);
+    else                 // one pass: suffix sums and selection in one launch
+        hipLaunchKernelGGL(rank_starts_kernel, dim3(N), dim3(1024), 0, s, bits, w_labels, w_chunk, h->chunk_roots + (long)i0 * d.nchunks * ROOT_K, w_totals, w_strip_totals,
+                           w_cands, w_acc, d);
     const dim3 all_words(cdiv(cdiv(H, 8) * cdiv(d.WW, 8), 4), N);      // 8 x 8-word tiles, four per block
     StageArgs2 sg;
     sg.rec = h->stage + (long)i0 * h->stage_cap;
