@@ -493,8 +493,12 @@ __device__ __forceinline__ void lds_union(int *par, int a, int b) {
         a = old;
     }
 }
-__global__ __launch_bounds__(SLAB_ROWS * 64) void ccl_slab_kernel(const unsigned *__restrict__ bits, int *__restrict__ labels, int *__restrict__ chunk_cnt,
-                                                       DbpostDims d, CclPass ps) {
+// maps != null (round 4; W % 32 == 0): the slab kernel thresholds its own rows -- `pred > thresh` straight from the probability map,
+// coalesced 16-byte loads, nibbles of eight lanes combined into a word -- writes the bitmap words for the later kernels and counts the
+// run starts of the bottom strip: binarize_flat_kernel's launch (21 us at 5.4 TB/s, then 4 MB read back here) is gone from the text route.
+__global__ __launch_bounds__(SLAB_ROWS * 64) void ccl_slab_kernel(unsigned *__restrict__ bits, int *__restrict__ labels, int *__restrict__ chunk_cnt,
+                                                       DbpostDims d, CclPass ps, const float *__restrict__ maps, float thresh,
+                                                       int *__restrict__ strip_runs, int count_from_row) {
     const int img = blockIdx.y;
     if (ccl_skip(ps, img)) return;
     __shared__ unsigned sb[SLAB_ROWS * 64];                        // the slab's bitmap words (WW <= 64)
@@ -508,13 +512,38 @@ __global__ __launch_bounds__(SLAB_ROWS * 64) void ccl_slab_kernel(const unsigned
     const int nw = rows * d.WW;
     if (blockIdx.x == 0)
         for (int i = tid; i < d.nchunks; i += blockDim.x) chunk_cnt[(long)img * d.nchunks + i] = 0;
-    const unsigned *bimg = bits + ((long)img * d.H + y0) * d.WW;
-    if (tid < nw) sb[tid] = bimg[tid];
+    unsigned *bimg = bits + ((long)img * d.H + y0) * d.WW;
+    if (maps) {
+        // the slab's rows are one contiguous stretch of the map: quad q (four pixels) belongs to word q / 8; blockDim.x >= nw is a
+        // multiple of 8, so a lane keeps its place in its word from round to round and eight rounds cover the slab
+        const float4 *src = reinterpret_cast<const float4 *>(maps + (long)img * d.HW + (long)y0 * d.W);
+        const int nq = nw * 8;
+        float4 v4[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int q = tid + k * (int)blockDim.x; v4[k] = q < nq ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int q = tid + k * (int)blockDim.x;
+            const unsigned nib = (v4[k].x > thresh) | ((v4[k].y > thresh) << 1) | ((v4[k].z > thresh) << 2) | ((v4[k].w > thresh) << 3);
+            unsigned v = nib << (4 * (tid & 7));
+            v |= __shfl_xor(v, 1);
+            v |= __shfl_xor(v, 2);
+            v |= __shfl_xor(v, 4);
+            if (q < nq && (tid & 7) == 0) { sb[q >> 3] = v; bimg[q >> 3] = v; }
+        }
+    } else if (tid < nw) sb[tid] = bimg[tid];
     __syncthreads();
     const int yl = tid / d.WW, wi = tid - yl * d.WW;              // tid >= nw: idle along (barriers)
     const bool on = tid < nw;
     WordCtx c = {0u, 0u, 0u, 0u};
     if (on) c = word_ctx(sb + yl * d.WW, wi, d);
+    if (maps && strip_runs && count_from_row > 0 && y0 + rows > count_from_row) {      // (uniform) run starts of both polarities in the bottom strip,
+        int cs = 0;                                             // column 0 against the background frame: binarize_flat_kernel's count
+        if (on && y0 + yl >= count_from_row) cs = __popc(c.starts) - ((wi == 0 && !(c.w & 1u)) ? 1 : 0);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) cs += __shfl_xor(cs, o);
+        if (lane == 0 && cs) atomicAdd(&strip_runs[img], cs);
+    }
     // exclusive prefix of the run-start counts over the slab's words
     int cnt = __popc(c.starts), incl = cnt;
 #pragma unroll
@@ -3393,10 +3422,14 @@ static void run_chain(ptocr_dbpost *h, const float *d_maps, const uint8_t *d_bit
     // be enough and is left out for that image (its four kernels return at once); a caller's own bitmap or the dilation is not counted
     // (no count: the strip pass always runs).
     const dim3 row_grid(cdiv(W, 1024), H, N);
+    // text route on maps whose width is a multiple of 32: the slab kernel thresholds its own rows (no binarize launch)
+    static const int global_ccl = getenv("PTOCR_DBPOST_GLOBAL_CCL") && atoi(getenv("PTOCR_DBPOST_GLOBAL_CCL")) == 1;      // experiment: text route on the global union-find
+    const bool fused_binarize = counted && !h->noise_now && strip_y == 0 && (W & 31) == 0 && !global_ccl;
+    const int count_row = H > 2 * STRIP_ROWS ? H - STRIP_ROWS : 0;
     if (d_bitmap) hipLaunchKernelGGL(pack_u8_kernel, row_grid, dim3(256), 0, s, d_bitmap, w_bits, d);
-    else {
+    else if (!fused_binarize) {
         DbpostDims dc = d;                                       // the count is taken whether or not the strip pass runs this time
-        dc.strip_y = H > 2 * STRIP_ROWS ? H - STRIP_ROWS : 0;
+        dc.strip_y = count_row;
         if ((W & 31) == 0)
             hipLaunchKernelGGL(binarize_flat_kernel, dim3(cdiv(H * (W >> 2), 512), N), dim3(256), 0, s, d_maps, w_bits, dc, thresh, counted ? w_strip_runs : nullptr);
         else
@@ -3416,7 +3449,6 @@ static void run_chain(ptocr_dbpost *h, const float *d_maps, const uint8_t *d_bit
         const int words = (H - ps.y_first) * d.WW;
         const dim3 word_grid(cdiv(words > d.nchunks ? words : d.nchunks, 256), N);
         ps.row_step = 0;
-        static const int global_ccl = getenv("PTOCR_DBPOST_GLOBAL_CCL") && atoi(getenv("PTOCR_DBPOST_GLOBAL_CCL")) == 1;
         if (h->noise_now || !counted) {                             // noise route (or no count): the global union-find, four threads per word
             hipLaunchKernelGGL(ccl_init_kernel, word_grid, dim3(256), 0, s, bits, w_labels, w_chunk, d, ps);
             hipLaunchKernelGGL(ccl_merge_kernel<4>, dim3(cdiv(4 * words, 256), N), dim3(256), 0, s, bits, w_labels, d, ps);
@@ -3426,7 +3458,8 @@ static void run_chain(ptocr_dbpost *h, const float *d_maps, const uint8_t *d_bit
         } else {
             // text route: slabs of eight rows labelled in LDS, then the slab boundary rows linked globally
             const int rows = H - ps.y_first, nslab = cdiv(rows, SLAB_ROWS);
-            hipLaunchKernelGGL(ccl_slab_kernel, dim3(nslab, N), dim3(cdiv(SLAB_ROWS * d.WW, 64) * 64), 0, s, bits, w_labels, w_chunk, d, ps);
+            hipLaunchKernelGGL(ccl_slab_kernel, dim3(nslab, N), dim3(cdiv(SLAB_ROWS * d.WW, 64) * 64), 0, s, bits, w_labels, w_chunk, d, ps,
+                               fused_binarize ? d_maps : nullptr, thresh, w_strip_runs, count_row);
             if (nslab > 1) {
                 CclPass pb = ps;
                 pb.row_step = SLAB_ROWS;
