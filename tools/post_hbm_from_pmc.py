@@ -28,7 +28,7 @@ for k in f:
     total_b += (rd + wr) * n * 1e6
     e = per.setdefault(name, {"launches": 0, "mb": 0.0, "us": 0.0}); e["launches"] += n; e["mb"] += (rd + wr) * n; e["us"] += dur * n
 # calls = launches of a once-per-call kernel
-once = [v["launches"] for kk, v in per.items() if ("binarize" in kk or "stem3x3" in kk)]
+once = [v["launches"] for kk, v in per.items() if ("pool_offsets" in kk or "stem3x3" in kk)]
 calls = once[0] if once else 1
 for v in per.values():
     v["gbps"] = round(v["mb"] / max(v["us"], 1e-9) * 1e3, 1); v["mb_per_call"] = round(v["mb"] / calls, 2); v["us_per_call"] = round(v["us"] / calls, 1)
