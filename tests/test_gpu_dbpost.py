@@ -228,6 +228,19 @@ def test_edge_cases():
     _compare(maps, [[w, h]] * len(cases))
 
 
+@pytest.mark.parametrize("h,w", [(1, 32), (3, 64), (8, 32), (9, 96), (17, 2048), (96, 2048), (64, 1024)])
+def test_widths_that_are_multiples_of_32_threshold_inside_the_slab_kernel(h, w):
+    """maps whose width is a multiple of 32 skip the binarize launch on the text route: the slab kernel thresholds its own rows (one
+    to eight of them, up to the widest map the workspace takes: 2048 pixels = 64 words, a 512-thread slab)"""
+    rng = np.random.default_rng(h * 10007 + w)
+    m = _random_scene(rng, max(h, 8), w)[:h][None] if h < 8 else _random_scene(rng, h, w)[None]
+    m = np.ascontiguousarray(m, np.float32)
+    m[0, :, ::97] = 0.9                                           # some columns of single pixels / short vertical strokes
+    if h >= 9:
+        m[0, h // 2, :] = 0.95                                    # one border as wide as the map (wider than 1024 px: the full-size pass)
+    _compare(m, [[2 * w, 3 * h]])
+
+
 def test_wide_component_uses_global_mask_slot():
     h, w = 300, 1280
     m = np.zeros((1, h, w), np.float32)
