@@ -195,6 +195,15 @@ int ptocr_pwconv_bf16(const void *d_x, const void *d_w, const float *d_bias, con
  * out_up block per pixel (nearest upsample) into channels [coff, coff + cstore) of a tensor with channel stride out_ldc. */
 int ptocr_conv3x3_bf16(const void *d_x, const void *d_w, const float *d_bias, void *d_y, int N, int H, int W, int Cin, int cstore,
                        int act, int out_up, int out_ldc, int out_coff, void *stream);
+
+/* The FPN lateral fused into the smoothing conv of the largest level (reference fpn.py:102-131: out2 = in2(c2) + upsample(out3), then
+ * p2 = out2_conv(out2)): y = conv3x3(relu(bn(conv1x1(x2))) + nearest_x2(td)), the intermediate never written.
+ * x2 bf16[N,H,W,16] (input channels padded to 16), wl bf16[96][16] + bl f32[96] (the lateral, BN folded), td bf16[N,H/2,W/2,td_ldc]
+ * (>= 96 channels), w3 bf16[32][9*96] + b3 f32[32] (the smoothing conv); y, cstore, act, out_up, out_ldc, out_coff as in
+ * ptocr_conv3x3_bf16.  Bit-identical to ptocr_pwconv_bf16 (res_mode 2) followed by ptocr_conv3x3_bf16. */
+int ptocr_conv3x3_lat_bf16(const void *d_x2, const void *d_wl, const float *d_bl, const void *d_td, int td_ldc, const void *d_w3,
+                           const float *d_b3, void *d_y, int N, int H, int W, int cstore, int act, int out_up, int out_ldc,
+                           int out_coff, void *stream);
 /* depthwise k x k conv + bias + activation; d_partial (optional) f32[N][nblk][C], nblk = ptocr_dwconv_bf16_nblk(...): per-chunk
  * channel sums of the activated output for the Squeeze-Excitation pool (fixed summation order: deterministic). */
 int ptocr_dwconv_bf16(const void *d_x, const float *d_w, const float *d_bias, void *d_y, float *d_partial, int N, int H, int W,

@@ -544,6 +544,206 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// ---- FPN lateral INSIDE the smoothing conv (round 4).  The largest FPN level of the bf16 detector ran as two launches: the lateral
+// `in2` (1x1, 16 -> 96, + ReLU, + nearest-x2 top-down add: 362 MB written at 184 x 320 x 32 images, 223 us) and the smoothing conv
+// `out2` (3x3, 96 -> 24: reads those 362 MB back, 190 us).  The lateral's output has no other consumer, so this kernel never writes it:
+// a workgroup stages the 16-channel patch of c2 (10 x 34 pixels, 11 KB) and the matching 6 x 18 pixels of the top-down tensor in LDS,
+// computes the 96 lateral channels of its patch with one bf16 MFMA per 32 pixels x 32 channels (K = 16) -- bias, ReLU, top-down add in
+// fp32, ONE rounding to bf16: the same arithmetic in the same order as pw_bf16_kernel, so the patch holds bit for bit what the 3x3 kernel
+// used to read -- writes them where conv3x3_bf16_pers8_kernel's patch lives, and runs that kernel's MFMA phase, exchange and write-back
+// unchanged.  Prefetch per tile: 5 sixteen-byte pieces per thread instead of 8.
+struct C3LatArgs {
+    C3Args c;                       // the smoothing conv (x unused; Cin = 96)
+    const __bf16 *x2, *wl, *td;     // lateral input [N,H,W,16], lateral weights [96][16], top-down tensor [N,H/2,W/2,td_ldc]
+    const float *bl;                // lateral bias f32[96]
+    int td_ldc;
+};
+
+template <int ACT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_lat_bf16_kernel(C3LatArgs q, int tiles_x, int tiles_per_img, int total) {
+    constexpr int NCS = 6, TH = 8, HC = NCS / 2;
+    constexpr int NCH = 2 * NCS, STRIDE = 16 * NCH + 16;         // 96 channels: 12 pieces of 16 bytes + 16 bytes of padding per patch pixel
+    constexpr int PW = C3_TW + 2, PH = TH + 2, NPX = PH * PW;    // 34 x 10 = 340 patch pixels
+    constexpr int TDW = C3_TW / 2 + 2, TDH = TH / 2 + 2, NTD = TDH * TDW;   // 18 x 6 = 108 top-down pixels
+    constexpr int TDS = 16 * NCH + 16;                           // top-down pixel stride in LDS (same padding rule)
+    constexpr int N2 = (NPX * 2 + 511) / 512, NT3 = (NTD * NCH + 511) / 512;     // prefetch pieces per thread: 2 + 3
+    const C3Args &p = q.c;
+    __shared__ __attribute__((aligned(16))) unsigned char patch[NPX * STRIDE];
+    __shared__ __attribute__((aligned(16))) unsigned char c2l[NPX * 32];
+    __shared__ __attribute__((aligned(16))) unsigned char tdl[NTD * TDS];
+    __shared__ __attribute__((aligned(16))) float s_bl[96];
+    static_assert(sizeof(patch) >= 4 * 64 * 32 * 4 + TH * C3_TW * 32 * 2, "patch buffer doubles as partial-sum + output staging");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int rw = wave & 3, half = wave >> 2;
+    if (threadIdx.x < 96) s_bl[threadIdx.x] = q.bl[threadIdx.x];
+    int n, ty0, tx0;
+    auto decode = [&](int t) {
+        n = t / tiles_per_img;
+        const int rem = t - n * tiles_per_img;
+        ty0 = (rem / tiles_x) * TH; tx0 = (rem % tiles_x) * C3_TW;
+    };
+    // tile-invariant piece coordinates, once per thread
+    int c2_py[N2], c2_px[N2], c2_lds[N2];
+#pragma unroll
+    for (int k = 0; k < N2; k++) {
+        const int i = threadIdx.x + 512 * k, pix = i >> 1;
+        c2_py[k] = pix / PW; c2_px[k] = i < NPX * 2 ? pix - (pix / PW) * PW : (1 << 20);
+        c2_lds[k] = pix * 32 + (i & 1) * 16;
+    }
+    int td_py[NT3], td_px[NT3], td_ch[NT3], td_lds[NT3];
+#pragma unroll
+    for (int k = 0; k < NT3; k++) {
+        const int i = threadIdx.x + 512 * k, pix = i / NCH;
+        td_ch[k] = i - pix * NCH;
+        td_py[k] = pix / TDW; td_px[k] = i < NTD * NCH ? pix - (pix / TDW) * TDW : (1 << 20);
+        td_lds[k] = pix * TDS + td_ch[k] * 16;
+    }
+    const int H2 = p.H >> 1, W2 = p.W >> 1;
+    bf16x8 pv2[N2], pvt[NT3];
+    auto gload = [&]() {
+        const __bf16 *x2 = q.x2 + (long)n * p.H * p.W * 16;
+        const __bf16 *td = q.td + (long)n * H2 * W2 * q.td_ldc;
+#pragma unroll
+        for (int k = 0; k < N2; k++) {
+            const int iy = ty0 - 1 + c2_py[k], ix = tx0 - 1 + c2_px[k];
+            pv2[k] = ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) ? *reinterpret_cast<const bf16x8 *>(x2 + ((long)iy * p.W + ix) * 16 + (threadIdx.x & 1) * 8) : zero8();
+        }
+#pragma unroll
+        for (int k = 0; k < NT3; k++) {
+            const int sy = (ty0 >> 1) - 1 + td_py[k], sx = (tx0 >> 1) - 1 + td_px[k];
+            pvt[k] = ((unsigned)sy < (unsigned)H2 && (unsigned)sx < (unsigned)W2) ? *reinterpret_cast<const bf16x8 *>(td + ((long)sy * W2 + sx) * q.td_ldc + td_ch[k] * 8) : zero8();
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int k = 0; k < N2; k++) if (c2_px[k] < (1 << 20)) *reinterpret_cast<bf16x8 *>(c2l + c2_lds[k]) = pv2[k];
+#pragma unroll
+        for (int k = 0; k < NT3; k++) if (td_px[k] < (1 << 20)) *reinterpret_cast<bf16x8 *>(tdl + td_lds[k]) = pvt[k];
+    };
+    // the smoothing conv's weight fragments (as conv3x3_bf16_pers8_kernel) and the lateral's: rows 32 cb + r, k half h
+    const __bf16 *wrow = p.w + (long)r * 9 * p.Cin + 8 * h + half * HC * 16;
+    bf16x8 aw[9][HC];
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+        for (int cs = 0; cs < HC; cs++) aw[tap][cs] = *reinterpret_cast<const bf16x8 *>(wrow + tap * p.Cin + cs * 16);
+    bf16x8 al[3];
+#pragma unroll
+    for (int cb = 0; cb < 3; cb++) al[cb] = *reinterpret_cast<const bf16x8 *>(q.wl + (long)(32 * cb + r) * 16 + 8 * h);
+    const int U = p.out_up, CS = p.cstore, PCS = CS >> 3;
+    f32x4 biasr[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) biasr[g] = 8 * g + 4 * h < CS ? *reinterpret_cast<const f32x4 *>(p.bias + 8 * g + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int NWB = 2;
+    int wb_src[NWB], wb_yx[NWB], wb_part[NWB];
+#pragma unroll
+    for (int w = 0; w < NWB; w++) {
+        const int i = threadIdx.x + 512 * w;
+        const int px = i / PCS, part_i = i - px * PCS;
+        wb_src[w] = i < TH * C3_TW * PCS ? px * 32 + part_i * 8 : -1;
+        wb_yx[w] = ((px / C3_TW) << 16) | (px % C3_TW);
+        wb_part[w] = part_i * 8;
+    }
+    int tile, tstep, tend;
+    if ((gridDim.x & 7) == 0) {
+        const int j = blockIdx.x & 7;
+        tile = (int)((long)j * total / 8) + (int)(blockIdx.x >> 3);
+        tstep = (int)(gridDim.x >> 3);
+        tend = (int)((long)(j + 1) * total / 8);
+    } else { tile = blockIdx.x; tstep = gridDim.x; tend = total; }
+    if (tile >= tend) return;
+    decode(tile);
+    gload();
+    lstore();
+    __syncthreads();
+    f32x4 *part = reinterpret_cast<f32x4 *>(patch);
+    __bf16 *ob = reinterpret_cast<__bf16 *>(patch + 4 * 64 * 2 * sizeof(f32x16));
+    for (;;) {
+        const int c_n = n, c_ty0 = ty0, c_tx0 = tx0;
+        // ---- the lateral: 11 groups of 32 patch pixels x 3 blocks of 32 channels, one (group, block) unit per wave and round
+        for (int u = wave; u < 11 * 3; u += 8) {
+            const int g = u / 3, cb = u - g * 3;
+            const int pix = 32 * g + r;                          // this lane's patch pixel (MFMA column)
+            const int pixc = pix < NPX ? pix : NPX - 1;
+            const bf16x8 b = *reinterpret_cast<const bf16x8 *>(c2l + pixc * 32 + 16 * h);
+            f32x16 la = (f32x16)(0.f);
+            la = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb == 0 ? al[0] : cb == 1 ? al[1] : al[2], b, la, 0, 0, 0);
+            const int py = pixc / PW, px = pixc - py * PW;
+            const int iy = c_ty0 - 1 + py, ix = c_tx0 - 1 + px;
+            const bool inside = pix < NPX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            // top-down pixel of (iy, ix): (iy >> 1, ix >> 1), relative to the staged region's origin ((ty0 >> 1) - 1, (tx0 >> 1) - 1)
+            const int tpy = ((c_ty0 + py + 1) >> 1) - (c_ty0 >> 1), tpx = ((c_tx0 + px + 1) >> 1) - (c_tx0 >> 1);     // = (iy >> 1) - origin, for iy >= -1
+            const unsigned char *tdp = tdl + (tpy * TDW + tpx) * TDS;
+            if (pix < NPX) {
+#pragma unroll
+                for (int qd = 0; qd < 4; qd++) {
+                    const int co = 32 * cb + 8 * qd + 4 * h;
+                    const f32x4 bias = *reinterpret_cast<const f32x4 *>(s_bl + co);
+                    const bf16x4 t4 = *reinterpret_cast<const bf16x4 *>(tdp + co * 2);
+                    bf16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) o[j] = inside ? (__bf16)(fmaxf(la[4 * qd + j] + bias[j], 0.f) + (float)t4[j]) : (__bf16)0.f;
+                    *reinterpret_cast<bf16x4 *>(patch + pix * STRIDE + co * 2) = o;
+                }
+            }
+        }
+        __syncthreads();
+        const int next = tile + tstep;
+        const bool has_next = next < tend;
+        if (has_next) { decode(next); gload(); }                 // in flight during this tile's MFMAs
+
+        f32x16 acc[2];
+        acc[0] = (f32x16)(0.f); acc[1] = (f32x16)(0.f);
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int dy = tap / 3, dx = tap % 3;
+            const unsigned char *b0 = patch + ((2 * rw + dy) * PW + r + dx) * STRIDE + 16 * h + half * HC * 32;
+            const unsigned char *b1 = b0 + PW * STRIDE;
+#pragma unroll
+            for (int cs = 0; cs < HC; cs++) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[tap][cs], *reinterpret_cast<const bf16x8 *>(b0 + cs * 32), acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[tap][cs], *reinterpret_cast<const bf16x8 *>(b1 + cs * 32), acc[1], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                         // the patch is consumed: its LDS now carries partial sums and outputs
+        auto give = [&](const f32x16 &a) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) part[((wave * 4 + g) << 6) + lane] = f32x4{a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+        };
+        auto finish = [&](const f32x16 &a, int j) {
+            f32x4 o2[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++) o2[g] = part[(((wave ^ 4) * 4 + g) << 6) + lane];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                bf16x4 o;
+#pragma unroll
+                for (int qq = 0; qq < 4; qq++) o[qq] = (__bf16)actc<ACT>((a[4 * g + qq] + o2[g][qq]) + biasr[g][qq]);
+                *reinterpret_cast<bf16x4 *>(ob + ((2 * rw + j) * C3_TW + r) * 32 + 8 * g + 4 * h) = o;
+            }
+        };
+        if (half) give(acc[0]); else give(acc[1]);
+        __syncthreads();
+        if (half) finish(acc[1], 1); else finish(acc[0], 0);
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < NWB; w++) {
+            const int oy = c_ty0 + (wb_yx[w] >> 16), ox = c_tx0 + (wb_yx[w] & 0xffff);
+            if (wb_src[w] < 0 || oy >= p.H || ox >= p.W) continue;
+            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(ob + wb_src[w]);
+            __bf16 *dst = p.y + (((long)c_n * p.H * U + oy * U) * ((long)p.W * U) + ox * U) * p.out_ldc + p.out_coff + wb_part[w];
+            for (int uy = 0; uy < U; uy++)
+                for (int ux = 0; ux < U; ux++) *reinterpret_cast<bf16x8 *>(dst + ((long)uy * p.W * U + ux) * p.out_ldc) = v;
+        }
+        if (!has_next) break;
+        __syncthreads();                                         // output staging read: the LDS takes the next tile's inputs
+        lstore();
+        __syncthreads();
+        tile = next;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- depthwise conv (+ SE pooling)
 // block = (C/8 channel groups) x (L = 256 / (C/8) pixel lanes) over a chunk of output pixels of one image; a thread
 // computes 8 channels of its pixels (16-byte loads and stores, fp32 arithmetic).  With `partial` set the kernel also leaves the
@@ -1002,6 +1202,37 @@ extern "C" int ptocr_conv3x3_bf16(const void *d_x, const void *d_w, const float 
     }
     hipLaunchKernelGGL(conv3x3_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     return launch_ok("conv3x3_bf16_kernel");
+}
+
+// The FPN lateral fused into the smoothing conv (conv3x3_lat_bf16_kernel): y = conv3x3(relu(bn(conv1x1(x2))) + nearest_x2(td)) with the
+// intermediate never written.  x2 bf16[N,H,W,16] (16 padded input channels), wl bf16[96][16] + bl f32[96] (the lateral, BN folded),
+// td bf16[N,H/2,W/2,td_ldc] (>= 96 channels), w3 bf16[32][9*96] + b3 f32[32] (the smoothing conv), y as in ptocr_conv3x3_bf16.
+extern "C" int ptocr_conv3x3_lat_bf16(const void *d_x2, const void *d_wl, const float *d_bl, const void *d_td, int td_ldc, const void *d_w3,
+                                      const float *d_b3, void *d_y, int N, int H, int W, int cstore, int act, int out_up, int out_ldc,
+                                      int out_coff, void *stream) {
+    PT_CHECK(d_x2 && d_wl && d_bl && d_td && d_w3 && d_b3 && d_y && N >= 1 && H >= 2 && W >= 2, "ptocr_conv3x3_lat_bf16: null / empty argument");
+    PT_CHECK(H % 2 == 0 && W % 2 == 0 && td_ldc >= 96 && td_ldc % 8 == 0, "ptocr_conv3x3_lat_bf16: even map sizes and a top-down tensor of >= 96 channels");
+    PT_CHECK(cstore % 8 == 0 && cstore >= 8 && cstore <= 32 && act >= 0 && act <= 2 && out_up >= 1 && out_up <= 8, "ptocr_conv3x3_lat_bf16: cstore <= 32, out_up <= 8");
+    PT_CHECK(out_ldc >= out_coff + cstore && out_ldc % 8 == 0 && out_coff % 8 == 0, "ptocr_conv3x3_lat_bf16: bad strides");
+    PT_CHECK((long)H * W * 96 * 2 < (1L << 31), "ptocr_conv3x3_lat_bf16: image larger than 2 GiB");
+    C3LatArgs q;
+    q.c.x = nullptr; q.c.w = (const __bf16 *)d_w3; q.c.bias = d_b3; q.c.y = (__bf16 *)d_y; q.c.M = (long)N * H * W; q.c.H = H; q.c.W = W; q.c.Cin = 96;
+    q.c.cstore = cstore; q.c.act = act; q.c.out_up = out_up; q.c.out_ldc = out_ldc; q.c.out_coff = out_coff;
+    q.x2 = (const __bf16 *)d_x2; q.wl = (const __bf16 *)d_wl; q.td = (const __bf16 *)d_td; q.bl = d_bl; q.td_ldc = td_ldc;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        PT_HIP(hipGetDevice(&dev));
+        PT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const int tiles_x = cdiv(W, C3_TW), tpi = tiles_x * cdiv(H, 8);
+    const long total = (long)N * tpi;
+    PT_CHECK(total < (1L << 31), "ptocr_conv3x3_lat_bf16: too many tiles");
+    const int grid = total < (long)n_cu ? (int)total : n_cu;
+#define PT_C3L(A) hipLaunchKernelGGL((conv3x3_lat_bf16_kernel<A>), dim3(grid), dim3(512), 0, (hipStream_t)stream, q, tiles_x, tpi, (int)total)
+    PT_ACT_SWITCH(act, PT_C3L);
+#undef PT_C3L
+    return launch_ok("conv3x3_lat_bf16_kernel");
 }
 
 extern "C" int ptocr_dwconv_bf16(const void *d_x, const float *d_w, const float *d_bias, void *d_y, float *d_partial, int N, int H, int W,

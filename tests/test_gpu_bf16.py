@@ -122,6 +122,41 @@ def test_conv3x3_many_tiles_images_and_concat_slice():
     assert float(((y[..., :24].double() - ref).abs() / (ref.abs() + 1)).max()) <= 6e-3
 
 
+@pytest.mark.parametrize("n,h,w", [(2, 16, 64), (3, 38, 74), (1, 184, 320), (2, 10, 6)])
+def test_lateral_fused_into_the_smoothing_conv_is_bit_identical(n, h, w):
+    """ptocr_conv3x3_lat_bf16 (round 4: the FPN lateral in2 computed inside the patch staging of the smoothing conv out2, its 96-channel
+    output never written) against the two launches it replaces, ptocr_pwconv_bf16 (ReLU, nearest-x2 top-down add) + ptocr_conv3x3_bf16:
+    the same bf16 products, fp32 sums in the same order and ONE rounding of the intermediate -- the outputs must be identical to the
+    last bit, on maps with partial tiles on both edges and into a slice of a concat buffer whose other slices stay untouched"""
+    from pytorchocr_amd.modeling import bf16_path as bp
+    from pytorchocr_amd.modeling import ops
+    torch.manual_seed(100 * h + w)
+    dev = torch.device("cuda:0")
+    lat_conv = torch.nn.Conv2d(16, 96, 1, bias=False)
+    lat_bn = torch.nn.BatchNorm2d(96).eval(); lat_bn.running_var.uniform_(0.5, 1.5); lat_bn.running_mean.uniform_(-0.2, 0.2)
+    lat = bp._Pw(lat_conv, lat_bn, dev, ops.ACT_RELU)
+    sm_conv = torch.nn.Conv2d(96, 24, 3, 1, 1, bias=False)
+    sm_bn = torch.nn.BatchNorm2d(24).eval(); sm_bn.running_var.uniform_(0.5, 1.5); sm_bn.running_mean.uniform_(-0.2, 0.2)
+    c3 = bp._C3(sm_conv, sm_bn, dev, 1)
+    c2 = _bf(torch.randn(n, h, w, 16)).cuda()
+    td = _bf(torch.randn(n, h // 2, w // 2, 96)).cuda()
+    two = torch.full((n, h, w, 96), 7.0, dtype=torch.bfloat16, device=dev)
+    out2 = bp.pwconv(c2, lat, res=td, res_mode=2)
+    bp.conv3x3(out2, c3, out=two, up=1, coff=72, cstore=24)
+    one = torch.full((n, h, w, 96), 7.0, dtype=torch.bfloat16, device=dev)
+    bp.conv3x3_lat(c2, lat, td, c3, out=one, up=1, coff=72, cstore=24)
+    torch.cuda.synchronize()
+    assert torch.equal(one.view(torch.int16), two.view(torch.int16))
+    assert float(one[..., 72:].float().abs().max()) > 0 and float((one[..., :72].float() - 7.0).abs().max()) == 0
+    # and against float64 arithmetic on the same bf16 operands
+    wl = lat.w.cpu().double()[:, :16]
+    mid = F.relu(torch.einsum("nhwc,oc->nhwo", c2.cpu().double(), wl) + lat.b.cpu().double()) + F.interpolate(td.cpu().double().permute(0, 3, 1, 2), scale_factor=2, mode="nearest").permute(0, 2, 3, 1)
+    mid = mid.to(torch.bfloat16).double()
+    wd = c3.w.cpu().double().reshape(32, 3, 3, 96)[:24].permute(0, 3, 1, 2)
+    ref = F.relu(F.conv2d(mid.permute(0, 3, 1, 2), wd, c3.b.cpu().double()[:24], 1, 1)).permute(0, 2, 3, 1)
+    assert float(((one[..., 72:].double().cpu() - ref).abs() / (ref.abs() + 1)).max()) <= 8e-3
+
+
 @pytest.mark.parametrize("hw", [(38, 64), (37, 62)])            # W % 4 == 0: two pixels per thread on 16-byte loads; otherwise one per thread
 def test_stem_kernel_both_forms(hw):
     import ctypes as C
