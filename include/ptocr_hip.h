@@ -208,6 +208,14 @@ int ptocr_conv3x3_lat_bf16(const void *d_x2, const void *d_wl, const float *d_bl
  * channel sums of the activated output for the Squeeze-Excitation pool (fixed summation order: deterministic). */
 int ptocr_dwconv_bf16(const void *d_x, const float *d_w, const float *d_bias, void *d_y, float *d_partial, int N, int H, int W,
                       int C, int k, int stride, int act, void *stream);
+/* MobileNetV3 inverted residual, first two stages of the block in one launch (reference det_mobilenet_v3.py:106-151: conv1 1x1 + BN +
+ * act, conv2 depthwise 3x3 / stride 2 + BN + act; no SE): the expanded tensor is never written.  x bf16[N,H,W,16] (input channels padded
+ * to 16); we bf16[C32][16] + be f32[C32], C32 = C rounded up to 32 (expansion, BN folded, padding rows zero); wd f32[9][C] tap-major + bd f32[C] (depthwise, BN
+ * folded); y bf16[N,(H-1)/2+1,(W-1)/2+1,C]; C a multiple of 16, <= 96; act_e == act_d in {1 ReLU, 2 Hardswish}.  Bit-identical to
+ * ptocr_pwconv_bf16 followed by ptocr_dwconv_bf16. */
+int ptocr_expand_dw3x3s2_bf16(const void *d_x, const void *d_we, const float *d_be, const float *d_wd, const float *d_bd, void *d_y,
+                              int N, int H, int W, int C, int act_e, int act_d, void *stream);
+
 int ptocr_dwconv_bf16_nblk(int N, int H, int W, int k, int stride);
 /* SE gate from those sums: d_scale f32[N][C] = hardsigmoid(fc2(relu(fc1(sum / HW)))) (det_mobilenet_v3.py:76-85) */
 int ptocr_se_fc_f32(const float *d_partial, const float *d_w1, const float *d_b1, const float *d_w2, const float *d_b2,

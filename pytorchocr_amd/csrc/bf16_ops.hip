@@ -888,6 +888,169 @@ __global__ __launch_bounds__(256) void dwconv_bf16_kernel(DwArgs p) {
     }
 }
 
+// ---- expansion INSIDE the depthwise conv (round 4).  The second block of MobileNetV3-small expands 16 -> 72 channels at 184 x 320 (a
+// 1x1 conv: 301 MB written per 32 images) only for the depthwise 3x3 / stride 2 that follows to read them back (the largest round trip of
+// the backbone: 96 + 134 us).  Here a workgroup takes a tile of 4 x 16 outputs: it stages the 9 x 33-pixel input patch (16 channels,
+// 9.5 KB), expands it with one bf16 MFMA per 32 pixels x 32 channels (bias, activation, ONE rounding to bf16 -- what pw_bf16_kernel
+// would have stored, bit for bit; pixels outside the image stay zero: the depthwise conv pads the EXPANDED tensor) into 51 KB of LDS and
+// runs dwconv_bf16_kernel's arithmetic (same taps in the same order, packed fp32 FMAs) from there.  The expanded tensor is never written.
+struct ExDwArgs {
+    const __bf16 *x, *we;           // input [N,H,W,16], expansion weights bf16[96][16] (rows beyond the layer's channels are zero)
+    const float *be, *wd, *bd;      // expansion bias f32[96]; depthwise weights f32[9][C] tap-major, bias f32[C]
+    __bf16 *y;                      // [N,Ho,Wo,C]
+    int H, W, Ho, Wo, C;            // C = padded expanded channels (multiple of 16, <= 96)
+};
+
+constexpr int XD_THREADS = 320;     // five waves: ten 32-pixel groups of the patch (two per wave) and, at 80 channels, 32 runs x 10 channel octets (one per thread)
+
+template <int C, int ACT_E, int ACT_D>
+__global__ __launch_bounds__(XD_THREADS) void expand_dw3x3s2_bf16_kernel(ExDwArgs p, int tiles_x, int tiles_y) {
+    constexpr int TOH = 4, TOW = 16, PH = 2 * TOH + 1, PW = 2 * TOW + 1, NPX = PH * PW;      // 9 x 33 = 297 input pixels
+    constexpr int NT = XD_THREADS, NW = NT / 64;
+    __shared__ __attribute__((aligned(16))) unsigned char xin[NPX * 32];
+    __shared__ __attribute__((aligned(16))) float wl[10 * C];  // depthwise [9 taps][C] + bias [C]
+    extern __shared__ __attribute__((aligned(16))) unsigned char ex[];      // [NPX][EXS]: the expanded patch
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int t = blockIdx.x, n = blockIdx.y;
+    const int oy0 = (t / tiles_x) * TOH, ox0 = (t % tiles_x) * TOW;
+    const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;
+    constexpr int C8 = C >> 3;
+    constexpr int EXS = 2 * C + 16;                                 // bytes per expanded pixel: an odd number of 16-byte chunks (C % 16 == 0)
+    const bool tile_inside = iy0 >= 0 && ix0 >= 0 && iy0 + PH <= p.H && ix0 + PW <= p.W;      // block-uniform
+    // phase 1: the input patch (zeros outside the image), all loads in flight at once, and the depthwise table
+    const __bf16 *ximg = p.x + (long)n * p.H * p.W * 16;
+    {
+        constexpr int NL = (NPX * 2 + NT - 1) / NT, NWL = (10 * C + NT - 1) / NT;
+        bf16x8 v[NL];
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int i = tid + NT * k, pix = i >> 1, py = pix / PW, px = pix - py * PW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            v[k] = zero8();
+            if (i < NPX * 2 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                v[k] = *reinterpret_cast<const bf16x8 *>(ximg + ((long)iy * p.W + ix) * 16 + (i & 1) * 8);
+        }
+        float w4[NWL];
+#pragma unroll
+        for (int k = 0; k < NWL; k++) {
+            const int i = tid + NT * k;
+            w4[k] = i < 9 * C ? p.wd[i] : i < 10 * C ? p.bd[i - 9 * C] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int i = tid + NT * k;
+            if (i < NPX * 2) *reinterpret_cast<bf16x8 *>(xin + (i >> 1) * 32 + (i & 1) * 16) = v[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NWL; k++) {
+            const int i = tid + NT * k;
+            if (i < 10 * C) wl[i] = w4[k];
+        }
+    }
+    // the expansion's weights and bias stay in registers: the kernel runs two workgroups per CU (LDS), registers are free
+    constexpr int ncb = (C + 31) >> 5;
+    bf16x8 ae[ncb];
+    f32x4 be[ncb][4];
+#pragma unroll
+    for (int cb = 0; cb < ncb; cb++) {
+        ae[cb] = *reinterpret_cast<const bf16x8 *>(p.we + (long)(32 * cb + r) * 16 + 8 * h);
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++) be[cb][qd] = *reinterpret_cast<const f32x4 *>(p.be + 32 * cb + 8 * qd + 4 * h);
+    }
+    __syncthreads();
+    // phase 2: the expansion, 32 pixels per wave and round: the pixel operand read once, the (up to) three MFMAs back to back
+    constexpr int NG = (NPX + 31) / 32;                          // 10 pixel groups
+    auto expand = [&](auto ins_tag) {
+        constexpr bool INS = decltype(ins_tag)::value;          // every pixel of the patch inside the image: no selects
+        for (int g = wave; g < NG; g += NW) {
+            const int pix = 32 * g + r, pixc = pix < NPX ? pix : NPX - 1;
+            const bf16x8 b = *reinterpret_cast<const bf16x8 *>(xin + pixc * 32 + 16 * h);
+            bool inside = true;
+            if (!INS) {
+                const int py = pixc / PW, px = pixc - py * PW;
+                inside = (unsigned)(iy0 + py) < (unsigned)p.H && (unsigned)(ix0 + px) < (unsigned)p.W;
+            }
+            f32x16 acc[ncb];
+#pragma unroll
+            for (int cb = 0; cb < ncb; cb++) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ae[cb], b, (f32x16)(0.f), 0, 0, 0);
+            unsigned char *dst = ex + pix * EXS + 8 * h;
+            if (pix < NPX) {
+#pragma unroll
+                for (int cb = 0; cb < ncb; cb++) {
+#pragma unroll
+                    for (int qd = 0; qd < 4; qd++) {
+                        if (32 * cb + 8 * qd < C) {             // C is a multiple of 16: both halves of the wave in or out
+                            const f32x2 s0 = f32x2{acc[cb][4 * qd], acc[cb][4 * qd + 1]} + f32x2{be[cb][qd][0], be[cb][qd][1]};
+                            const f32x2 s1 = f32x2{acc[cb][4 * qd + 2], acc[cb][4 * qd + 3]} + f32x2{be[cb][qd][2], be[cb][qd][3]};
+                            const f32x4 v = {actc<ACT_E>(s0[0]), actc<ACT_E>(s0[1]), actc<ACT_E>(s1[0]), actc<ACT_E>(s1[1])};
+                            bf16x4 o = __builtin_convertvector(v, bf16x4);
+                            if (!INS && !inside) o = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+                            *reinterpret_cast<bf16x4 *>(dst + (32 * cb + 8 * qd) * 2) = o;
+                        }
+                    }
+                }
+            }
+        }
+    };
+    if (tile_inside) expand(std::true_type{});
+    else expand(std::false_type{});
+    __syncthreads();
+    // phase 3: the depthwise 3x3 / stride 2 on the expanded patch: runs of two outputs per thread and channel octet, every output's taps
+    // in dwconv_bf16_kernel<3, 2>'s order (rows, then columns)
+    constexpr int R = 2, K = 3, S = 2, NC = (R - 1) * S + K, RPR = TOW / R, NRUN = TOH * RPR;
+    for (int task = tid; task < NRUN * C8; task += NT) {
+        const int pl = task / C8, ql = task - pl * C8;              // run, channel octet
+        const int ry = pl / RPR, rx0 = (pl - ry * RPR) * R;          // run's output row and first output column inside the tile
+        const int oy = oy0 + ry;
+        if (oy >= p.Ho) continue;
+        const float *bl = wl + 9 * C + ql * 8;
+        f32x2 acc[R][4];
+#pragma unroll
+        for (int rr = 0; rr < R; rr++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[rr][j] = f32x2{bl[2 * j], bl[2 * j + 1]};
+#pragma unroll
+        for (int a = 0; a < K; a++) {
+            const int iy = oy * S - 1 + a;
+            if ((unsigned)iy >= (unsigned)p.H) continue;
+            f32x2 wr[K][4];
+#pragma unroll
+            for (int b = 0; b < K; b++) {
+                const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wl + (a * K + b) * C + ql * 8), w1 = *reinterpret_cast<const f32x4 *>(wl + (a * K + b) * C + ql * 8 + 4);
+                wr[b][0] = f32x2{w0[0], w0[1]}; wr[b][1] = f32x2{w0[2], w0[3]}; wr[b][2] = f32x2{w1[0], w1[1]}; wr[b][3] = f32x2{w1[2], w1[3]};
+            }
+            const unsigned char *row = ex + ((ry * S + a) * PW) * EXS + ql * 16;
+#pragma unroll
+            for (int ci = 0; ci < NC; ci++) {
+                const int ix = (ox0 + rx0) * S - 1 + ci;
+                if ((unsigned)ix >= (unsigned)p.W) continue;
+                const u32x4 d = *reinterpret_cast<const u32x4 *>(row + (rx0 * S + ci) * EXS);
+                f32x2 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[j] = f32x2{__builtin_bit_cast(float, d[j] << 16), __builtin_bit_cast(float, d[j] & 0xffff0000u)};
+#pragma unroll
+                for (int rr = 0; rr < R; rr++) {
+                    const int b = ci - rr * S;
+                    if (b >= 0 && b < K) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) acc[rr][j] = __builtin_elementwise_fma(v[j], wr[b][j], acc[rr][j]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < R; rr++) {
+            const int ox = ox0 + rx0 + rr;
+            if (ox >= p.Wo) continue;
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = (__bf16)actc<ACT_D>(acc[rr][j >> 1][j & 1]);
+            *reinterpret_cast<bf16x8 *>(p.y + (((long)n * p.Ho + oy) * p.Wo + ox) * C + (long)ql * 8) = o;
+        }
+    }
+}
+
 template <int K, int S>
 static int launch_dw(const DwArgs &p, int N, hipStream_t stream) {
     const size_t lds = sizeof(float) * ((size_t)(K * K + 1) * p.ob * 8 + 256 * 8);
@@ -1250,6 +1413,43 @@ extern "C" int ptocr_dwconv_bf16(const void *d_x, const float *d_w, const float 
     p.xcd = xcd;
     if (k == 3) return stride == 1 ? launch_dw<3, 1>(p, N, (hipStream_t)stream) : launch_dw<3, 2>(p, N, (hipStream_t)stream);
     return stride == 1 ? launch_dw<5, 1>(p, N, (hipStream_t)stream) : launch_dw<5, 2>(p, N, (hipStream_t)stream);
+}
+
+// 1x1 expansion (16 padded input channels) + depthwise 3x3 / stride 2 / pad 1 in one launch (expand_dw3x3s2_bf16_kernel): the expanded
+// tensor is never written.  x bf16[N,H,W,16]; we bf16[r32(C)][16] + be f32[r32(C)] (BN folded; rows past the layer's channels zero); wd f32[9][C], bd f32[C]; y
+// bf16[N,Ho,Wo,C]; C a multiple of 16, <= 96.  No SE pool (the block it is built for has none).
+extern "C" int ptocr_expand_dw3x3s2_bf16(const void *d_x, const void *d_we, const float *d_be, const float *d_wd, const float *d_bd, void *d_y,
+                                         int N, int H, int W, int C, int act_e, int act_d, void *stream) {
+    PT_CHECK(d_x && d_we && d_be && d_wd && d_bd && d_y && N >= 1 && H >= 1 && W >= 1, "ptocr_expand_dw3x3s2_bf16: null / empty argument");
+    PT_CHECK(C % 16 == 0 && C >= 16 && C <= 96 && act_e >= 0 && act_e <= 2 && act_d >= 0 && act_d <= 2, "ptocr_expand_dw3x3s2_bf16: C must be a multiple of 16, <= 96");
+    PT_CHECK(N <= 65535, "ptocr_expand_dw3x3s2_bf16: batch too large for one launch");
+    ExDwArgs p;
+    p.x = (const __bf16 *)d_x; p.we = (const __bf16 *)d_we; p.be = d_be; p.wd = d_wd; p.bd = d_bd; p.y = (__bf16 *)d_y;
+    p.H = H; p.W = W; p.Ho = (H - 1) / 2 + 1; p.Wo = (W - 1) / 2 + 1; p.C = C;
+    const int tiles_x = cdiv(p.Wo, 16), tiles_y = cdiv(p.Ho, 4);
+    const dim3 grid(tiles_x * tiles_y, N);
+#define PT_XD(CC, E) do { \
+        constexpr int lds = 9 * 33 * (2 * CC + 16); \
+        static bool attr_set = false; \
+        if (!attr_set) { \
+            PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&expand_dw3x3s2_bf16_kernel<CC, E, E>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+            attr_set = true; \
+        } \
+        hipLaunchKernelGGL((expand_dw3x3s2_bf16_kernel<CC, E, E>), grid, dim3(XD_THREADS), (size_t)lds, (hipStream_t)stream, p, tiles_x, tiles_y); \
+    } while (0)
+#define PT_XD_C(E) do { \
+        switch (C) { \
+        case 16: PT_XD(16, E); break; case 32: PT_XD(32, E); break; case 48: PT_XD(48, E); break; \
+        case 64: PT_XD(64, E); break; case 80: PT_XD(80, E); break; default: PT_XD(96, E); break; \
+        } \
+    } while (0)
+    if (act_e != act_d || (act_e != 1 && act_e != 2))
+        return fail("ptocr_expand_dw3x3s2_bf16: the expansion and the depthwise conv must share ReLU or Hardswish (got %d, %d)", act_e, act_d);
+    if (act_e == 1) PT_XD_C(1);
+    else PT_XD_C(2);
+#undef PT_XD_C
+#undef PT_XD
+    return launch_ok("expand_dw3x3s2_bf16_kernel");
 }
 
 extern "C" int ptocr_dwconv_bf16_nblk(int N, int H, int W, int k, int stride) {

@@ -173,6 +173,26 @@ def dwconv(x, dw, want_pool):
     return y, partial, nblk
 
 
+EXDW_FUSE = os.environ.get("PTOCR_BF16_EXDW_FUSE", "1") != "0"    # 0: expansion and depthwise conv of a 16-channel stride-2 block as two launches
+
+
+def _exdw_ok(blk):
+    ex, dw = blk.get("ex"), blk["dw"]
+    return (EXDW_FUSE and ex is not None and "se" not in blk and ex.cin == 16 and dw.k == 3 and dw.stride == 2 and dw.c <= 96
+            and ex.cstore == dw.c and ex.act == dw.act and ex.act in (ops.ACT_RELU, ops.ACT_HSWISH))
+
+
+def expand_dw(x, ex, dw):
+    """1x1 expansion + depthwise 3x3 / stride 2 in one launch: the expanded tensor is never written"""
+    n, h, w_, cin = x.shape
+    assert cin == 16 and ex.cin == 16
+    y = torch.empty((n, (h - 1) // 2 + 1, (w_ - 1) // 2 + 1, dw.c), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.lib().ptocr_expand_dw3x3s2_bf16(_ptr(x), _ptr(ex.w), _ptr(ex.b), _ptr(dw.w), _ptr(dw.b), _ptr(y), n, h, w_, dw.c, ex.act, dw.act,
+                                                    _lib.cur_stream()), "ptocr_expand_dw3x3s2_bf16")
+    _count(x, ex.w, dw.w, y)
+    return y
+
+
 def se_gate(partial, nblk, se, hw):
     n = partial.shape[0]
     scale = torch.empty((n, se.c), dtype=torch.float32, device=partial.device)
@@ -250,8 +270,11 @@ class Mbv3DbBf16:
                 if "cba" in blk:
                     t = pwconv(t, blk["cba"])
                     continue
-                e = pwconv(t, blk["ex"]) if "ex" in blk else t
-                d, partial, nblk = dwconv(e, blk["dw"], "se" in blk)
+                if _exdw_ok(blk):
+                    d, partial, nblk = expand_dw(t, blk["ex"], blk["dw"]), None, 0
+                else:
+                    e = pwconv(t, blk["ex"]) if "ex" in blk else t
+                    d, partial, nblk = dwconv(e, blk["dw"], "se" in blk)
                 scale = se_gate(partial, nblk, blk["se"], d.shape[1] * d.shape[2]) if "se" in blk else None
                 t = pwconv(d, blk["pw"], res=t if blk["res"] else None, res_mode=1 if blk["res"] else 0, scale=scale)
             feats.append(t)

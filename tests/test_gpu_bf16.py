@@ -157,6 +157,39 @@ def test_lateral_fused_into_the_smoothing_conv_is_bit_identical(n, h, w):
     assert float(((one[..., 72:].double().cpu() - ref).abs() / (ref.abs() + 1)).max()) <= 8e-3
 
 
+@pytest.mark.parametrize("n,h,w,cexp,act", [(2, 16, 64, 72, 1), (3, 37, 75, 72, 1), (1, 184, 320, 72, 1), (2, 9, 5, 88, 2), (2, 24, 34, 40, 2),
+                                            (1, 1, 1, 96, 1), (2, 8, 32, 16, 2)])
+def test_expansion_fused_into_the_depthwise_conv_is_bit_identical(n, h, w, cexp, act):
+    """ptocr_expand_dw3x3s2_bf16 (round 4: the 1x1 expansion of a 16-channel stride-2 inverted residual computed inside the depthwise
+    conv's tile staging, the expanded tensor never written) against the two launches it replaces, ptocr_pwconv_bf16 + ptocr_dwconv_bf16:
+    the same bf16 products, ONE rounding of the expanded tensor, the depthwise taps in the same order -- identical to the last bit on maps
+    with partial tiles on both edges, odd sizes (the bottom / right padding tap present or not) and channel counts that pad differently"""
+    from pytorchocr_amd.modeling import bf16_path as bp
+    torch.manual_seed(1000 * h + w + cexp)
+    dev = torch.device("cuda:0")
+    ec = torch.nn.Conv2d(16, cexp, 1, bias=False)
+    eb = torch.nn.BatchNorm2d(cexp).eval(); eb.running_var.uniform_(0.5, 1.5); eb.running_mean.uniform_(-0.5, 0.5)
+    dc = torch.nn.Conv2d(cexp, cexp, 3, 2, 1, groups=cexp, bias=False)
+    db = torch.nn.BatchNorm2d(cexp).eval(); db.running_var.uniform_(0.5, 1.5); db.running_mean.uniform_(-0.5, 0.5)
+    ex, dw = bp._Pw(ec, eb, dev, act), bp._Dw(dc, db, dev, act)
+    blk = {"ex": ex, "dw": dw}
+    assert bp._exdw_ok(blk) and not bp._exdw_ok(dict(blk, se=1))
+    x = _bf(torch.randn(n, h, w, 16)).cuda()
+    e = bp.pwconv(x, ex)
+    two, _, _ = bp.dwconv(e, dw, False)
+    one = bp.expand_dw(x, ex, dw)
+    torch.cuda.synchronize()
+    assert one.shape == two.shape == (n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, bp._r16(cexp))
+    assert torch.equal(one.view(torch.int16), two.view(torch.int16))
+    assert float(one.float().abs().max()) > 0
+    # and against float64 arithmetic on the same bf16 operands
+    fa = (lambda t: F.relu(t)) if act == 1 else (lambda t: t * F.relu6(t + 3) / 6)
+    mid = fa(torch.einsum("nhwc,oc->nhwo", x.cpu().double(), ex.w.cpu().double()[:cexp, :16]) + ex.b.cpu().double()[:cexp]).to(torch.bfloat16).double()
+    wd = dw.w.cpu().double()[:, :cexp].t().reshape(cexp, 1, 3, 3)
+    ref = fa(F.conv2d(mid.permute(0, 3, 1, 2), wd, dw.b.cpu().double()[:cexp], 2, 1, groups=cexp)).permute(0, 2, 3, 1)
+    assert float(((one[..., :cexp].double().cpu() - ref).abs() / (ref.abs() + 1)).max()) <= 8e-3
+
+
 @pytest.mark.parametrize("hw", [(38, 64), (37, 62)])            # W % 4 == 0: two pixels per thread on 16-byte loads; otherwise one per thread
 def test_stem_kernel_both_forms(hw):
     import ctypes as C
