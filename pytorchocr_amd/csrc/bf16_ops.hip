@@ -841,16 +841,24 @@ __global__ __launch_bounds__(256) void dwconv_bf16_kernel(DwArgs p) {
                     const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wl + (a * K + b) * CB + ql * 8), w1 = *reinterpret_cast<const f32x4 *>(wl + (a * K + b) * CB + ql * 8 + 4);
                     wr[b][0] = f32x2{w0[0], w0[1]}; wr[b][1] = f32x2{w0[2], w0[3]}; wr[b][2] = f32x2{w1[0], w1[1]}; wr[b][3] = f32x2{w1[2], w1[3]};
                 }
+                // All the columns of the row are loaded before the first is used (clamped addresses, no branch: with a bounds check and
+                // `continue` per column every load sat in its own basic block and was waited for alone -- NC dependent round trips per
+                // row); a column outside the image is then zeroed, which adds +0 products where the first version skipped the taps.
                 const __bf16 *row = p.x + (((long)n * p.H + iy) * p.W) * p.C + q * 8;
+                const int off0 = (ox0 * S - PAD) * p.C, offmax = (p.W - 1) * p.C;
+                u32x4 dd[NC];
+#pragma unroll
+                for (int ci = 0; ci < NC; ci++) {
+#if DW_DBG & 2
+                    dd[ci] = u32x4{(unsigned)ci, (unsigned)iy, 0u, 0u};
+#else
+                    dd[ci] = *reinterpret_cast<const u32x4 *>(row + min(max(off0 + ci * p.C, 0), offmax));
+#endif
+                }
 #pragma unroll
                 for (int ci = 0; ci < NC; ci++) {
                     const int ix = ox0 * S - PAD + ci;
-                    if ((unsigned)ix >= (unsigned)p.W) continue;
-#if DW_DBG & 2
-                    const u32x4 d = {(unsigned)ix, (unsigned)iy, 0u, 0u};
-#else
-                    const u32x4 d = *reinterpret_cast<const u32x4 *>(row + (long)ix * p.C);
-#endif
+                    const u32x4 d = (unsigned)ix < (unsigned)p.W ? dd[ci] : u32x4{0u, 0u, 0u, 0u};
                     f32x2 v[4];
 #pragma unroll
                     for (int j = 0; j < 4; j++) v[j] = f32x2{__builtin_bit_cast(float, d[j] << 16), __builtin_bit_cast(float, d[j] & 0xffff0000u)};
@@ -1022,9 +1030,7 @@ __global__ __launch_bounds__(XD_THREADS) void expand_dw3x3s2_bf16_kernel(ExDwArg
             }
             const unsigned char *row = ex + ((ry * S + a) * PW) * EXS + ql * 16;
 #pragma unroll
-            for (int ci = 0; ci < NC; ci++) {
-                const int ix = (ox0 + rx0) * S - 1 + ci;
-                if ((unsigned)ix >= (unsigned)p.W) continue;
+            for (int ci = 0; ci < NC; ci++) {                   // a column outside the image is zero in the patch: dwconv_bf16_kernel adds the same +0 products
                 const u32x4 d = *reinterpret_cast<const u32x4 *>(row + (rx0 * S + ci) * EXS);
                 f32x2 v[4];
 #pragma unroll
@@ -1402,6 +1408,7 @@ extern "C" int ptocr_dwconv_bf16(const void *d_x, const float *d_w, const float 
                                  int C, int k, int stride, int act, void *stream) {
     PT_CHECK(d_x && d_w && d_bias && d_y && C % 8 == 0 && C <= 2048 && (k == 3 || k == 5) && (stride == 1 || stride == 2) && act >= 0 && act <= 2 && N <= 65535,
              "ptocr_dwconv_bf16: need C %% 8 == 0, k in {3,5}, stride in {1,2}");
+    PT_CHECK(N >= 1 && H >= 1 && W >= 1 && ((long)W + 16) * C < (1L << 31), "ptocr_dwconv_bf16: empty tensor, or a row wider than 2 Gi elements");
     const int pad = (k - 1) / 2;
     DwArgs p;
     p.x = (const __bf16 *)d_x; p.w = d_w; p.bias = d_bias; p.y = (__bf16 *)d_y; p.partial = d_partial; p.H = H; p.W = W; p.C = C; p.k = k;
