@@ -196,6 +196,13 @@ int ptocr_pwconv_bf16(const void *d_x, const void *d_w, const float *d_bias, con
 int ptocr_conv3x3_bf16(const void *d_x, const void *d_w, const float *d_bias, void *d_y, int N, int H, int W, int Cin, int cstore,
                        int act, int out_up, int out_ldc, int out_coff, void *stream);
 
+/* The DB head's first conv (reference det_db_head.py:10-12: Conv2d(in, in/4, 3, padding=1) + BN + ReLU) reading the FPN output
+ * (reference fpn.py:96-100: torch.cat([out5 .. out2], 1)) as FOUR planes bf16[4][N,H,W,24] instead of one [N,H,W,96] concat, so that each
+ * smoothing conv writes whole cache lines.  w bf16[32][9*96] / bias f32[32] as for ptocr_conv3x3_bf16 (channel order of the concat);
+ * y bf16[N,H,W,out_ldc], cstore channels written.  Bit-identical to ptocr_conv3x3_bf16 on the concatenated tensor. */
+int ptocr_conv3x3_planes_bf16(const void *d_x, const void *d_w, const float *d_bias, void *d_y, int N, int H, int W, int cstore, int act,
+                              int out_ldc, void *stream);
+
 /* The FPN lateral fused into the smoothing conv of the largest level (reference fpn.py:102-131: out2 = in2(c2) + upsample(out3), then
  * p2 = out2_conv(out2)): y = conv3x3(relu(bn(conv1x1(x2))) + nearest_x2(td)), the intermediate never written.
  * x2 bf16[N,H,W,16] (input channels padded to 16), wl bf16[96][16] + bl f32[96] (the lateral, BN folded), td bf16[N,H/2,W/2,td_ldc]

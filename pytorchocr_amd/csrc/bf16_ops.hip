@@ -389,24 +389,30 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_lds_kernel(C3Args p) {
 // eight-wave version 14.2 k (prefetch address arithmetic 1.35 k, MFMA phase 4.8 k, partial-sum exchange with 64-way bank conflicts
 // + an epilogue of 144 scalar branches around run-time activation codes and a bias load queued behind the prefetch 5.8 k, stores
 // 1.15 k, patch to LDS 0.8 k); now 9.6 k (0.8 / 4.8 / 2.0 / 0.65 / 0.5), 155 us.
-template <int NCS, int ACT>
+// PLANES (round 4): the input is FOUR tensors [N,H,W,Cin/4] one after the other (the FPN's concat kept as four planes: each smoothing
+// conv then writes whole cache lines -- a 48-byte slice of a 192-byte pixel of the concat buffer is a partial line for each of the four
+// writers) and the patch is gathered plane by plane: the same pieces land at the same LDS offsets, everything after the staging is shared.
+template <int NCS, int ACT, bool PLANES = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_bf16_pers8_kernel(C3Args p, int tiles_x, int tiles_per_img, int total) {
     constexpr int TH = 8, HC = NCS / 2;
     constexpr int NCH = 2 * NCS, STRIDE = 16 * NCH + 16;
-    constexpr int NPIECE = (TH + 2) * (C3_TW + 2) * NCH;
-    constexpr int NLD = (NPIECE + 511) / 512;
+    constexpr int NPL = PLANES ? 4 : 1, PCH = NCH / NPL;             // planes, 16-byte pieces of a pixel in one plane
+    static_assert(NCH % NPL == 0, "planes split the channels evenly");
+    constexpr int NPIECE = (TH + 2) * (C3_TW + 2) * PCH;             // pieces per plane
+    constexpr int NLD = (NPIECE + 511) / 512;                        // loads per thread and plane
     __shared__ __attribute__((aligned(16))) unsigned char patch[(TH + 2) * (C3_TW + 2) * STRIDE];
     static_assert(sizeof(patch) >= 4 * 64 * 32 * 4 + TH * C3_TW * 32 * 2, "patch buffer doubles as partial-sum + output staging");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int rw = wave & 3, half = wave >> 2;
-    bf16x8 pv[NLD];
+    bf16x8 pv[NPL][NLD];
     int n, ty0, tx0;
     auto decode = [&](int t) {
         n = t / tiles_per_img;
         const int rem = t - n * tiles_per_img;
         ty0 = (rem / tiles_x) * TH; tx0 = (rem % tiles_x) * C3_TW;
     };
+    const int pcin = p.Cin / NPL;                                    // channels of one plane
     // Tile-invariant part of the patch addressing, once per thread: piece k of this thread is pixel (py, px) of the patch, channels
     // 8 ch..  Per tile the loads go through a buffer descriptor of the IMAGE: rows above and below it fall outside the descriptor
     // and return zeros by themselves, columns left and right of it are sent out of range by hand -- four VALU instructions per piece
@@ -416,26 +422,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int k = 0; k < NLD; k++) {
         const int i = threadIdx.x + 512 * k;
-        const int pix = i / NCH, ch = i - pix * NCH;
+        const int pix = i / PCH, ch = i - pix * PCH;
         const int py = pix / (C3_TW + 2), px = pix - py * (C3_TW + 2);
-        pbyte[k] = (unsigned)(((py * p.W + px) * p.Cin + ch * 8) * 2);
+        pbyte[k] = (unsigned)(((py * p.W + px) * pcin + ch * 8) * 2);
         ppx[k] = i < NPIECE ? px : (1 << 20);                    // beyond any width: never loaded, never stored
         lds_off[k] = pix * STRIDE + ch * 16;
     }
-    const int img_bytes = p.H * p.W * p.Cin * 2;                 // < 2^31 (host check)
+    const int img_bytes = p.H * p.W * pcin * 2;                  // < 2^31 (host check)
+    const long plane_elems = p.M * pcin;                         // N * H * W * (channels of a plane)
     auto gload = [&]() {
-        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(p.x + (long)n * p.H * p.W * p.Cin), 0, img_bytes, 0x00020000);
-        const unsigned org = (unsigned)(((ty0 - 1) * p.W + (tx0 - 1)) * p.Cin * 2);      // negative for the first row / column: wraps out of range
+        const unsigned org = (unsigned)(((ty0 - 1) * p.W + (tx0 - 1)) * pcin * 2);       // negative for the first row / column: wraps out of range
 #pragma unroll
-        for (int k = 0; k < NLD; k++) {
-            const unsigned vo = (unsigned)(tx0 - 1 + ppx[k]) < (unsigned)p.W ? org + pbyte[k] : 0xffffffffu;
-            pv[k] = (C3_DBG & 1) ? zero8() : __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xr, vo, 0, 0));
+        for (int pl = 0; pl < NPL; pl++) {
+            const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(p.x + pl * plane_elems + (long)n * p.H * p.W * pcin), 0, img_bytes, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < NLD; k++) {
+                const unsigned vo = (unsigned)(tx0 - 1 + ppx[k]) < (unsigned)p.W ? org + pbyte[k] : 0xffffffffu;
+                pv[pl][k] = (C3_DBG & 1) ? zero8() : __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xr, vo, 0, 0));
+            }
         }
     };
     auto lstore = [&]() {
 #pragma unroll
-        for (int k = 0; k < NLD; k++)
-            if (ppx[k] < (1 << 20)) *reinterpret_cast<bf16x8 *>(patch + lds_off[k]) = pv[k];
+        for (int pl = 0; pl < NPL; pl++)
+#pragma unroll
+            for (int k = 0; k < NLD; k++)
+                if (ppx[k] < (1 << 20)) *reinterpret_cast<bf16x8 *>(patch + lds_off[k] + pl * PCH * 16) = pv[pl][k];
     };
     const __bf16 *wrow = p.w + (long)r * 9 * p.Cin + 8 * h + half * HC * 16;
     bf16x8 aw[9][HC];
@@ -774,12 +786,27 @@ struct DwArgs {
 // loaded once per kernel row and feed all four outputs (5x5 / s1: 40 loads per 4 outputs instead of 100), the weights and the bias
 // sit in LDS (the first version re-read them from global memory per tap: 75 loads per output pixel made the layer issue-bound at
 // 7x its HBM time).  A block owns whole output rows (p.chunk of them).
+#ifndef STEM_W_LDS
+#define STEM_W_LDS 0
+#endif
+#ifndef DW_R51
+#define DW_R51 4         // outputs per run: 5x5 stride 1, 5x5 stride 2, 3x3 stride 1, 3x3 stride 2
+#endif
+#ifndef DW_R52
+#define DW_R52 4
+#endif
+#ifndef DW_R31
+#define DW_R31 8
+#endif
+#ifndef DW_R32
+#define DW_R32 8
+#endif
 #ifndef DW_DBG
 #define DW_DBG 0            // timing experiments only: 1 no weight staging, 2 no global loads, 4 no stores
 #endif
 template <int K, int S, int ACT>
 __global__ __launch_bounds__(256) void dwconv_bf16_kernel(DwArgs p) {
-    constexpr int R = (S == 1 && K == 5) ? 8 : 4, NC = (R - 1) * S + K, PAD = (K - 1) / 2;       // 5x5 stride 1: runs of 8 outputs (12 loads per row for 8 outputs instead of 16; 3x3 loses with 8)
+    constexpr int R = (S == 1 && K == 5) ? DW_R51 : (S == 2 && K == 5) ? DW_R52 : (S == 1) ? DW_R31 : DW_R32, NC = (R - 1) * S + K, PAD = (K - 1) / 2;       // 5x5 stride 1: runs of 8 outputs (12 loads per row for 8 outputs instead of 16; 3x3 loses with 8)
     extern __shared__ __attribute__((aligned(16))) float dw_lds[];
     // A block owns p.ob channel octets (blockIdx.z picks the group): its slice of the weights is a few KB of LDS instead of (K*K+1)*C
     // floats, so that occupancy is set by registers -- the loads of a run are K dependent round trips and need many waves to hide.
@@ -1126,15 +1153,23 @@ __global__ __launch_bounds__(256) void stem3x3s2_bf16_kernel(const float *__rest
 template <int ACT>
 __global__ __launch_bounds__(512) void stem3x3s2_bf16_pair_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                                                                   __bf16 *__restrict__ y, int H, int W, int Ho, int Wo) {
+#if STEM_W_LDS
     __shared__ __attribute__((aligned(16))) float sw[27 * 16 + 16];
     for (int i = threadIdx.x; i < 27 * 16 + 16; i += blockDim.x) sw[i] = i < 27 * 16 ? w[i] : bias[i - 27 * 16];
     __syncthreads();
+    const float *wb = sw + 27 * 16;
+#else
+    // The weights are the same for every lane and every index below is a compile-time constant: read straight from the (read-only,
+    // wave-uniform) global arrays they become scalar loads and SGPR operands of the packed FMAs -- from LDS each of the 216 weight
+    // pairs was a broadcast ds_read per thread, as many LDS instructions as half the FMAs.
+    const float *sw = w, *wb = bias;
+#endif
     const long n = blockIdx.z;
     const int t = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y;       // (an XCD-aware row order was tried: no change, 178 us)
     if (2 * t >= Wo) return;
     f32x2 accA[8], accB[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) accA[j] = accB[j] = *reinterpret_cast<const f32x2 *>(sw + 27 * 16 + 2 * j);
+    for (int j = 0; j < 8; j++) accA[j] = accB[j] = *reinterpret_cast<const f32x2 *>(wb + 2 * j);
 #pragma unroll
     for (int c = 0; c < 3; c++)
 #pragma unroll
@@ -1330,6 +1365,32 @@ extern "C" int ptocr_pwconv_bf16(const void *d_x, const void *d_w, const float *
 #undef PT_PW4
 #undef PT_PW_G
     return launch_ok("pw_bf16_kernel");
+}
+
+// The head's 3x3 conv reading the FPN output as FOUR planes bf16[4][N,H,W,24] (conv3x3_bf16_pers8_kernel<6, ACT, true>): Cin = 96 in the
+// concat's channel order (plane, channel), y bf16[N,H,W,32] (cstore channels written, the rest of the 32 zero as in ptocr_conv3x3_bf16).
+extern "C" int ptocr_conv3x3_planes_bf16(const void *d_x, const void *d_w, const float *d_bias, void *d_y, int N, int H, int W, int cstore, int act,
+                                         int out_ldc, void *stream) {
+    PT_CHECK(d_x && d_w && d_bias && d_y && N >= 1 && H >= 1 && W >= 1, "ptocr_conv3x3_planes_bf16: null / empty argument");
+    PT_CHECK(cstore % 8 == 0 && cstore >= 8 && cstore <= 32 && act >= 0 && act <= 2 && out_ldc >= cstore && out_ldc % 8 == 0,
+             "ptocr_conv3x3_planes_bf16: need cstore %% 8 == 0, cstore <= 32 <= out_ldc");
+    C3Args p;
+    p.x = (const __bf16 *)d_x; p.w = (const __bf16 *)d_w; p.bias = d_bias; p.y = (__bf16 *)d_y; p.M = (long)N * H * W; p.H = H; p.W = W; p.Cin = 96;
+    p.cstore = cstore; p.act = act; p.out_up = 1; p.out_ldc = out_ldc; p.out_coff = 0;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        PT_HIP(hipGetDevice(&dev));
+        PT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const int tiles_x = cdiv(W, C3_TW), tpi = tiles_x * cdiv(H, 8);
+    const long total = (long)N * tpi;
+    PT_CHECK(total < (1L << 31) && (long)H * W * 96 * 2 < (1L << 31), "ptocr_conv3x3_planes_bf16: too many tiles / image larger than 2 GiB");
+    const int grid = total < (long)n_cu ? (int)total : n_cu;
+#define PT_C3P(A) hipLaunchKernelGGL((conv3x3_bf16_pers8_kernel<6, A, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p, tiles_x, tpi, (int)total)
+    PT_ACT_SWITCH(act, PT_C3P);
+#undef PT_C3P
+    return launch_ok("conv3x3_bf16_pers8_kernel<planes>");
 }
 
 extern "C" int ptocr_conv3x3_bf16(const void *d_x, const void *d_w, const float *d_bias, void *d_y, int N, int H, int W, int Cin, int cstore,

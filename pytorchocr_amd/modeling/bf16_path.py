@@ -142,6 +142,21 @@ def conv3x3(x, c3, out=None, up=1, coff=0, cstore=None):
     return out
 
 
+FUSE_PLANES = os.environ.get("PTOCR_BF16_FUSE_PLANES", "1") != "0"   # 0: the FPN output as one [N,H,W,96] concat buffer (rounds 2-3)
+
+
+def conv3x3_planes(planes, c3):
+    """the head's 3x3 conv on the FPN output kept as four planes bf16[4][N,H,W,24] (channel order of the concat)"""
+    k, n, h, w_, c = planes.shape
+    assert k == 4 and c == 24 and c3.cin == 96 and planes.is_contiguous()
+    cs = _r16(c3.cout)
+    out = torch.empty((n, h, w_, cs), dtype=torch.bfloat16, device=planes.device)
+    _lib.check(_lib.lib().ptocr_conv3x3_planes_bf16(_ptr(planes), _ptr(c3.w), _ptr(c3.b), _ptr(out), n, h, w_, cs, c3.act, cs, _lib.cur_stream()),
+               "ptocr_conv3x3_planes_bf16")
+    _count(planes, c3.w, out)
+    return out
+
+
 LAT_FUSE = os.environ.get("PTOCR_BF16_LAT_FUSE", "1") != "0"      # 0: lateral in2 and smoothing conv out2 as two launches (rounds 2-3)
 
 
@@ -286,21 +301,30 @@ class Mbv3DbBf16:
                     and self.lat["in2"].act == ops.ACT_RELU and c2.shape[1] % 2 == 0 and c2.shape[2] % 2 == 0)
         out2 = None if fuse_lat else pwconv(c2, self.lat["in2"], res=out3, res_mode=2)
         h4, w4 = c2.shape[1], c2.shape[2]
-        fuse = torch.empty((n, h4, w4, self.fuse_c), dtype=torch.bfloat16, device=x.device)
         sm = self.sm
-        conv3x3(in5, self.smooth["out5"], out=fuse, up=8, coff=0, cstore=sm)
-        conv3x3(out4, self.smooth["out4"], out=fuse, up=4, coff=sm, cstore=sm)
-        conv3x3(out3, self.smooth["out3"], out=fuse, up=2, coff=2 * sm, cstore=sm)
-        if fuse_lat:            # the largest lateral inside its smoothing conv: 0.7 GB less traffic per forward of 32 images
-            conv3x3_lat(c2, self.lat["in2"], out3, self.smooth["out2"], out=fuse, up=1, coff=3 * sm, cstore=sm)
+        # The concat of fpn.py:96-100 as four planes [4][N,H4,W4,24] when the head conv can gather them (its persistent kernel: 96 input
+        # channels): a smoothing conv then writes whole cache lines instead of 48-byte slices of 192-byte pixels.
+        planes = FUSE_PLANES and self.fuse_c == 96 and sm == 24 and self.head_c0.cin == 96
+        if planes:
+            fuse = torch.empty((4, n, h4, w4, sm), dtype=torch.bfloat16, device=x.device)
+            dst = [(fuse[k], 0) for k in range(4)]
         else:
-            conv3x3(out2, self.smooth["out2"], out=fuse, up=1, coff=3 * sm, cstore=sm)
-        hx = conv3x3(fuse, self.head_c0)                                   # [N, H4, W4, 32], channels 24..31 zero
+            fuse = torch.empty((n, h4, w4, self.fuse_c), dtype=torch.bfloat16, device=x.device)
+            dst = [(fuse, k * sm) for k in range(4)]
+        conv3x3(in5, self.smooth["out5"], out=dst[0][0], up=8, coff=dst[0][1], cstore=sm)
+        conv3x3(out4, self.smooth["out4"], out=dst[1][0], up=4, coff=dst[1][1], cstore=sm)
+        conv3x3(out3, self.smooth["out3"], out=dst[2][0], up=2, coff=dst[2][1], cstore=sm)
+        if fuse_lat:            # the largest lateral inside its smoothing conv: 0.7 GB less traffic per forward of 32 images
+            conv3x3_lat(c2, self.lat["in2"], out3, self.smooth["out2"], out=dst[3][0], up=1, coff=dst[3][1], cstore=sm)
+        else:
+            conv3x3(out2, self.smooth["out2"], out=dst[3][0], up=1, coff=dst[3][1], cstore=sm)
+        hx = conv3x3_planes(fuse, self.head_c0) if planes else conv3x3(fuse, self.head_c0)      # [N, H4, W4, 32], channels 24..31 zero
         maps = torch.empty((n, 1, 4 * h4, 4 * w4), dtype=torch.float32, device=x.device)
         _lib.check(_lib.lib().ptocr_db_head_tail_bf16(_ptr(hx), _ptr(self.t_w1), _ptr(self.t_b1), _ptr(self.t_w2), C.c_float(self.t_b2), _ptr(maps),
                                                       n, h4, w4, self.c4, hx.shape[3], _lib.cur_stream()), "ptocr_db_head_tail_bf16")
         _count(hx, maps)
         if want_feats:
             return {"backbone_out": [f.float().permute(0, 3, 1, 2)[:, :c].contiguous() for f, c in zip(feats, self.out_channels)],
-                    "neck_out": fuse.float().permute(0, 3, 1, 2)[:, :self.fuse_c].contiguous(), "maps": maps}
+                    "neck_out": (torch.cat(list(fuse), dim=3) if planes else fuse).float().permute(0, 3, 1, 2)[:, :self.fuse_c].contiguous(),
+                    "maps": maps}
         return {"maps": maps}

@@ -157,6 +157,25 @@ def test_lateral_fused_into_the_smoothing_conv_is_bit_identical(n, h, w):
     assert float(((one[..., 72:].double().cpu() - ref).abs() / (ref.abs() + 1)).max()) <= 8e-3
 
 
+@pytest.mark.parametrize("n,h,w", [(2, 16, 64), (3, 37, 75), (1, 184, 320), (2, 9, 5)])
+def test_head_conv_on_four_planes_is_bit_identical_to_the_concat(n, h, w):
+    """ptocr_conv3x3_planes_bf16 (round 4: the FPN output kept as four planes [4][N,H,W,24], gathered plane by plane into the patch of the
+    persistent 3x3 kernel) against ptocr_conv3x3_bf16 on torch.cat of the planes: the same patch in LDS, everything after it shared"""
+    from pytorchocr_amd.modeling import bf16_path as bp
+    torch.manual_seed(10 * h + w)
+    dev = torch.device("cuda:0")
+    conv = torch.nn.Conv2d(96, 24, 3, 1, 1, bias=False)
+    bn = torch.nn.BatchNorm2d(24).eval(); bn.running_var.uniform_(0.5, 1.5); bn.running_mean.uniform_(-0.2, 0.2)
+    c3 = bp._C3(conv, bn, dev, 1)
+    planes = _bf(torch.randn(4, n, h, w, 24)).cuda()
+    cat = torch.cat(list(planes), dim=3).contiguous()
+    one = bp.conv3x3_planes(planes, c3)
+    two = bp.conv3x3(cat, c3)
+    torch.cuda.synchronize()
+    assert one.shape == two.shape == (n, h, w, 32)
+    assert torch.equal(one.view(torch.int16), two.view(torch.int16)) and float(one.float().abs().max()) > 0
+
+
 @pytest.mark.parametrize("n,h,w,cexp,act", [(2, 16, 64, 72, 1), (3, 37, 75, 72, 1), (1, 184, 320, 72, 1), (2, 9, 5, 88, 2), (2, 24, 34, 40, 2),
                                             (1, 1, 1, 96, 1), (2, 8, 32, 16, 2)])
 def test_expansion_fused_into_the_depthwise_conv_is_bit_identical(n, h, w, cexp, act):
