@@ -1249,6 +1249,17 @@ __global__ __launch_bounds__(256) void head_tail_bf16_kernel(const __bf16 *__res
     }
 }
 
+#ifndef HT_FAST_SIGMOID
+#define HT_FAST_SIGMOID 1   // v_exp_f32 + v_rcp_f32 (about 2 ulp) instead of expf + a division: the sigmoids were a third of the kernel's instructions
+#endif
+__device__ __forceinline__ float ht_sigmoid(float v) {
+#if HT_FAST_SIGMOID
+    return __builtin_amdgcn_rcpf(1.f + __expf(-v));
+#else
+    return 1.f / (1.f + expf(-v));
+#endif
+}
+
 // The same tail on the matrix pipe: GEMM 1 (24 -> 4 x 24, per input pixel) as v_mfma_f32_32x32x16_bf16 with A = weights (rows = mid
 // channels, bf16, zero-padded 24 -> 32 in both directions; eight fragments per lane, loaded once), B = 32 pixels straight from global
 // memory; the lane then holds 16 mid channels of ONE pixel per (a, b) position, and the second contraction (24 -> 4 outputs) is
@@ -1270,59 +1281,74 @@ __global__ __launch_bounds__(256) void head_tail_bf16_mfma_kernel(const __bf16 *
                 const int ci = 16 * ks + 8 * h + j;
                 af[ab][ks][j] = (__bf16)((c < HT_C && ci < HT_C) ? w1[(ab * HT_C + ci) * HT_C + c] : 0.f);
             }
-    // this lane's mid channels: co = (i & 3) + 8 (i >> 2) + 4 h
-    float lb1[16], lw2[4][16];
+    // this lane's mid channels: co = (i & 3) + 8 (i >> 2) + 4 h; pairs (i, i + 1) and (q, q + 1) share packed fp32 instructions
+    f32x2 lb1[8], lw2[16][2];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const int co = (i & 3) + 8 * (i >> 2) + 4 * h;
-        lb1[i] = co < HT_C ? b1[co] : 0.f;
+        lb1[i >> 1][i & 1] = co < HT_C ? b1[co] : 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; q++) lw2[q][i] = co < HT_C ? w2[q * HT_C + co] : 0.f;
+        for (int q = 0; q < 4; q++) lw2[i][q >> 1][q & 1] = co < HT_C ? w2[q * HT_C + co] : 0.f;
     }
     const long nwave = (long)gridDim.x * 4, wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    for (long p0 = wid * 32; p0 < total; p0 += nwave * 32) {
+    auto load = [&](long p0, bf16x8 &q0, bf16x8 &q1) {
+        const long pix = p0 + c;
+        const __bf16 *xp = x + (pix < total ? pix : 0) * ldc;
+        q0 = *reinterpret_cast<const bf16x8 *>(xp + 8 * h);
+        q1 = zero8();
+        if (h == 0) q1 = *reinterpret_cast<const bf16x8 *>(xp + 16);        // channels 16..23; 24..31 (h = 1) are padding: zeros
+    };
+    long p0 = wid * 32;
+    if (p0 >= total) return;
+    bf16x8 bq0, bq1;
+    load(p0, bq0, bq1);
+    for (; p0 < total; p0 += nwave * 32) {
         const long pix = p0 + c;
         const bool live = pix < total;
-        const __bf16 *xp = x + (live ? pix : 0) * ldc;
-        bf16x8 bq0 = *reinterpret_cast<const bf16x8 *>(xp + 8 * h);
-        bf16x8 bq1 = zero8();
-        if (h == 0) bq1 = *reinterpret_cast<const bf16x8 *>(xp + 16);       // channels 16..23; 24..31 (h = 1) are padding: zeros
-        float o[4][4];
+        const bf16x8 cq0 = bq0, cq1 = bq1;
+        if (p0 + nwave * 32 < total) load(p0 + nwave * 32, bq0, bq1);       // the next 32 pixels travel while these are computed
+        f32x2 o[4][2];
 #pragma unroll
         for (int ab = 0; ab < 4; ab++) {
             f32x16 acc = (f32x16)(0.f);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ab][0], bq0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ab][1], bq1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ab][0], cq0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ab][1], cq1, acc, 0, 0, 0);
+            o[ab][0] = o[ab][1] = f32x2{0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < 4; q++) o[ab][q] = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const float mid = fmaxf(acc[i] + lb1[i], 0.f);
-#pragma unroll
-                for (int q = 0; q < 4; q++) o[ab][q] += mid * lw2[q][i];
+            for (int i = 0; i < 16; i += 2) {
+                const f32x2 s2 = f32x2{acc[i], acc[i + 1]} + lb1[i >> 1];
+                const float m0 = fmaxf(s2[0], 0.f), m1 = fmaxf(s2[1], 0.f);
+                o[ab][0] = __builtin_elementwise_fma(f32x2{m0, m0}, lw2[i][0], o[ab][0]);
+                o[ab][1] = __builtin_elementwise_fma(f32x2{m0, m0}, lw2[i][1], o[ab][1]);
+                o[ab][0] = __builtin_elementwise_fma(f32x2{m1, m1}, lw2[i + 1][0], o[ab][0]);
+                o[ab][1] = __builtin_elementwise_fma(f32x2{m1, m1}, lw2[i + 1][1], o[ab][1]);
             }
         }
+        // the two halves of the wave hold the two halves of the mid channels of the same pixel: lower lanes finish output rows 0-1
+        // (positions ab = 0, 1), upper lanes rows 2-3 (ab = 2, 3): eight values cross, each lane has eight sigmoids and two row stores
+        f32x2 mine[2][2];
 #pragma unroll
-        for (int ab = 0; ab < 4; ab++)
+        for (int k = 0; k < 2; k++)
 #pragma unroll
-            for (int q = 0; q < 4; q++) o[ab][q] += __shfl_xor(o[ab][q], 32);
-        if (live && h == 0) {
-            const int ox = (int)(pix % W);
-            const long t = pix / W;
-            const int oy = (int)(t % H);
-            const long n = t / H;
-            float *out = maps + ((n * 4 * H + 4 * oy) * (4L * W) + 4 * ox);
+            for (int qq = 0; qq < 2; qq++) {
+                const f32x2 keep = h ? o[2 + k][qq] : o[k][qq], send = h ? o[k][qq] : o[2 + k][qq];
+                mine[k][qq] = keep + f32x2{__shfl_xor(send[0], 32), __shfl_xor(send[1], 32)};
+            }
+        if (live) {
+            const unsigned upix = (unsigned)pix, t = upix / (unsigned)W;      // total < 2^31 (host check): 32-bit divisions, the 64-bit ones were ~300 instructions
+            const int ox = (int)(upix - t * (unsigned)W);
+            const unsigned n = t / (unsigned)H;
+            const int oy = (int)(t - n * (unsigned)H);
+            float *out = maps + (((long)n * 4 * H + 4 * oy + 2 * h) * (4L * W) + 4 * ox);
 #pragma unroll
-            for (int a = 0; a < 2; a++)
-#pragma unroll
-                for (int a2 = 0; a2 < 2; a2++) {
-                    f32x4 row;
-                    row[0] = 1.f / (1.f + expf(-(o[a * 2 + 0][a2 * 2 + 0] + b2)));
-                    row[1] = 1.f / (1.f + expf(-(o[a * 2 + 0][a2 * 2 + 1] + b2)));
-                    row[2] = 1.f / (1.f + expf(-(o[a * 2 + 1][a2 * 2 + 0] + b2)));
-                    row[3] = 1.f / (1.f + expf(-(o[a * 2 + 1][a2 * 2 + 1] + b2)));
-                    *reinterpret_cast<f32x4 *>(out + (long)(2 * a + a2) * (4L * W)) = row;
-                }
+            for (int a2 = 0; a2 < 2; a2++) {
+                f32x4 row;                                      // position b = 0 (mine[0]) then b = 1 (mine[1]), columns bb2 = 0, 1 of each
+                row[0] = ht_sigmoid(mine[0][a2][0] + b2);
+                row[1] = ht_sigmoid(mine[0][a2][1] + b2);
+                row[2] = ht_sigmoid(mine[1][a2][0] + b2);
+                row[3] = ht_sigmoid(mine[1][a2][1] + b2);
+                *reinterpret_cast<f32x4 *>(out + (long)a2 * (4L * W)) = row;
+            }
         }
     }
 }
@@ -1552,8 +1578,17 @@ extern "C" int ptocr_db_head_tail_bf16(const void *d_x, const float *d_w1, const
                            d_w2, b2, d_maps, H, W, ldc, total);
         return launch_ok("head_tail_bf16_kernel");
     }
+    PT_CHECK(total < (1L << 31), "ptocr_db_head_tail_bf16: too many pixels");
     const long groups = (total + 127) / 128;
-    const unsigned grid = (unsigned)(groups < 1024 ? groups : 1024);   // few, long-lived waves: the per-lane weight registers are set up once per wave
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        PT_HIP(hipGetDevice(&dev));
+        PT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    // few, long-lived waves (the per-lane weight registers are set up once per wave): three workgroups per CU is what the kernel's 150
+    // registers allow -- 1024 workgroups ran as one full round and a second one a third full
+    const unsigned grid = (unsigned)(groups < 3L * n_cu ? groups : 3L * n_cu);
     hipLaunchKernelGGL(head_tail_bf16_mfma_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)d_x, d_w1, d_b1, d_w2, b2, d_maps,
                        H, W, ldc, total);
     return launch_ok("head_tail_bf16_mfma_kernel");
