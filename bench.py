@@ -419,10 +419,13 @@ def run_det(args, rank, local, world, device):
     fwd_bytes = None
     if bf16 and rank == 0:                               # bytes one forward moves, counted by the launch wrappers (one untimed pass)
         from pytorchocr_amd.modeling import bf16_path
+        from pytorchocr_amd import _lib as _plib
         bf16_path.TRAFFIC = 0
+        calls0 = _plib.CALLS
         with torch.no_grad():
             model(x)
         fwd_bytes, bf16_path.TRAFFIC = bf16_path.TRAFFIC, None
+        fwd_launches = _plib.CALLS - calls0
         torch.cuda.synchronize()
         fwd_events = []
     ops.PROFILE = [] if rank == 0 else None
@@ -506,7 +509,9 @@ def run_det(args, rank, local, world, device):
                 "traffic": (_profile_json("mbv3s_bf16_traffic.json") or {}).get("hbm_bytes_per_forward"),
                 "traffic_source": "profiles/mbv3s_bf16_traffic.json (rocprofv3 --pmc passes of this command with --det-model mbv3s --dtype bf16): "
                                   "copied from the committed profile, NOT measured in this run",
-                "kernel": "whole bf16 forward (46 launches: stem, 1x1 MFMA convs, depthwise + SE pool, SE gate, 3x3 MFMA convs, head tail): "
+                "launches_per_forward": fwd_launches,
+                "kernel": "whole bf16 forward (stem, 1x1 MFMA convs, expansion + depthwise, depthwise + SE pool, SE gate, 3x3 MFMA convs with the lateral / four-plane "
+                          "gather inside, head tail): "
                           "bytes every launch reads + writes once (activations, weights; %.1f MB per forward of %d images) / median forward time "
                           "%.3f ms (HIP events on the launch stream, post-process of the previous batch overlapping)" % (fwd_bytes / 1e6, B, fms),
                 # fusing two launches removes their intermediate from `achieved`'s numerator as well as its time from the denominator: the

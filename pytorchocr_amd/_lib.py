@@ -59,7 +59,12 @@ def missing_exports():
     return [n for n in EXPORTS if not hasattr(L, n)]
 
 
+CALLS = 0           # entry points that returned through check(): one kernel launch each on the model paths (bench.py reports launches per forward)
+
+
 def check(rc, what=""):
+    global CALLS
+    CALLS += 1
     if rc != 0:
         raise RuntimeError("libptocr_hip %s failed: %s" % (what, lib().ptocr_last_error().decode()))
 

@@ -26,24 +26,33 @@ struct Pw64Args {
     long x_bytes;
 };
 
+// Round 4: TWO TEAMS of four waves per workgroup (two waves per SIMD), half a period apart.  With one wave per SIMD the MFMA loop of a
+// tile (16.4 k cycles) and its epilogue (32 sixteen-byte stores per lane, 1.93 GB per batch) took turns, on every CU at the same time:
+// the matrix pipe idle while the chip stored, HBM idle while it multiplied (857 us against an MFMA floor of 393).  Now team A multiplies
+// while team B stores and stages, then they swap -- the workgroup barrier is the phase clock, team 1 runs one barrier late.  A wave has
+// 256 registers at two per SIMD, so a tile is taken in PASSES of at most four 32-channel blocks (64 accumulator registers + 64 for the
+// top-down rows of the pass, requested when its MFMAs are issued and used one phase later; the next pixel tile is requested in the last
+// store phase of this one and waits in 32 registers).  Each team has ONE pixel tile in LDS, the weights are shared.
 template <int PW_K, int NMT>                    // input channels (32 or 64), Cout / 32
-__global__ __launch_bounds__(256, 1) void conv_pw64_kernel(Pw64Args p) {
+__global__ __launch_bounds__(512, 1) void conv_pw64_kernel(Pw64Args p) {
+    constexpr int NP = NMT > 4 ? 2 : 1, MTP = (NMT + NP - 1) / NP;           // passes per tile, channel blocks per pass (the last pass may have one fewer)
     constexpr int PW_RS = PW_K + 4;             // LDS row stride of the pixel tile (16-byte aligned rows)
     constexpr int QPP = PW_K / 4;               // 16-byte pieces per pixel
-    constexpr int NPC = PW_TM * QPP / 256;      // pieces per thread
+    constexpr int NPC = PW_TM * QPP / 256;      // pieces per thread of a team
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Wl = smem;                           // [64][Cout]
-    float *Xb = smem + PW_K * NMT * 32;         // [2][PW_TM][PW_RS]
+    float *Xb = smem + PW_K * NMT * 32;         // [2 teams][PW_TM][PW_RS]
     float *Bl = Xb + 2 * PW_TM * PW_RS;         // [Cout] bias
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x & 255, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int team = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.x_bytes, 0x00020000);
     constexpr int COUT = NMT * 32;
 
-    for (int i = tid; i < PW_K * COUT / 4; i += 256) reinterpret_cast<f32x4 *>(Wl)[i] = reinterpret_cast<const f32x4 *>(p.w)[i];
-    if (tid < COUT) Bl[tid] = p.bias[tid];
+    for (int i = threadIdx.x; i < PW_K * COUT / 4; i += 512) reinterpret_cast<f32x4 *>(Wl)[i] = reinterpret_cast<const f32x4 *>(p.w)[i];
+    if (threadIdx.x < COUT) Bl[threadIdx.x] = p.bias[threadIdx.x];
 
-    // tile loader: 128 pixels x QPP float4 pieces, NPC per thread; piece f = tid + 256 r -> pixel f / QPP, quad f % QPP
+    // tile loader: 128 pixels x QPP float4 pieces, NPC per thread of the team; piece f = tid + 256 r -> pixel f / QPP, quad f % QPP
     f32x4 xreg[NPC];
     auto gload = [&](int tile) {
 #pragma unroll
@@ -53,82 +62,93 @@ __global__ __launch_bounds__(256, 1) void conv_pw64_kernel(Pw64Args p) {
             xreg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (unsigned)(m * (PW_K * 4) + (f % QPP) * 16), 0, 0));
         }
     };
-    auto lstore = [&](int buf) {
+    float *Xt = Xb + team * PW_TM * PW_RS;
+    auto lstore = [&]() {
 #pragma unroll
         for (int r = 0; r < NPC; r++) {
             const int f = tid + 256 * r;
-            *reinterpret_cast<f32x4 *>(Xb + buf * PW_TM * PW_RS + (f / QPP) * PW_RS + (f % QPP) * 4) = xreg[r];
+            *reinterpret_cast<f32x4 *>(Xt + (f / QPP) * PW_RS + (f % QPP) * 4) = xreg[r];
         }
     };
 
     const int c = lane & 31, kh = lane >> 5;
     const float *wp = Wl + kh * COUT + c;                        // W[2s + kh][32 mt + c]
-    const int xoff = (32 * wave + c) * PW_RS + kh;               // X[32w + c][2s + kh]
+    const float *xp = Xt + (32 * wave + c) * PW_RS + kh;         // X[32w + c][2s + kh]
 
-    int tile = blockIdx.x;                                       // host launches gridDim.x <= ntiles
-    gload(tile);
-    lstore(0);
-    __syncthreads();
-    for (int it = 0;; it++) {
-        const int buf = it & 1;
-        const int next = tile + (int)gridDim.x;
-        const bool has_next = next < p.ntiles;
-        if (has_next) gload(next);                               // in flight during this tile's MFMAs
-
-        // the FPN top-down rows of this tile are requested before the MFMA loop, so that their latency hides behind it
-        // (issued one by one in the epilogue they cost 17 us per tile, twice the MFMA time)
-        const long m = (long)tile * PW_TM + 32 * wave + c;
-        const bool live = m < p.M;
-        f32x4 rres[NMT][4];
-        if (p.res_up2) {                                         // + nearest-upsampled coarser map, after the ReLU
-            const long mm = live ? m : 0;
-            const int hw = p.H * p.W;
-            const int n = (int)(mm / hw), rem = (int)(mm - (long)n * hw);
-            const int oy = rem / p.W, ox = rem - oy * p.W;
-            const float *rp = p.res + (((long)n * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) * COUT + 4 * kh;
+    f32x16 acc[MTP];
+    f32x4 rres[MTP][4];
+    auto multiply = [&](int tile, int pass) {
 #pragma unroll
-            for (int mt = 0; mt < NMT; mt++)
-#pragma unroll
-                for (int g = 0; g < 4; g++) rres[mt][g] = *reinterpret_cast<const f32x4 *>(rp + 32 * mt + 8 * g);
-        }
-        f32x16 acc[NMT];
-#pragma unroll
-        for (int a = 0; a < NMT; a++)
+        for (int a = 0; a < MTP; a++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][r] = 0.f;
-        const float *xp = Xb + buf * PW_TM * PW_RS + xoff;
+        const float *wq = wp + 32 * MTP * pass;
 #pragma unroll 4
         for (int s = 0; s < PW_K / 2; s++) {
             const float b = xp[2 * s];
 #pragma unroll
-            for (int mt = 0; mt < NMT; mt++)
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp[(2 * s) * COUT + 32 * mt], b, acc[mt], 0, 0, 0);
+            for (int mt = 0; mt < MTP; mt++)
+                if (MTP * pass + mt < NMT) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[(2 * s) * COUT + 32 * mt], b, acc[mt], 0, 0, 0);
         }
-
-        // epilogue: lane holds, for pixel m, output channels 32 mt + 8 g + 4 kh + {0..3}
-        if (live) {
-            float *yp = p.y + m * p.out_ldc + p.out_coff;
+        if (p.res_up2) {                                         // + nearest-upsampled coarser map, after the ReLU: used one phase later
+            const long m = (long)tile * PW_TM + 32 * wave + c;
+            const long mm = m < p.M ? m : 0;
+            const int hw = p.H * p.W;
+            const int n = (int)(mm / hw), rem = (int)(mm - (long)n * hw);
+            const int oy = rem / p.W, ox = rem - oy * p.W;
+            const float *rp = p.res + (((long)n * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) * COUT + 4 * kh + 32 * MTP * pass;
 #pragma unroll
-            for (int mt = 0; mt < NMT; mt++)
+            for (int mt = 0; mt < MTP; mt++)
 #pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const int co = 32 * mt + 8 * g + 4 * kh;
-                    f32x4 v = f32x4{acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]} +
-                              *reinterpret_cast<const f32x4 *>(Bl + co);
-                    if (p.relu == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                    if (p.relu == 2) {                                  // Hardswish: x * relu6(x + 3) / 6
+                for (int g = 0; g < 4; g++)
+                    if (MTP * pass + mt < NMT) rres[mt][g] = *reinterpret_cast<const f32x4 *>(rp + 32 * mt + 8 * g);
+        }
+    };
+    auto store_pass = [&](int tile, int pass) {                  // lane holds, for pixel m, output channels 32 mt + 8 g + 4 kh + {0..3} of the pass
+        const long m = (long)tile * PW_TM + 32 * wave + c;
+        if (m >= p.M) return;
+        float *yp = p.y + m * p.out_ldc + p.out_coff + 32 * MTP * pass;
+        const float *bl = Bl + 32 * MTP * pass;
 #pragma unroll
-                        for (int k = 0; k < 4; k++) v[k] = v[k] * fminf(fmaxf(v[k] + 3.f, 0.f), 6.f) * (1.f / 6.f);
-                    }
-                    if (p.res_up2) v += rres[mt][g];
-                    *reinterpret_cast<f32x4 *>(yp + co) = v;
+        for (int mt = 0; mt < MTP; mt++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                if (MTP * pass + mt >= NMT) continue;
+                const int co = 32 * mt + 8 * g + 4 * kh;
+                f32x4 v = f32x4{acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]} + *reinterpret_cast<const f32x4 *>(bl + co);
+                if (p.relu == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                if (p.relu == 2) {                                  // Hardswish: x * relu6(x + 3) / 6
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v[k] = v[k] * fminf(fmaxf(v[k] + 3.f, 0.f), 6.f) * (1.f / 6.f);
                 }
+                if (p.res_up2) v += rres[mt][g];
+                *reinterpret_cast<f32x4 *>(yp + co) = v;
+            }
+    };
+
+    // stream t = 2 * workgroup + team takes tiles t, t + 2 G, t + 4 G, ..; every wave of the workgroup passes the same number of barriers
+    // (2 per pass + 1: team 1 waits one phase at the start, team 0 at the end)
+    const int step = 2 * (int)gridDim.x;
+    const int iters = (p.ntiles + step - 1) / step;              // >= the tiles of either team
+    int tile = 2 * (int)blockIdx.x + team;
+    gload(tile);                                                 // beyond the last tile: zeros, never stored
+    lstore();
+    __syncthreads();
+    if (team == 1) __syncthreads();
+    for (int it = 0; it < iters; it++, tile += step) {
+        const int next = tile + step;
+        const bool have = tile < p.ntiles, has_next = next < p.ntiles;
+#pragma unroll
+        for (int pass = 0; pass < NP; pass++) {
+            if (have) multiply(tile, pass);
+            __syncthreads();                                     // (the other team's stores are issued)
+            if (pass == NP - 1 && has_next) gload(next);         // the tile in LDS is consumed; the next one travels behind this phase's stores
+            if (have) store_pass(tile, pass);
+            if (pass == NP - 1 && has_next) lstore();
+            __syncthreads();
         }
-        if (!has_next) break;
-        lstore(buf ^ 1);                                         // every wave finished reading buf^1 before the previous barrier
-        __syncthreads();
-        tile = next;
     }
+    if (team == 0) __syncthreads();
 }
 
 template <int PW_K, int NMT>
@@ -145,8 +165,8 @@ static int launch_pw64(const Pw64Args &a, hipStream_t stream) {
         PT_HIP(hipGetDevice(&dev));
         PT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     }
-    const int grid = a.ntiles < n_cu ? a.ntiles : n_cu;          // one persistent workgroup per CU
-    hipLaunchKernelGGL((conv_pw64_kernel<PW_K, NMT>), dim3((unsigned)grid), dim3(256), lds, stream, a);
+    const int grid = a.ntiles < 2 * n_cu ? (a.ntiles + 1) / 2 : n_cu;        // one persistent workgroup per CU, two tile streams (teams) in each
+    hipLaunchKernelGGL((conv_pw64_kernel<PW_K, NMT>), dim3((unsigned)grid), dim3(512), lds, stream, a);
     return launch_ok("conv_pw64_kernel");
 }
 
