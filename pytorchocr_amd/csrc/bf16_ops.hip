@@ -59,6 +59,9 @@ struct PwArgs {
     int out_ldc, out_coff, res_ldc;
 };
 
+#ifndef PW_DBG
+#define PW_DBG 0           // timing experiments only: 1 weight loads from one address, 2 pixel loads from one address, 4 no SE scaling
+#endif
 template <int NT, bool RES, int ACT, int GRP>
 __global__ __launch_bounds__(256) void pw_bf16_kernel(PwArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -94,12 +97,12 @@ __global__ __launch_bounds__(256) void pw_bf16_kernel(PwArgs p) {
     for (; ks + 4 <= nks; ks += 4) {
         bf16x8 b[4], a[NT][4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) b[u] = *reinterpret_cast<const bf16x8 *>(xrow + (ks + u) * 16);
+        for (int u = 0; u < 4; u++) b[u] = *reinterpret_cast<const bf16x8 *>(xrow + ((PW_DBG & 2) ? u : ks + u) * 16);
 #pragma unroll
         for (int t = 0; t < NT; t++)
 #pragma unroll
-            for (int u = 0; u < 4; u++) a[t][u] = *reinterpret_cast<const bf16x8 *>(wr[t] + (ks + u) * 16);
-        if (srow) {
+            for (int u = 0; u < 4; u++) a[t][u] = *reinterpret_cast<const bf16x8 *>(wr[t] + ((PW_DBG & 1) ? u : ks + u) * 16);
+        if (srow && !(PW_DBG & 4)) {
 #pragma unroll
             for (int u = 0; u < 4; u++) b[u] = scaled(b[u], ks + u);
         }
