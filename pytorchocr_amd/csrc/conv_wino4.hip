@@ -28,6 +28,9 @@
 #ifndef W4_RAW_SLOT
 #define W4_RAW_SLOT 0       // MFMA slot of a chunk at which the raw-patch refill (global loads / LDS stores of two pieces) is issued
 #endif
+#ifndef W4_RESPF
+#define W4_RESPF 1          // 1: the residual rows of an output pass are requested one pass ahead
+#endif
 #ifndef W4_DBG
 #define W4_DBG 0            // timing experiments only (PTOCR_EXTRA_HIPCC_FLAGS=-DW4_DBG=n): 1 no global stores, 2 no consumer, 4 no exchange writes,
                             // 8 no input transform, 16 no weight-fragment loads, 32 no raw refill, 64 no transform math (LDS traffic kept)
@@ -60,7 +63,7 @@ __device__ __forceinline__ f32x2 pk_hi_pm_clo(f32x2 c, f32x2 p) {
 constexpr int W4_VH = 80;                      // floats per (xi, k pair) block of V: 32 tiles x 2 channels + 16 (second pair 16 banks off)
 constexpr int W4_V = 36 * 2 * W4_VH;           // floats per V buffer
 constexpr int W4_PX = 17;                      // LDS pixel stride (floats) of the raw patch: 16 channels + 1
-constexpr int W4_EL = 68;                      // exchange tile row stride
+constexpr int W4_EL = 68;                      // exchange tile row stride (72, which puts the two halves of a writing wave on disjoint banks, measures the same: 13.3 k cycles)
 constexpr int W4_THREADS = 768;
 // raw buffer: room for every 16-byte piece the 768 threads store (pieces past the patch are never read), so that piece r of a
 // thread sits at a compile-time offset (192 pixels) behind its piece 0
@@ -324,6 +327,19 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args p) {
     const unsigned y_pix0 = (unsigned)((c_n * p.H + c_oy) * up) * y_row + (unsigned)(p.out_coff * 4);
     const unsigned r_row = (unsigned)(p.W * p.res_ldc * 4);
     const unsigned r_pix0 = (unsigned)(c_n * p.H + c_oy) * r_row;
+    // MODE 1: the residual rows of a pass are requested one pass ahead (pass 0's before the first partial tiles are written, pass p + 1's
+    // once pass p's stores are issued): requested at the top of the consumer section their round trip sat between the barrier and the
+    // first LDS read of every pass.
+    f32x4 rres[4];
+    auto res_gload = [&](int pass) {
+        const int odd = pass >> 1, nt = pass & 1;
+        const int ox = ox0 + 4 * c_tx + odd + 2 * c_bs, col = n0 + nt * 32 + cq * 4;
+        const unsigned ro = (c_on && col < p.cout_store && ox < p.W) ? r_pix0 + (unsigned)((ox * p.res_ldc + col) * 4) : oob;
+#pragma unroll
+        for (int a = 0; a < 4; a++)                              // rows below the image read as zeros (beyond the buffer) or a later image: not stored
+            rres[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ro + (ro == oob ? 0u : (unsigned)a * r_row), 0, 0));
+    };
+    if (MODE == 1 && W4_RESPF) res_gload(0);
 #pragma unroll
     for (int pass = 0; pass < 4; pass++) {
         const int odd = pass >> 1, nt = pass & 1;               // the pair of output columns (0, 2) or (1, 3); channel half
@@ -350,13 +366,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args p) {
             auto T = [&](int i) {
                 return *reinterpret_cast<const f32x4 *>(ep + (2 * i) * 32 * W4_EL) + *reinterpret_cast<const f32x4 *>(ep + (2 * i + 1) * 32 * W4_EL);
             };
-            f32x4 rres[4];
-            if (MODE == 1) {
-                const unsigned ro = r_pix0 + (unsigned)((ox * p.res_ldc + col) * 4);
-#pragma unroll
-                for (int a = 0; a < 4; a++)                      // rows below the image read as zeros (beyond the buffer) or a later image: not stored
-                    rres[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ro + (unsigned)a * r_row, 0, 0));
-            }
+            if (MODE == 1 && !W4_RESPF) res_gload(pass);
             const f32x4 bias4 = *reinterpret_cast<const f32x4 *>(p.bias + col);
             f32x4 yv[4];
             {
@@ -385,6 +395,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args p) {
                 }
             }
         }
+        if (MODE == 1 && W4_RESPF && pass < 3) res_gload(pass + 1);
         if (pass < 3) __syncthreads();
     }
     if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 3] = __builtin_readcyclecounter();
