@@ -340,6 +340,11 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args p) {
             rres[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ro + (ro == oob ? 0u : (unsigned)a * r_row), 0, 0));
     };
     if (MODE == 1 && W4_RESPF) res_gload(0);
+    // the bias of the two channel halves, requested here: as a global load at the top of every pass's consumer section its round trip
+    // (the consumer knock-out: 7 k of the epilogue's 13.3 k cycles) stood between the barrier and the stores four times per workgroup
+    f32x4 bias2[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) bias2[nt] = *reinterpret_cast<const f32x4 *>(p.bias + n0 + nt * 32 + cq * 4);     // Cout is a multiple of 64
 #pragma unroll
     for (int pass = 0; pass < 4; pass++) {
         const int odd = pass >> 1, nt = pass & 1;               // the pair of output columns (0, 2) or (1, 3); channel half
@@ -367,7 +372,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args p) {
                 return *reinterpret_cast<const f32x4 *>(ep + (2 * i) * 32 * W4_EL) + *reinterpret_cast<const f32x4 *>(ep + (2 * i + 1) * 32 * W4_EL);
             };
             if (MODE == 1 && !W4_RESPF) res_gload(pass);
-            const f32x4 bias4 = *reinterpret_cast<const f32x4 *>(p.bias + col);
+            const f32x4 bias4 = bias2[nt];
             f32x4 yv[4];
             {
                 const f32x4 t1 = T(1), t2 = T(2);

@@ -12,6 +12,7 @@ namespace ptocr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int HT_C = 64;                 // channels in and mid
 constexpr int HT_LD = HT_C + 4;          // LDS row stride (floats)
@@ -28,7 +29,7 @@ __global__ __launch_bounds__(256, 2) void db_head_tail_kernel(const float *__res
                                                               int ntiles, long x_bytes) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *ws = smem;                                        // [256 col][HT_LD]
-    float *w2s = ws + 256 * HT_LD;                           // [4][64]
+    float *w2s = ws + 256 * HT_LD;                           // [64][4]
     float *b1s = w2s + 4 * HT_C;                             // [256]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, (int)x_bytes, 0x00020000);
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(256, 2) void db_head_tail_kernel(const float *__res
         const int r = i >> 4, c4 = i & 15;
         *reinterpret_cast<f32x4 *>(&ws[r * HT_LD + c4 * 4]) = *reinterpret_cast<const f32x4 *>(w1 + (long)r * HT_C + c4 * 4);
     }
-    w2s[tid] = w2[tid];
+    w2s[(tid & 63) * 4 + (tid >> 6)] = w2[tid];               // [co][a'b']: the four weights of a mid channel are ONE 16-byte read
     b1s[tid] = b1[tid];
     const int j = lane & 31, h = lane >> 5;                  // pixel within the wave's 32, k half
     f32x4 xcur[8], xnext[8];                                 // B operand: pixel j, k = 8 kk + 4 h + t
@@ -89,16 +90,30 @@ __global__ __launch_bounds__(256, 2) void db_head_tail_kernel(const float *__res
                 }
             }
             // D[row = co][col = pixel j]: register r holds co = (r&3) + 8*(r>>2) + 4*h (+32 for tile 1)
+            // bias + ReLU + second contraction in packed fp32 (pairs of mid channels for the bias add, pairs of outputs for the FMAs); the
+            // four w2 of a channel and four consecutive b1 are one 16-byte LDS read each: 40 reads per group instead of 160 four-byte ones
+            // (round 4: this epilogue, ~350 VALU + 160 LDS instructions per group, was what kept the matrix pipe at 64 %)
+            f32x2 o01 = {0.f, 0.f}, o23 = {0.f, 0.f};
 #pragma unroll
-            for (int oo = 0; oo < 4; oo++) outv[bb][oo] = 0.f;
+            for (int rq = 0; rq < 4; rq++) {
+                const int cq0 = 8 * rq + 4 * h;                      // co of register 4 rq (tile 0); tile 1: + 32
+                const f32x4 bq0 = *reinterpret_cast<const f32x4 *>(b1s + g * 64 + cq0), bq1 = *reinterpret_cast<const f32x4 *>(b1s + g * 64 + 32 + cq0);
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int co0 = (r & 3) + 8 * (r >> 2) + 4 * h, co1 = co0 + 32;
-                const float m0 = fmaxf(acc0[r] + b1s[g * 64 + co0], 0.f);
-                const float m1 = fmaxf(acc1[r] + b1s[g * 64 + co1], 0.f);
+                for (int t = 0; t < 4; t += 2) {
+                    const f32x2 s0 = f32x2{acc0[4 * rq + t], acc0[4 * rq + t + 1]} + f32x2{bq0[t], bq0[t + 1]};
+                    const f32x2 s1 = f32x2{acc1[4 * rq + t], acc1[4 * rq + t + 1]} + f32x2{bq1[t], bq1[t + 1]};
 #pragma unroll
-                for (int oo = 0; oo < 4; oo++) outv[bb][oo] += m0 * w2s[oo * HT_C + co0] + m1 * w2s[oo * HT_C + co1];
+                    for (int u = 0; u < 2; u++) {
+                        const float m0 = fmaxf(s0[u], 0.f), m1 = fmaxf(s1[u], 0.f);
+                        const f32x4 wa = *reinterpret_cast<const f32x4 *>(w2s + (cq0 + t + u) * 4), wb = *reinterpret_cast<const f32x4 *>(w2s + (32 + cq0 + t + u) * 4);
+                        o01 = __builtin_elementwise_fma(f32x2{m0, m0}, f32x2{wa[0], wa[1]}, o01);
+                        o23 = __builtin_elementwise_fma(f32x2{m0, m0}, f32x2{wa[2], wa[3]}, o23);
+                        o01 = __builtin_elementwise_fma(f32x2{m1, m1}, f32x2{wb[0], wb[1]}, o01);
+                        o23 = __builtin_elementwise_fma(f32x2{m1, m1}, f32x2{wb[2], wb[3]}, o23);
+                    }
+                }
             }
+            outv[bb][0] = o01[0]; outv[bb][1] = o01[1]; outv[bb][2] = o23[0]; outv[bb][3] = o23[1];
             // the other half of the mid channels lives in lane ^ 32
 #pragma unroll
             for (int oo = 0; oo < 4; oo++) outv[bb][oo] += __shfl_xor(outv[bb][oo], 32);
