@@ -789,6 +789,12 @@ struct DwArgs {
 // loaded once per kernel row and feed all four outputs (5x5 / s1: 40 loads per 4 outputs instead of 100), the weights and the bias
 // sit in LDS (the first version re-read them from global memory per tap: 75 loads per output pixel made the layer issue-bound at
 // 7x its HBM time).  A block owns whole output rows (p.chunk of them).
+#ifndef STEM_DBG
+#define STEM_DBG 0         // timing experiments only: 1 every block reads image row 0, 2 no loads, 4 no stores
+#endif
+#ifndef STEM_ST_T
+#define STEM_ST_T 1        // 1: the stem's stores transposed through LDS (lane-contiguous kilobytes)
+#endif
 #ifndef STEM_W_LDS
 #define STEM_W_LDS 0
 #endif
@@ -1169,7 +1175,8 @@ __global__ __launch_bounds__(512) void stem3x3s2_bf16_pair_kernel(const float *_
 #endif
     const long n = blockIdx.z;
     const int t = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y;       // (an XCD-aware row order was tried: no change, 178 us)
-    if (2 * t >= Wo) return;
+    if (!STEM_ST_T && 2 * t >= Wo) return;                     // (with the transposed stores a thread past the row still takes part in its wave's exchange: its loads are clamped below)
+    const int tl = min(t, (W >> 2) - 1);                          // load column of a thread past the row: the last one (its outputs are never stored)
     f32x2 accA[8], accB[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) accA[j] = accB[j] = *reinterpret_cast<const f32x2 *>(wb + 2 * j);
@@ -1179,9 +1186,9 @@ __global__ __launch_bounds__(512) void stem3x3s2_bf16_pair_kernel(const float *_
         for (int ky = 0; ky < 3; ky++) {
             const int iy = 2 * oy - 1 + ky;
             if ((unsigned)iy >= (unsigned)H) continue;            // block-uniform
-            const float *row = x + ((n * 3 + c) * H + iy) * (long)W;
-            const f32x4 q = *reinterpret_cast<const f32x4 *>(row + 4 * t);
-            const float left = t > 0 ? row[4 * t - 1] : 0.f;
+            const float *row = x + ((n * 3 + c) * H + ((STEM_DBG & 1) ? 0 : iy)) * (long)W;
+            const f32x4 q = (STEM_DBG & 2) ? f32x4{(float)t, (float)iy, 1.f, 2.f} : *reinterpret_cast<const f32x4 *>(row + 4 * tl);
+            const float left = (STEM_DBG & 2) ? 3.f : tl > 0 ? row[4 * tl - 1] : 0.f;
             const f32x2 *wr = reinterpret_cast<const f32x2 *>(sw + ((c * 3 + ky) * 3) * 16);
             const float va[3] = {left, q[0], q[1]}, vb[3] = {q[1], q[2], q[3]};
 #pragma unroll
@@ -1200,9 +1207,33 @@ __global__ __launch_bounds__(512) void stem3x3s2_bf16_pair_kernel(const float *_
         o[0][j] = (__bf16)actc<ACT>(accA[j >> 1][j & 1]); o[1][j] = (__bf16)actc<ACT>(accA[4 + (j >> 1)][j & 1]);
         o[2][j] = (__bf16)actc<ACT>(accB[j >> 1][j & 1]); o[3][j] = (__bf16)actc<ACT>(accB[4 + (j >> 1)][j & 1]);
     }
+    if ((STEM_DBG & 4) && o[0][0] != (__bf16)123.f) return;
+#if STEM_ST_T
+    // A thread's two pixels are 64 contiguous bytes and a wave's 128 pixels 4 KB, but stored thread by thread every instruction touched all
+    // 32 lines of the 4 KB with 16 bytes per lane pair (the no-store knock-out: 58 of the kernel's 160 us).  Through LDS the pieces are
+    // transposed so that instruction k writes the k-th KILOBYTE of the wave, lane by lane contiguous.
+    __shared__ __attribute__((aligned(16))) bf16x8 stg[8][4 * 64 + 4];       // per wave: piece 4 lane + k (padding: the transposed reads of a quarter wave on distinct banks)
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 4; k++) stg[wv][4 * lane + k] = o[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int t_w0 = blockIdx.x * blockDim.x + wv * 64;                   // first thread of the wave
+        bf16x8 *wdst = reinterpret_cast<bf16x8 *>(y + ((n * Ho + oy) * Wo + 2 * t_w0) * 16);
+        const int npiece = min(4 * 64, (Wo - 2 * t_w0) * 2);                  // pieces of this wave inside the row (Wo even)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int pc = 64 * k + lane;
+            if (pc < npiece) wdst[pc] = stg[wv][pc];
+        }
+    }
+#else
     bf16x8 *dst = reinterpret_cast<bf16x8 *>(y + ((n * Ho + oy) * Wo + 2 * t) * 16);
 #pragma unroll
     for (int k = 0; k < 4; k++) dst[k] = o[k];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------- DB head tail
