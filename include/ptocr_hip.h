@@ -90,6 +90,12 @@ int ptocr_conv3x3_wino4_f32(const float *d_x, const float *d_u, const float *d_b
                             int N, int H, int W, int Cin, int Cout, int cout_store, int relu, int res_mode, int res_ldc,
                             int out_ldc, int out_coff, int up, void *stream);
 long ptocr_conv3x3_wino4_patches(int N, int H, int W);
+/* CRNN conv1 + relu1 + pooling1 (reference rec_vgg.py:28-35: Conv2d 3x3 + ReLU, MaxPool2d(2, 2)) in one launch: the Winograd F(4x4) kernel's
+ * epilogue takes the 2x2 maxima of each 4x4 output tile; the full-resolution tensor is never written.  d_u as for ptocr_conv3x3_wino4_f32;
+ * y f32[N, H/2, W/2, out_ldc] (cout_store channels written); H and W even.  Bit-identical to the conv followed by ptocr_maxpool2d_f32. */
+int ptocr_conv3x3_wino4_pool2_f32(const float *d_x, const float *d_u, const float *d_bias, float *d_y, int N, int H, int W, int Cin,
+                                  int Cout, int cout_store, int out_ldc, void *stream);
+
 /* Experiment, not the fp32 path (the host enables it with PTOCR_WINO_SPLIT=1; off by default): ptocr_conv3x3_wino4_f32 with
  * two-piece bf16 operands on the bf16 matrix pipe, fp32 accumulate -- x = h + m, h = bf16(x), m = bf16(x - h); a b becomes
  * (a_h + a_m)(b_h + b_m), 16 mantissa bits per operand.  d_u: the packing above with every fp32 U replaced by the dword

@@ -76,12 +76,17 @@ struct Wino4Args {
     int tiles_x, tiles_y;                      // patches per image group
     int relu, res_mode, out_ldc, out_coff, res_ldc, up;
     int cout_store;
+    int pool;                                  // MODE 3: ReLU + MaxPool2d(2, 2) in the epilogue, y is [N, H/2, W/2, ldc]
     int total;
     long x_bytes, u_bytes, y_bytes, res_bytes;
     unsigned long long *dbg;
 };
 
-// MODE: 0 plain, 1 pre-ReLU residual add, 2 nearest-upsample replication (compile-time: the epilogue stays free of dead code)
+// MODE: 0 plain, 1 pre-ReLU residual add, 2 nearest-upsample replication, 3 ReLU + MaxPool2d(2, 2) (compile-time: the epilogue stays
+// free of dead code).  MODE 3 (round 4, CRNN conv1 + pooling1, rec_vgg.py:33-35): a 4x4 output tile holds 2x2 whole pool windows (tile
+// origins are multiples of four, H and W even), and a consumer thread's columns of the two passes of a channel half -- 2 c_bs and
+// 2 c_bs + 1 -- are one window's: the passes run (even, odd) columns per channel half, the even pass parks its four rows in registers,
+// the odd pass takes the maxima and stores two pooled rows.  The full-resolution tensor (671 MB for 512 lines) is never written.
 // SPLIT (experiment, ptocr_conv3x3_wino4_split_f32): the 36 GEMMs on the bf16 matrix pipe with two-piece operands.  x = h + m,
 // h = bf16(x), m = bf16(x - h) (16 mantissa bits in all); a product a b becomes a_h (b_h + b_m) + a_m (b_h + b_m), fp32 accumulate:
 // two v_mfma_f32_32x32x8_bf16_1k (32 cycles each) per 4-channel chunk and accumulator tile instead of two v_mfma_f32_32x32x2_f32
@@ -323,8 +328,10 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args p) {
     const bool c_on = tid < 512 && c_tile < NTV && c_n < p.N;
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.y_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.res), 0, (int)p.res_bytes, 0x00020000);
-    const unsigned y_row = (unsigned)(p.W * up * p.out_ldc * 4);                  // bytes per output row
-    const unsigned y_pix0 = (unsigned)((c_n * p.H + c_oy) * up) * y_row + (unsigned)(p.out_coff * 4);
+    const unsigned y_row = MODE == 3 ? (unsigned)((p.W >> 1) * p.out_ldc * 4) : (unsigned)(p.W * up * p.out_ldc * 4);                  // bytes per output row
+    const unsigned y_pix0 = MODE == 3 ? (unsigned)(c_n * (p.H >> 1) + (c_oy >> 1)) * y_row + (unsigned)(p.out_coff * 4)
+                                      : (unsigned)((c_n * p.H + c_oy) * up) * y_row + (unsigned)(p.out_coff * 4);
+    f32x4 hold[4];                                              // MODE 3: the even column's four rows, kept for the odd pass
     const unsigned r_row = (unsigned)(p.W * p.res_ldc * 4);
     const unsigned r_pix0 = (unsigned)(c_n * p.H + c_oy) * r_row;
     // MODE 1: the residual rows of a pass are requested one pass ahead (pass 0's before the first partial tiles are written, pass p + 1's
@@ -347,7 +354,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args p) {
     for (int nt = 0; nt < 2; nt++) bias2[nt] = *reinterpret_cast<const f32x4 *>(p.bias + n0 + nt * 32 + cq * 4);     // Cout is a multiple of 64
 #pragma unroll
     for (int pass = 0; pass < 4; pass++) {
-        const int odd = pass >> 1, nt = pass & 1;               // the pair of output columns (0, 2) or (1, 3); channel half
+        const int odd = MODE == 3 ? (pass & 1) : (pass >> 1), nt = MODE == 3 ? (pass >> 1) : (pass & 1);     // the pair of output columns (0, 2) or (1, 3); channel half
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const float a0 = acc[0][nt][r], a1 = acc[1][nt][r], a2 = acc[2][nt][r];
@@ -382,9 +389,32 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args p) {
                 const f32x4 s34 = t3 + t4, d34 = t3 - t4;
                 yv[0] += s34; yv[1] += 2.f * d34; yv[2] += 4.f * s34; yv[3] += 8.f * d34;
             }
+            if (MODE == 3) {
+                f32x4 v[4];
+#pragma unroll
+                for (int a = 0; a < 4; a++) {
+                    v[a] = yv[a] + bias4;
+                    v[a][0] = fmaxf(v[a][0], 0.f); v[a][1] = fmaxf(v[a][1], 0.f); v[a][2] = fmaxf(v[a][2], 0.f); v[a][3] = fmaxf(v[a][3], 0.f);
+                }
+                if (odd == 0) {
+#pragma unroll
+                    for (int a = 0; a < 4; a++) hold[a] = v[a];
+                } else {
+                    const unsigned po = y_pix0 + (unsigned)(((ox >> 1) * p.out_ldc + col) * 4);
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; h2++) {             // pooled rows (c_oy >> 1) + h2: rows 2 h2, 2 h2 + 1 of the tile (both inside the map or both below it: H is even)
+                        f32x4 m;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) m[k] = fmaxf(fmaxf(hold[2 * h2][k], hold[2 * h2 + 1][k]), fmaxf(v[2 * h2][k], v[2 * h2 + 1][k]));
+                        if ((W4_DBG & 1) && m[0] != 123.456f) continue;
+                        const unsigned rowo = c_oy + 2 * h2 < p.H ? po + (unsigned)h2 * y_row : oob;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, m), yr, rowo, 0, 0);
+                    }
+                }
+            }
             const unsigned yo = y_pix0 + (unsigned)((ox * up * p.out_ldc + col) * 4);
 #pragma unroll
-            for (int a = 0; a < 4; a++) {
+            for (int a = 0; a < 4 && MODE != 3; a++) {
                 f32x4 v = yv[a] + bias4;
                 if (MODE == 1) v += rres[a];
                 if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
@@ -430,6 +460,7 @@ static int launch_wino4(const Wino4Args &a, hipStream_t stream, bool split) {
         if (a.up > 1) return launch_wino4m<TXN, TYN, TN, 2, true>(a, stream);
         return launch_wino4m<TXN, TYN, TN, 0, true>(a, stream);
     }
+    if (a.pool) return launch_wino4m<TXN, TYN, TN, 3, false>(a, stream);
     if (a.res_mode == PTOCR_RES_ADD_PRE_RELU) return launch_wino4m<TXN, TYN, TN, 1, false>(a, stream);
     if (a.up > 1) return launch_wino4m<TXN, TYN, TN, 2, false>(a, stream);
     return launch_wino4m<TXN, TYN, TN, 0, false>(a, stream);
@@ -465,7 +496,7 @@ extern "C" long ptocr_conv3x3_wino4_patches(int N, int H, int W) { return wino4_
 // Everything else as ptocr_conv3x3_wino_f32.
 static int wino4_run(bool split, const float *d_x, const float *d_u, const float *d_bias, const float *d_res, float *d_y,
                      int N, int H, int W, int Cin, int Cout, int cout_store, int relu, int res_mode, int res_ldc,
-                     int out_ldc, int out_coff, int up, void *stream) {
+                     int out_ldc, int out_coff, int up, void *stream, int pool = 0) {
     PT_CHECK(d_x && d_u && d_bias && d_y, "ptocr_conv3x3_wino4_f32: null argument");
     PT_CHECK(N > 0 && H > 0 && W > 0, "ptocr_conv3x3_wino4_f32: empty tensor");
     PT_CHECK(Cin % 16 == 0 && Cout % 64 == 0, "ptocr_conv3x3_wino4_f32: need Cin %% 16 == 0 and Cout %% 64 == 0");
@@ -479,11 +510,13 @@ static int wino4_run(bool split, const float *d_x, const float *d_u, const float
     a.x = d_x; a.u = d_u; a.bias = d_bias; a.res = d_res; a.y = d_y;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.relu = relu; a.res_mode = res_mode; a.out_ldc = out_ldc; a.out_coff = out_coff; a.res_ldc = res_ldc > 0 ? res_ldc : Cout;
-    a.up = up; a.cout_store = cout_store;
+    a.up = up; a.cout_store = cout_store; a.pool = pool;
+    PT_CHECK(!pool || (!split && relu == 1 && res_mode == PTOCR_RES_NONE && up == 1 && H % 2 == 0 && W % 2 == 0),
+             "ptocr_conv3x3_wino4_pool2_f32: the fused pool needs ReLU, no residual, no upsample and even H, W");
     a.dbg = g_wino4_dbg;
     a.x_bytes = (long)N * H * W * Cin * 4;
     a.u_bytes = (long)Cout * Cin * 36 * 4;
-    a.y_bytes = (long)N * H * up * W * up * out_ldc * 4;
+    a.y_bytes = pool ? (long)N * (H / 2) * (W / 2) * out_ldc * 4 : (long)N * H * up * W * up * out_ldc * 4;
     a.res_bytes = res_mode ? (long)N * H * W * a.res_ldc * 4 : 0;
     PT_CHECK(a.x_bytes < (1L << 31) && a.u_bytes < (1L << 31) && a.y_bytes < (1L << 31) && a.res_bytes < (1L << 31),
              "ptocr_conv3x3_wino4_f32: tensor larger than 2 GiB");
@@ -502,6 +535,13 @@ extern "C" int ptocr_conv3x3_wino4_f32(const float *d_x, const float *d_u, const
                                        int N, int H, int W, int Cin, int Cout, int cout_store, int relu, int res_mode, int res_ldc,
                                        int out_ldc, int out_coff, int up, void *stream) {
     return wino4_run(false, d_x, d_u, d_bias, d_res, d_y, N, H, W, Cin, Cout, cout_store, relu, res_mode, res_ldc, out_ldc, out_coff, up, stream);
+}
+
+// 3x3 / stride 1 / pad 1 conv + folded BN + ReLU + MaxPool2d(2, 2) in one launch (conv_wino4_kernel MODE 3): y f32[N, H/2, W/2, out_ldc],
+// cout_store channels written; H and W even.  Bit-identical to ptocr_conv3x3_wino4_f32 followed by ptocr_maxpool2d_f32 (max is exact).
+extern "C" int ptocr_conv3x3_wino4_pool2_f32(const float *d_x, const float *d_u, const float *d_bias, float *d_y, int N, int H, int W, int Cin,
+                                             int Cout, int cout_store, int out_ldc, void *stream) {
+    return wino4_run(false, d_x, d_u, d_bias, nullptr, d_y, N, H, W, Cin, Cout, cout_store, 1, PTOCR_RES_NONE, 0, out_ldc, 0, 1, stream, 1);
 }
 
 // Experiment (PTOCR_WINO_SPLIT=1 on the host side, off by default): the same convolution with two-piece bf16 operands on the bf16

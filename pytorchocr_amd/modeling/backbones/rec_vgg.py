@@ -86,7 +86,7 @@ class VGG(ops.PackedModule):
                     x = ops.maxpool2d(x, (2, 2), (2, 1), (0, 1))
             return x
         x = ops.conv3x3_relu_pool2(x4, p[0])                                   # conv0 + relu0 + pooling0, fused
-        x = ops.conv2d(x, p[1]); x = ops.maxpool2d(x, 2, 2, 0)
+        x = ops.conv2d_relu_pool2(x, p[1])                                     # conv1 + relu1 + pooling1, fused when the layer runs on the F(4x4) kernel
         x = ops.conv2d(x, p[2])
         x = ops.conv2d(x, p[3]); x = ops.maxpool2d(x, (2, 2), (2, 1), (0, 1))
         x = ops.conv2d(x, p[4])

@@ -402,6 +402,34 @@ def stem_relu_pool(x4, x_nchw, pc):
     return out
 
 
+CONV_POOL_FUSE = _os.environ.get("PTOCR_CONV_POOL_FUSE", "1") != "0"      # 0: conv + ReLU and MaxPool2d(2, 2) as two launches
+
+
+def conv2d_relu_pool2(x, pc):
+    """3x3 / s1 / p1 conv + ReLU + MaxPool2d(2, 2) (CRNN conv1 + pooling1, rec_vgg.py:28-35): one launch when the layer runs on the F(4x4)
+    Winograd kernel (its epilogue takes the maxima of the 2x2 windows inside each 4x4 output tile), conv2d + maxpool2d otherwise"""
+    _require_cuda(x, "conv2d_relu_pool2")
+    N, H, W, Cin = x.shape
+    fused = (CONV_POOL_FUSE and USE_WINOGRAD and getattr(pc, "wino4_u", None) is not None and getattr(pc, "wino4_us", None) is None and pc.relu
+             and pc.kh == 3 and pc.kw == 3 and pc.stride == 1 and pc.pad_h == 1 and pc.pad_w == 1 and not pc.convt
+             and H % 2 == 0 and W % 2 == 0 and pc.c_tensor % 4 == 0 and pc.c_tensor <= pc.wino_cout
+             and _wino4_wins(H, W, Cin) and N * H * W * max(Cin, pc.c_tensor) * 4 < 2 ** 31)
+    if not fused:
+        return maxpool2d(conv2d(x, pc), 2, 2, 0)
+    out = torch.empty((N, H // 2, W // 2, pc.c_tensor), dtype=torch.float32, device=x.device)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(_lib.lib().ptocr_conv3x3_wino4_pool2_f32(_lib.ptr(x), _lib.ptr(pc.wino4_u), _lib.ptr(pc.wino_b), _lib.ptr(out), N, H, W, Cin,
+                                                        pc.wino_cout, pc.c_tensor, out.shape[3], _lib.cur_stream()), "ptocr_conv3x3_wino4_pool2_f32")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((e0, e1))
+        if PROFILE_LABELS is not None:
+            PROFILE_LABELS.append("wino43x3 %dx%dx%dx%d->%d pool2" % (N, H, W, Cin, pc.cout_real))
+    return out
+
+
 def maxpool2d(x, k, s, p):
     _require_cuda(x, "maxpool2d")
     kh, kw = (k, k) if isinstance(k, int) else k

@@ -310,6 +310,43 @@ def test_winograd_3x3_matches_torch(case, mode, monkeypatch):
     assert float((big[..., :64] - 3).abs().max()) == 0
 
 
+@pytest.mark.parametrize("case", [(8, 64, 16, 160, 128), (2, 64, 20, 36, 64), (5, 32, 150, 170, 64), (6, 64, 8, 48, 64), (7, 32, 4, 40, 64), (3, 32, 6, 22, 128),
+                                  (1, 32, 32, 16, 64), (9, 32, 8, 16, 64), (6, 16, 4, 82, 128), (3, 64, 46, 80, 64), (2, 48, 2, 2, 64)])
+def test_winograd_with_fused_relu_and_2x2_pool(case, monkeypatch):
+    """ptocr_conv3x3_wino4_pool2_f32 (round 4: MaxPool2d(2, 2) taken inside the F(4x4) kernel's epilogue -- CRNN conv1 + pooling1) against
+    the two launches it replaces: max is exact, so the pooled tensor must be IDENTICAL to maxpool2d(conv2d(x)) -- every patch geometry,
+    maps with partial patches on both edges, the CRNN's own shape; and against torch within the Winograd tolerance"""
+    from pytorchocr_amd.modeling import ops
+    monkeypatch.setattr(ops, "WINO4_MODE", "1")
+    N, Cin, H, W, Cout = case
+    dev = _dev()
+    conv = nn.Conv2d(Cin, Cout, 3, 1, 1, bias=False)
+    bn = nn.BatchNorm2d(Cout).eval()
+    with torch.no_grad():
+        conv.weight.copy_(_rand(Cout, Cin, 3, 3, seed=11) * (3.0 / (Cin * 9)) ** 0.5)
+        bn.weight.copy_(_rand(Cout, seed=13) * 0.4 + 1); bn.bias.copy_(_rand(Cout, seed=14) * 0.2)
+        bn.running_mean.copy_(_rand(Cout, seed=15) * 0.2); bn.running_var.copy_(_rand(Cout, seed=16) * 0.5 + 1)
+    x = _rand(N, Cin, H, W, seed=17)
+    pc = ops.PackedConv(conv, bn, dev, relu=True, cin_pad=Cin)
+    xd = _nhwc(x).to(dev)
+    monkeypatch.setattr(ops, "PROFILE", [])
+    monkeypatch.setattr(ops, "PROFILE_LABELS", [])
+    one = ops.conv2d_relu_pool2(xd, pc)
+    assert len(ops.PROFILE_LABELS) == 1 and ops.PROFILE_LABELS[0].endswith("pool2")          # one launch, the fused one
+    monkeypatch.setattr(ops, "CONV_POOL_FUSE", False)
+    two = ops.conv2d_relu_pool2(xd, pc)
+    torch.cuda.synchronize()
+    assert one.shape == two.shape == (N, H // 2, W // 2, Cout) and torch.equal(one, two)
+    with torch.no_grad():
+        ref = F.max_pool2d(F.relu(bn(conv(x))), 2, 2)
+    assert (one.cpu().permute(0, 3, 1, 2) - ref).abs().max().item() <= 3e-5 * max(1.0, ref.abs().max().item())
+    # odd sizes fall back to the two launches
+    monkeypatch.setattr(ops, "CONV_POOL_FUSE", True)
+    xo = _nhwc(_rand(1, Cin, 5, 7, seed=18)).to(dev)
+    yo = ops.conv2d_relu_pool2(xo, pc)
+    assert yo.shape == (1, 2, 3, Cout) and torch.equal(yo, ops.maxpool2d(ops.conv2d(xo, pc), 2, 2, 0))
+
+
 @pytest.mark.parametrize("case", [(2, 20, 36, 256), (1, 7, 9, 96), (3, 46, 80, 32), (1, 184, 320, 256),
                                   (2, 20, 36, 256, 128), (1, 7, 9, 128, 128), (3, 92, 160, 256, 128), (40, 2, 6, 128, 128)])
 def test_pointwise_k64_kernel(case):
