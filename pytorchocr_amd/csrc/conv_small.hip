@@ -64,6 +64,82 @@ __global__ __launch_bounds__(256) void conv3x3_small_pool_kernel(const float *__
     *reinterpret_cast<f32x4 *>(y + (((long)n * Hp + py) * Wp + px) * 64 + cq * 4) = m;
 }
 
+// Round 4: SIXTEEN channels per thread (four threads per pooled pixel instead of sixteen) and the multiply / add pairs as packed fp32
+// instructions on channel pairs.  The first form was bound by instruction issue: sixteen threads each loaded the same 4x4 input patch
+// (sixteen 16-byte loads per thread) and spent 288 scalar v_mul / v_add on their four channels -- 301 us for the CRNN's first layer
+// (512 lines), whose output is 336 MB.  Same products, same order, still a separate multiply and add (the file is built with
+// -ffp-contract=off and the oracle tolerances were set on that): bit-identical outputs.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef CS_WIDE
+#define CS_WIDE 1
+#endif
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_small_pool16_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                                   const float *__restrict__ bias, float *__restrict__ y,
+                                                                   int N, int H, int W, int Hp, int Wp) {
+    __shared__ __attribute__((aligned(16))) float ws[CIN * 9 * 64];
+    for (int i = threadIdx.x; i < CIN * 9 * 64; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const int ix4 = blockIdx.x * 256 + threadIdx.x;
+    const int c16 = ix4 & 3, px = ix4 >> 2, py = blockIdx.y, n = blockIdx.z;
+    if (px >= Wp) return;
+    float in[CIN][4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int iy = 2 * py - 1 + r, ix = 2 * px - 1 + c;
+            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(x + (((long)n * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)) * 4);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 v = ok ? t : z;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ci++) in[ci][r][c] = v[ci];
+        }
+    f32x2 acc[2][2][8];                                          // [a][b][channel pair]
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const f32x2 b2 = *reinterpret_cast<const f32x2 *>(bias + c16 * 16 + 2 * k);
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) acc[a][b][k] = b2;
+    }
+#pragma unroll
+    for (int ci = 0; ci < CIN; ci++)
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) {
+                const float *wp = &ws[((ci * 3 + ky) * 3 + kx) * 64 + c16 * 16];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4++) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4 *>(wp + 4 * q4);
+                    const f32x2 w0 = {wv[0], wv[1]}, w1 = {wv[2], wv[3]};
+#pragma unroll
+                    for (int a = 0; a < 2; a++)
+#pragma unroll
+                        for (int b = 0; b < 2; b++) {
+                            const float v = in[ci][a + ky][b + kx];
+                            const f32x2 vv = {v, v};
+                            acc[a][b][2 * q4] = acc[a][b][2 * q4] + w0 * vv;          // v_pk_mul_f32 + v_pk_add_f32: two roundings, as the scalar form
+                            acc[a][b][2 * q4 + 1] = acc[a][b][2 * q4 + 1] + w1 * vv;
+                        }
+                }
+            }
+    float *dst = y + (((long)n * Hp + py) * Wp + px) * 64 + c16 * 16;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; q4++) {
+        f32x4 m;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int pr = 2 * q4 + (k >> 1), e = k & 1;
+            m[k] = fmaxf(fmaxf(fmaxf(acc[0][0][pr][e], acc[0][1][pr][e]), fmaxf(acc[1][0][pr][e], acc[1][1][pr][e])), 0.f);
+        }
+        *reinterpret_cast<f32x4 *>(dst + 4 * q4) = m;
+    }
+}
+
 }  // namespace ptocr
 
 using namespace ptocr;
@@ -76,8 +152,19 @@ extern "C" int ptocr_conv3x3_small_relu_pool_f32(const float *d_x, const float *
     PT_CHECK(N > 0 && H >= 2 && W >= 2 && Cin >= 1 && Cin <= 4, "ptocr_conv3x3_small_relu_pool_f32: need H, W >= 2 and 1 <= Cin <= 4");
     const int Hp = H / 2, Wp = W / 2;
     PT_CHECK(N <= 65535 && Hp <= 65535, "ptocr_conv3x3_small_relu_pool_f32: batch or pooled height > 65535");
-    const dim3 grid((unsigned)((Wp * 16 + 255) / 256), (unsigned)Hp, (unsigned)N);
     hipStream_t s = (hipStream_t)stream;
+    static const bool wide = CS_WIDE && !(getenv("PTOCR_CONV_SMALL_WIDE") && atoi(getenv("PTOCR_CONV_SMALL_WIDE")) == 0);
+    if (wide) {
+        const dim3 grid4((unsigned)((Wp * 4 + 255) / 256), (unsigned)Hp, (unsigned)N);
+        switch (Cin) {
+            case 1: hipLaunchKernelGGL(conv3x3_small_pool16_kernel<1>, grid4, dim3(256), 0, s, d_x, d_w, d_bias, d_y, N, H, W, Hp, Wp); break;
+            case 2: hipLaunchKernelGGL(conv3x3_small_pool16_kernel<2>, grid4, dim3(256), 0, s, d_x, d_w, d_bias, d_y, N, H, W, Hp, Wp); break;
+            case 3: hipLaunchKernelGGL(conv3x3_small_pool16_kernel<3>, grid4, dim3(256), 0, s, d_x, d_w, d_bias, d_y, N, H, W, Hp, Wp); break;
+            default: hipLaunchKernelGGL(conv3x3_small_pool16_kernel<4>, grid4, dim3(256), 0, s, d_x, d_w, d_bias, d_y, N, H, W, Hp, Wp); break;
+        }
+        return launch_ok("conv3x3_small_pool16_kernel");
+    }
+    const dim3 grid((unsigned)((Wp * 16 + 255) / 256), (unsigned)Hp, (unsigned)N);
     switch (Cin) {
         case 1: hipLaunchKernelGGL(conv3x3_small_pool_kernel<1>, grid, dim3(256), 0, s, d_x, d_w, d_bias, d_y, N, H, W, Hp, Wp); break;
         case 2: hipLaunchKernelGGL(conv3x3_small_pool_kernel<2>, grid, dim3(256), 0, s, d_x, d_w, d_bias, d_y, N, H, W, Hp, Wp); break;
