@@ -73,6 +73,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef CS_WIDE
 #define CS_WIDE 1
 #endif
+#ifndef CS_ROWS
+#define CS_ROWS 1           // pooled rows a thread of the wide form walks (4, with the next row prefetched: 170 registers, 258 us against 202)
+#endif
 template <int CIN>
 __global__ __launch_bounds__(256) void conv3x3_small_pool16_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                                    const float *__restrict__ bias, float *__restrict__ y,
@@ -80,63 +83,81 @@ __global__ __launch_bounds__(256) void conv3x3_small_pool16_kernel(const float *
     __shared__ __attribute__((aligned(16))) float ws[CIN * 9 * 64];
     for (int i = threadIdx.x; i < CIN * 9 * 64; i += 256) ws[i] = w[i];
     __syncthreads();
+    // (CS_ROWS > 1: a thread walks several pooled rows of its column with the next patch requested before this one is multiplied -- an
+    // experiment: the kernel's time is the SUM of its loads, arithmetic and stores (77 us of packed arithmetic, ~84 of stores, ~35 of
+    // loads), but four rows per thread cost more in occupancy than the overlap returned)
     const int ix4 = blockIdx.x * 256 + threadIdx.x;
-    const int c16 = ix4 & 3, px = ix4 >> 2, py = blockIdx.y, n = blockIdx.z;
+    const int c16 = ix4 & 3, px = ix4 >> 2, py0 = blockIdx.y * CS_ROWS, n = blockIdx.z;
     if (px >= Wp) return;
-    float in[CIN][4][4];
+    float inb[2][CIN][4][4];
+    auto gload = [&](int py, float (&in)[CIN][4][4]) {
 #pragma unroll
-    for (int r = 0; r < 4; r++)
+        for (int r = 0; r < 4; r++)
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const int iy = 2 * py - 1 + r, ix = 2 * px - 1 + c;
-            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            const f32x4 t = *reinterpret_cast<const f32x4 *>(x + (((long)n * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)) * 4);
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 v = ok ? t : z;
+            for (int c = 0; c < 4; c++) {
+                const int iy = 2 * py - 1 + r, ix = 2 * px - 1 + c;
+                const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                const f32x4 t = *reinterpret_cast<const f32x4 *>(x + (((long)n * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)) * 4);
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 v = ok ? t : z;
 #pragma unroll
-            for (int ci = 0; ci < CIN; ci++) in[ci][r][c] = v[ci];
-        }
-    f32x2 acc[2][2][8];                                          // [a][b][channel pair]
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const f32x2 b2 = *reinterpret_cast<const f32x2 *>(bias + c16 * 16 + 2 * k);
-#pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int b = 0; b < 2; b++) acc[a][b][k] = b2;
-    }
-#pragma unroll
-    for (int ci = 0; ci < CIN; ci++)
-#pragma unroll
-        for (int ky = 0; ky < 3; ky++)
-#pragma unroll
-            for (int kx = 0; kx < 3; kx++) {
-                const float *wp = &ws[((ci * 3 + ky) * 3 + kx) * 64 + c16 * 16];
-#pragma unroll
-                for (int q4 = 0; q4 < 4; q4++) {
-                    const f32x4 wv = *reinterpret_cast<const f32x4 *>(wp + 4 * q4);
-                    const f32x2 w0 = {wv[0], wv[1]}, w1 = {wv[2], wv[3]};
-#pragma unroll
-                    for (int a = 0; a < 2; a++)
-#pragma unroll
-                        for (int b = 0; b < 2; b++) {
-                            const float v = in[ci][a + ky][b + kx];
-                            const f32x2 vv = {v, v};
-                            acc[a][b][2 * q4] = acc[a][b][2 * q4] + w0 * vv;          // v_pk_mul_f32 + v_pk_add_f32: two roundings, as the scalar form
-                            acc[a][b][2 * q4 + 1] = acc[a][b][2 * q4 + 1] + w1 * vv;
-                        }
-                }
+                for (int ci = 0; ci < CIN; ci++) in[ci][r][c] = v[ci];
             }
-    float *dst = y + (((long)n * Hp + py) * Wp + px) * 64 + c16 * 16;
+    };
+    // the thread's sixteen channels are the quads c16, c16 + 4, c16 + 8, c16 + 12: store q4 of the four threads of a pixel is then 64
+    // contiguous bytes (consecutive quads) instead of four 16-byte pieces 64 bytes apart
+    f32x4 bq[4];
 #pragma unroll
-    for (int q4 = 0; q4 < 4; q4++) {
-        f32x4 m;
+    for (int q4 = 0; q4 < 4; q4++) bq[q4] = *reinterpret_cast<const f32x4 *>(bias + (c16 + 4 * q4) * 4);
+    auto compute = [&](int py, const float (&in)[CIN][4][4]) {
+        f32x2 acc[2][2][8];                                      // [a][b][2 q4 + pair of the quad]
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int pr = 2 * q4 + (k >> 1), e = k & 1;
-            m[k] = fmaxf(fmaxf(fmaxf(acc[0][0][pr][e], acc[0][1][pr][e]), fmaxf(acc[1][0][pr][e], acc[1][1][pr][e])), 0.f);
+        for (int q4 = 0; q4 < 4; q4++)
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) { acc[a][b][2 * q4] = f32x2{bq[q4][0], bq[q4][1]}; acc[a][b][2 * q4 + 1] = f32x2{bq[q4][2], bq[q4][3]}; }
+#pragma unroll
+        for (int ci = 0; ci < CIN; ci++)
+#pragma unroll
+            for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++) {
+                    const float *wp = &ws[((ci * 3 + ky) * 3 + kx) * 64 + c16 * 4];
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4 *>(wp + 16 * q4);
+                        const f32x2 w0 = {wv[0], wv[1]}, w1 = {wv[2], wv[3]};
+#pragma unroll
+                        for (int a = 0; a < 2; a++)
+#pragma unroll
+                            for (int b = 0; b < 2; b++) {
+                                const float v = in[ci][a + ky][b + kx];
+                                const f32x2 vv = {v, v};
+                                acc[a][b][2 * q4] = acc[a][b][2 * q4] + w0 * vv;          // v_pk_mul_f32 + v_pk_add_f32: two roundings, as the scalar form
+                                acc[a][b][2 * q4 + 1] = acc[a][b][2 * q4 + 1] + w1 * vv;
+                            }
+                    }
+                }
+        float *dst = y + (((long)n * Hp + py) * Wp + px) * 64 + c16 * 4;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) {
+            f32x4 m;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int pr = 2 * q4 + (k >> 1), e = k & 1;
+                m[k] = fmaxf(fmaxf(fmaxf(acc[0][0][pr][e], acc[0][1][pr][e]), fmaxf(acc[1][0][pr][e], acc[1][1][pr][e])), 0.f);
+            }
+            *reinterpret_cast<f32x4 *>(dst + 16 * q4) = m;
         }
-        *reinterpret_cast<f32x4 *>(dst + 4 * q4) = m;
+    };
+    gload(py0, inb[0]);
+#pragma unroll
+    for (int it = 0; it < CS_ROWS; it++) {
+        const int py = py0 + it;
+        if (py >= Hp) break;                                     // block-uniform
+        if (it + 1 < CS_ROWS) gload(min(py + 1, Hp - 1), inb[(it + 1) & 1]);
+        compute(py, inb[it & 1]);
     }
 }
 
@@ -155,7 +176,7 @@ extern "C" int ptocr_conv3x3_small_relu_pool_f32(const float *d_x, const float *
     hipStream_t s = (hipStream_t)stream;
     static const bool wide = CS_WIDE && !(getenv("PTOCR_CONV_SMALL_WIDE") && atoi(getenv("PTOCR_CONV_SMALL_WIDE")) == 0);
     if (wide) {
-        const dim3 grid4((unsigned)((Wp * 4 + 255) / 256), (unsigned)Hp, (unsigned)N);
+        const dim3 grid4((unsigned)((Wp * 4 + 255) / 256), (unsigned)((Hp + CS_ROWS - 1) / CS_ROWS), (unsigned)N);
         switch (Cin) {
             case 1: hipLaunchKernelGGL(conv3x3_small_pool16_kernel<1>, grid4, dim3(256), 0, s, d_x, d_w, d_bias, d_y, N, H, W, Hp, Wp); break;
             case 2: hipLaunchKernelGGL(conv3x3_small_pool16_kernel<2>, grid4, dim3(256), 0, s, d_x, d_w, d_bias, d_y, N, H, W, Hp, Wp); break;

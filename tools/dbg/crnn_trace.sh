@@ -7,7 +7,7 @@ import csv, glob, os
 f = max(glob.glob(os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/ct/*/*kernel_trace.csv"), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "conv3x3_small_pool_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "conv3x3_small_pool" in r["Kernel_Name"]]
 start = idx[-1]
 tot = 0
 for r in rows[start:]:
