@@ -24,7 +24,19 @@ constexpr int LH = 256;             // hidden size
 constexpr int LROWS = 16;           // batch rows per workgroup
 constexpr int HLD = LH + 4;         // LDS row stride of h (floats): conflict-free ds_read_b128 over 16 rows
 
+// Gate activations of the LSTM cell.  LSTM_FAST_ACT (round 4): v_exp_f32 + v_rcp_f32 forms (absolute error ~1e-7, the size of the
+// differences between this device's libm and the CPU's that the label-id tests already live with) instead of expf / tanhf / a division:
+// the cell update is on the critical path of every time step, after the MFMAs and before the exchange of h.
+#ifndef LSTM_FAST_ACT
+#define LSTM_FAST_ACT 1
+#endif
+#if LSTM_FAST_ACT
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
+#else
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return tanhf(x); }
+#endif
 
 // only_if != nullptr: the launch is the REPAIR pass behind a split-form launch -- it runs only when that launch reported a
 // timed-out exchange (*only_if != 0) and then recomputes the whole layer; otherwise every workgroup exits at once.
@@ -125,10 +137,10 @@ __global__ __launch_bounds__(256) void lstm_bidir_kernel(const float *__restrict
             for (int r = 0; r < 4; r++) {
                 const float ig = sigmoidf_(acc[0][q][r]);
                 const float fg = sigmoidf_(acc[1][q][r]);
-                const float gg = tanhf(acc[2][q][r]);
+                const float gg = tanhf_(acc[2][q][r]);
                 const float og = sigmoidf_(acc[3][q][r]);
                 c[q][r] = fg * c[q][r] + ig * gg;
-                const float h = og * tanhf(c[q][r]);
+                const float h = og * tanhf_(c[q][r]);
                 const int row = 4 * kq + r, unit = 64 * wave + 16 * q + jc;
                 hbuf[cur ^ 1][row][unit] = h;
                 const int b = b0 + row;
@@ -188,72 +200,85 @@ __global__ __launch_bounds__(256, 1) void lstm_bidir_split_kernel(const float *_
     f32x4 xnext[4];
     load_x(xnext, 0);
     bool ok = true;
+    // Round 4: this part's OWN slice of h(step-1) goes straight into hbuf at the cell update (no trip through memory), and the quarter
+    // of the step's MFMAs that multiplies it runs between the first poll of the partners' slices and the look at what came back: one
+    // round trip of the exchange hides behind 64 of the 256 MFMAs of the step.
+    for (int i = tid; i < LROWS * HLD; i += 256) (&hbuf[0][0])[i] = 0.f;   // h(-1) = 0
+    __syncthreads();
+    const int prow = tid >> 4, pu0 = (tid & 15) * 16;                       // polling: thread i fetches row i >> 4, units 16 (i & 15) .. +15
+    const bool foreign = ((tid & 15) >> 2) != part;                         // units of another part (the own slice is already in hbuf)
+    const float *hrow = &hbuf[jc][4 * kq];                                  // A operand: row jc, k = 16*kb + 4*kq + t
+    auto mfma_kb = [&](f32x4 (&acc)[4], int kb) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(hrow + 16 * kb);
+#pragma unroll
+        for (int tt = 0; tt < 4; tt++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tt], w[g][kb][tt], acc[g], 0, 0, 0);
+    };
     for (int step = 0; step < T; step++) {
         const int t = dir ? (T - 1 - step) : step;
         f32x4 acc[4];
 #pragma unroll
         for (int g = 0; g < 4; g++) acc[g] = xnext[g];
         if (step + 1 < T) load_x(xnext, step + 1);
-        // h(step-1) of all four parts -> LDS: thread i fetches row i >> 4, units 16 (i & 15) .. +15
-        {
-            const int row = tid >> 4, u0 = (tid & 15) * 16;
-            float hv[16];
-            if (step == 0) {
+        const u64 *src = hx_base + ((long)((step + 1) & 1) * LROWS + prow) * LH + pu0;     // parity of step - 1
+        const unsigned want = (unsigned)step;                               // tag of step-1 is (step-1) + 1
+        u64 pv[16];
+        const bool poll = step > 0 && foreign;
+        if (poll) {
 #pragma unroll
-                for (int i = 0; i < 16; i++) hv[i] = 0.f;
-            } else {
-                const u64 *src = hx_base + ((long)((step - 1) & 1) * LROWS + row) * LH + u0;
-                const unsigned want = (unsigned)step;                       // tag of step-1 is (step-1) + 1
-                for (unsigned spins = 0;; spins++) {
-                    bool all = true;
+            for (int i = 0; i < 16; i++) pv[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // the own slice's k blocks (every w[g][kb] index stays a compile-time constant: the part only gates the blocks)
 #pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        const u64 v = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        hv[i] = __builtin_bit_cast(float, (unsigned)v);
-                        all &= (unsigned)(v >> 32) == want;
-                    }
-                    if (all) break;
-                    // give up, never hang: the own bound, or (looked at every 64 polls) a workgroup that already gave up
-                    if (spins + 1 >= spin_limit ||
-                        ((spins & 63) == 63 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                        ok = false; atomicExch(err, 1); wg_failed = 1; break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
+        for (int kb = 0; kb < LH / 16; kb++)
+            if ((kb >> 2) == part) mfma_kb(acc, kb);
+        if (poll) {
+            for (unsigned spins = 0;; spins++) {
+                bool all = true;
+#pragma unroll
+                for (int i = 0; i < 16; i++) all &= (unsigned)(pv[i] >> 32) == want;
+                if (all) break;
+                // give up, never hang: the own bound, or (looked at every 64 polls) a workgroup that already gave up
+                if (spins + 1 >= spin_limit ||
+                    ((spins & 63) == 63 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    ok = false; atomicExch(err, 1); wg_failed = 1; break;
                 }
+                __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+                for (int i = 0; i < 16; i++) pv[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 #pragma unroll
-            for (int i = 0; i < 16; i += 4) *reinterpret_cast<f32x4 *>(&hbuf[row][u0 + i]) = f32x4{hv[i], hv[i + 1], hv[i + 2], hv[i + 3]};
+            for (int i = 0; i < 16; i += 4)
+                *reinterpret_cast<f32x4 *>(&hbuf[prow][pu0 + i]) = f32x4{__builtin_bit_cast(float, (unsigned)pv[i]), __builtin_bit_cast(float, (unsigned)pv[i + 1]),
+                                                                         __builtin_bit_cast(float, (unsigned)pv[i + 2]), __builtin_bit_cast(float, (unsigned)pv[i + 3])};
         }
         __syncthreads();
         if (wg_failed) break;                             // the WHOLE workgroup leaves (uniform: read behind the barrier); the
                                                           // repair pass recomputes the layer, the partners bail out on `err`
-        const float *hrow = &hbuf[jc][4 * kq];            // A operand: row jc, k = 16*kb + 4*kq + t
 #pragma unroll
-        for (int kb = 0; kb < LH / 16; kb++) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(hrow + 16 * kb);
-#pragma unroll
-            for (int tt = 0; tt < 4; tt++)
-#pragma unroll
-                for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tt], w[g][kb][tt], acc[g], 0, 0, 0);
-        }
+        for (int kb = 0; kb < LH / 16; kb++)
+            if ((kb >> 2) != part) mfma_kb(acc, kb);
         // cell update (torch gate order i, f, g, o) and publication of this part's slice of h(step)
         u64 *dst = hx_base + (long)(step & 1) * LROWS * LH;
+        // (the own slice written below was last read BEFORE the barrier above, the partners' slices are rewritten after the one at the end)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const float ig = sigmoidf_(acc[0][r]);
             const float fg = sigmoidf_(acc[1][r]);
-            const float gg = tanhf(acc[2][r]);
+            const float gg = tanhf_(acc[2][r]);
             const float og = sigmoidf_(acc[3][r]);
             c[r] = fg * c[r] + ig * gg;
-            const float h = og * tanhf(c[r]);
+            const float h = og * tanhf_(c[r]);
             const int row = 4 * kq + r;
             if (!(spin_limit == 1u && part == LPARTS - 1))        // test hook (spin limit 1): this part never publishes
                 __hip_atomic_store(dst + (long)row * LH + unit, ((u64)(unsigned)(step + 1) << 32) | __builtin_bit_cast(unsigned, h),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hbuf[row][unit] = h;
             const int b = b0 + row;
             if (b < B) out[((long)b * T + t) * (2 * LH) + dir * LH + unit] = h;
         }
-        __syncthreads();                                  // hbuf is rewritten at the top of the next step
+        __syncthreads();                                  // the own slice of h(step) is in hbuf for the next step's first MFMAs
     }
     (void)ok;
 }
