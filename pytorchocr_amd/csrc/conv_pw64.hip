@@ -33,6 +33,12 @@ struct Pw64Args {
 // 256 registers at two per SIMD, so a tile is taken in PASSES of at most four 32-channel blocks (64 accumulator registers + 64 for the
 // top-down rows of the pass, requested when its MFMAs are issued and used one phase later; the next pixel tile is requested in the last
 // store phase of this one and waits in 32 registers).  Each team has ONE pixel tile in LDS, the weights are shared.
+#ifndef PW64_DBG
+#define PW64_DBG 0          // timing experiments only: 1 no stores, 2 no top-down row loads
+#endif
+// (Knock-outs, tools/dbg/pw64_knock.sh: 745 us; 614 without the stores, 622 without the top-down rows, 607 with neither -- the MFMA
+// loop alone runs at 65 % of the matrix pipe.  k-contiguous LDS layouts for both operands -- one 16-byte read per four k steps instead
+// of four 4-byte ones -- measured WORSE: 810 us, 681 with both knock-outs; not kept.)
 template <int PW_K, int NMT>                    // input channels (32 or 64), Cout / 32
 __global__ __launch_bounds__(512, 1) void conv_pw64_kernel(Pw64Args p) {
     constexpr int NP = NMT > 4 ? 2 : 1, MTP = (NMT + NP - 1) / NP;           // passes per tile, channel blocks per pass (the last pass may have one fewer)
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(512, 1) void conv_pw64_kernel(Pw64Args p) {
             for (int mt = 0; mt < MTP; mt++)
                 if (MTP * pass + mt < NMT) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[(2 * s) * COUT + 32 * mt], b, acc[mt], 0, 0, 0);
         }
-        if (p.res_up2) {                                         // + nearest-upsampled coarser map, after the ReLU: used one phase later
+        if (p.res_up2 && !(PW64_DBG & 2)) {                      // + nearest-upsampled coarser map, after the ReLU: used one phase later
             const long m = (long)tile * PW_TM + 32 * wave + c;
             const long mm = m < p.M ? m : 0;
             const int hw = p.H * p.W;
@@ -122,6 +128,7 @@ __global__ __launch_bounds__(512, 1) void conv_pw64_kernel(Pw64Args p) {
                     for (int k = 0; k < 4; k++) v[k] = v[k] * fminf(fmaxf(v[k] + 3.f, 0.f), 6.f) * (1.f / 6.f);
                 }
                 if (p.res_up2) v += rres[mt][g];
+                if ((PW64_DBG & 1) && v[0] != 123.456f) continue;
                 *reinterpret_cast<f32x4 *>(yp + co) = v;
             }
     };
