@@ -29,8 +29,11 @@
 #define W4_RAW_SLOT 0       // MFMA slot of a chunk at which the raw-patch refill (global loads / LDS stores of two pieces) is issued
 #endif
 #ifndef W4_PRIO
-#define W4_PRIO 3            // wave priority raised around every MFMA issue: nothing alone on the chip (3 058 vs 3 074 cycles per chunk), +0.35 % on the headline
-                            // (2 104 / 2 112 -> 2 115 / 2 117 images/s alternating on one box), where the post-process of the previous batch shares the CUs
+#define W4_PRIO 0            // experiment, OFF: wave priority raised around every MFMA issue.  Nothing alone on the chip (3 058 vs 3 074 cycles per chunk),
+                            // +0.35 % on the headline where the post-process of the previous batch shares the CUs (2 104 / 2 112 -> 2 115 / 2 117
+                            // images/s) -- but the first full default bench run with it ended in a GPU memory access fault that no run before
+                            // it (and none of the test suites) had shown: it changes which kernel's waves run when several share a CU, and
+                            // was withdrawn rather than trusted
 #endif
 #ifndef W4_RESPF
 #define W4_RESPF 1          // 1: the residual rows of an output pass are requested one pass ahead

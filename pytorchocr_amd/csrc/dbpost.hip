@@ -2943,7 +2943,7 @@ __device__ __forceinline__ void border_quad_body(const StageArgs &a, const Dbpos
     QuadArena &A = arena[qi];
     long long *st = (a.stamps && group < 4 * 63 && (group & 3) == 0) ? a.stamps + ((long)img * 63 + (group >> 2)) * 16 : nullptr;
     stamp(st, 0);
-    const int n = __hip_atomic_load(&a.hn[bi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int n = min(max(__hip_atomic_load(&a.hn[bi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0), S_MH);      // (clamped: never an index beyond the hull slots, whatever the word holds)
     for (int i = c; i < n; i += 4) {
         const unsigned long long v = __hip_atomic_load(reinterpret_cast<unsigned long long *>(a.hin + bi * S_MH + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         A.pts[i].x = __uint_as_float((unsigned)v); A.pts[i].y = __uint_as_float((unsigned)(v >> 32));
