@@ -715,7 +715,34 @@ def main():
     if args.dtype == "bf16" and (args.workload != "det" or args.det_model != "mbv3s"):
         raise SystemExit("bench.py: --dtype bf16 is BASELINE configs[3], i.e. --workload det --det-model mbv3s")
     args.crnn_batch = (args.batch or 512) if args.workload == "crnn" else 512
-    if args.workload == "det":
+    # One GPU: the embedded lines of the other BASELINE configs run as CHILD processes of this one (started after the headline is
+    # measured, one at a time): whatever happens in one of them -- they are the pipeline's most concurrent paths -- the headline line is
+    # still printed, with the child's error in its place.  Several ranks: in-process, all ranks together, as before.
+    isolate = world == 1 and os.environ.get("PTOCR_BENCH_INPROC") != "1"
+
+    def child_line(extra):
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-embed", "--crnn-steps", "0"] + [str(v) for v in extra]
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=dict(os.environ, PTOCR_BENCH_INPROC="1"))
+            rows = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+            if r.returncode == 0 and rows:
+                return json.loads(rows[-1])
+            return {"error": "child exited with %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-400:])}
+        except Exception as e:                                       # time-out, unparsable line
+            return {"error": "%s: %s" % (type(e).__name__, e)}
+
+    if args.workload == "det" and isolate and args.det_model == "r18" and args.dtype == "f32":
+        line = run_det(args, rank, local, world, device)
+        crnn_steps = args.steps if args.crnn_steps < 0 else args.crnn_steps
+        torch.cuda.empty_cache()
+        if crnn_steps > 0:
+            line["crnn"] = child_line(["--workload", "crnn", "--steps", crnn_steps, "--warmup", min(args.warmup, 10), "--cpu-lines", args.cpu_lines])
+        if args.embed:
+            line["mbv3s_bf16"] = child_line(["--det-model", "mbv3s", "--dtype", "bf16", "--steps", args.steps, "--warmup", min(args.warmup, 10),
+                                             "--cpu-images", min(args.cpu_images, 4), "--distinct-images", args.distinct_images, "--weights", args.weights]
+                                            + ([] if args.overlap else ["--no-overlap"]) + (["--post-input", args.post_input] if args.post_input else []))
+            line["ocr"] = child_line(["--workload", "ocr", "--steps", max(2, min(5, args.steps)), "--warmup", 2, "--cpu-images", min(args.cpu_images, 1)])
+    elif args.workload == "det":
         line = run_det(args, rank, local, world, device)
         crnn_steps = args.steps if args.crnn_steps < 0 else args.crnn_steps
         if crnn_steps > 0 and args.det_model == "r18":
