@@ -3281,8 +3281,11 @@ static int dbpost_alloc(ptocr_dbpost *h, int max_n, int max_h, int max_w) {
     PT_HIP(hipMalloc(&h->list, sizeof(int) * max_n * MAX_CAND));
     PT_HIP(hipMemset(h->list, 0, sizeof(int) * max_n * MAX_CAND));
     PT_HIP(hipMalloc(&h->tie, sizeof(int) * max_n * MAX_CAND));
+    PT_HIP(hipMemset(h->tie, 0, sizeof(int) * max_n * MAX_CAND));                 // never garbage: a count or an index read one call too early is then a stale VALID one
     PT_HIP(hipMalloc(&h->cands, sizeof(Cand) * max_n * MAX_CAND));
+    PT_HIP(hipMemset(h->cands, 0, sizeof(Cand) * max_n * MAX_CAND));                 // never garbage: a count or an index read one call too early is then a stale VALID one
     PT_HIP(hipMalloc(&h->acc, sizeof(Acc) * max_n * MAX_CAND));
+    PT_HIP(hipMemset(h->acc, 0, sizeof(Acc) * max_n * MAX_CAND));                 // never garbage: a count or an index read one call too early is then a stale VALID one
     PT_HIP(hipMalloc(&h->pool, sizeof(unsigned) * max_n * h->pool_cap));
     {
         h->stage_cap = ((long)cdiv(max_h, 8) * cdiv(max_w, 256) + cdiv(max_h, 8) + cdiv(max_w, 256) + 1) * STAGE_TILE;      // any H x W within the workspace: cdiv(H,8) cdiv(WW,8) tiles
@@ -3290,9 +3293,12 @@ static int dbpost_alloc(ptocr_dbpost *h, int max_n, int max_h, int max_w) {
         PT_HIP(hipMalloc(&h->stage_hdr, sizeof(int) * max_n * (h->stage_cap / STAGE_TILE)));
     }
     PT_HIP(hipMalloc(&h->hin, sizeof(F2) * (size_t)max_n * MAX_CAND * S_MH));
+    PT_HIP(hipMemset(h->hin, 0, sizeof(F2) * (size_t)max_n * MAX_CAND * S_MH));                 // never garbage: a count or an index read one call too early is then a stale VALID one
     PT_HIP(hipMalloc(&h->hn, sizeof(int) * max_n * MAX_CAND));
+    PT_HIP(hipMemset(h->hn, 0, sizeof(int) * max_n * MAX_CAND));                 // never garbage: a count or an index read one call too early is then a stale VALID one
     PT_HIP(hipMalloc(&h->mini, sizeof(float) * 8 * max_n * MAX_CAND));
     PT_HIP(hipMalloc(&h->results, sizeof(Result) * max_n * MAX_CAND));
+    PT_HIP(hipMemset(h->results, 0, sizeof(Result) * max_n * MAX_CAND));                 // never garbage: a count or an index read one call too early is then a stale VALID one
     PT_HIP(hipMalloc(&h->src_wh, sizeof(int) * 2 * max_n));
     PT_HIP(hipMalloc(&h->boxes, sizeof(short) * 8 * max_n * MAX_CAND));
     PT_HIP(hipEventCreate(&h->ev0));
