@@ -224,6 +224,48 @@ def test_scene_checkpoint_maps_and_boxes_against_the_reference(which, gold_dir, 
     assert abs(len(got) - len(exp)) <= 1 and same >= len(exp) - 1, (len(got), len(exp), same)
 
 
+def test_post_process_beside_the_next_forward_returns_the_boxes_it_returns_alone(contract):
+    """The bench's (and a service's) configuration: DBPostProcess.submit queues the post-process of batch i on its own stream and the
+    convolutions of batch i + 1 run beside it.  The boxes of every overlapped call must be the boxes of the same maps post-processed
+    alone -- different scenes per step, so that a result leaking from one call into the next (a stale count, a ready word of another
+    call) would show; the maps themselves must not change either.  Twelve steps of 8 scenes at the bench's 736 x 1280."""
+    from pytorchocr_amd.modeling.architectures import build_model
+    from pytorchocr_amd.postprocess import build_post_process
+    from pytorchocr_amd.utils.synth import load_scene_readout, synth_scene_inputs, synth_scene_state_dict
+    cfg, key, _ = SCENES["r18"]
+    sd = synth_scene_state_dict(contract[key], *load_scene_readout("r18"))
+    m = build_model(cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.to("cuda:0").eval()
+    n, h, w = 8, 736, 1280
+    xs = [torch.from_numpy(synth_scene_inputs(n, h, w, seed=900 + i)).cuda() for i in range(3)]
+    shapes = np.array([[h, w, 1.0, 1.0]] * n)
+    post = build_post_process(dict(name="DBPostProcess", thresh=0.3, box_thresh=0.5, unclip_ratio=1.7, cpp_speedup=True), {})
+    alone, maps_alone = [], []
+    with torch.no_grad():
+        for x in xs:
+            mp = m(x)["maps"]
+            torch.cuda.synchronize()
+            maps_alone.append(mp.clone())
+            alone.append(post({"maps": mp}, shapes))
+    assert min(len(b["points"]) for r in alone for b in r) >= 50
+    pending, got = None, []
+    with torch.no_grad():
+        for step in range(12):
+            mp = m(xs[step % 3])["maps"]
+            assert torch.equal(mp, maps_alone[step % 3])
+            fut = post.submit({"maps": mp}, shapes)
+            if pending is not None:
+                got.append(pending.result())
+            pending = fut
+        got.append(pending.result())
+    torch.cuda.synchronize()
+    for step, res in enumerate(got):
+        exp = alone[step % 3]
+        for a, b in zip(res, exp):
+            assert len(a["points"]) == len(b["points"]) and np.array_equal(np.asarray(a["points"]), np.asarray(b["points"])), step
+
+
 @pytest.mark.parametrize("seed", range(6 + int(os.environ.get("PTOCR_MODEL_FUZZ", "0"))))      # PTOCR_MODEL_FUZZ=n: n more seeds
 def test_detectors_random_sizes_against_the_oracle(seed, contract):
     """DBNet-r18 / DBNet++-r18 / DBNet-mbv3s at random input sizes (multiples of 32, as DetResizeForTest makes them) and batch sizes
