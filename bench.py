@@ -356,6 +356,17 @@ def _conv_profile(prof, labels):
     return sum(ms), len(ms), wino_ms, wino_flops, n_wino
 
 
+PROFILE_PASS_STEPS = 10                     # steps of the untimed per-launch-event pass behind `roofline`
+
+
+def _profile_pass_note(prof_steps, dt_prof, timed_step_s):
+    """where the per-launch durations of `roofline` come from, and what the event records cost: the same step with and without them"""
+    return {"pass": "separate pass of %d steps of the same step right after the timed region (ops.PROFILE on: two hipEventRecords around "
+                    "every conv launch); the timed region carries no per-launch events" % prof_steps,
+            "ms_per_step_with_launch_events": round(dt_prof / prof_steps * 1e3, 3),
+            "ms_per_step_timed_region": round(timed_step_s * 1e3, 3)}
+
+
 def _profile_json(name):
     p = os.path.join(ROOT, "profiles", name)
     if os.path.exists(p):
@@ -464,8 +475,9 @@ def run_det(args, rank, local, world, device):
         fwd_launches = _plib.CALLS - calls0
         torch.cuda.synchronize()
         fwd_events = []
-    ops.PROFILE = [] if rank == 0 else None
-    ops.PROFILE_LABELS = [] if rank == 0 else None
+    # The timed region carries NO per-launch instrumentation (ops.PROFILE stays None: round 5 bracketed every conv launch of the timed
+    # steps with two hipEventRecords, 58 per step).  The per-launch HIP events behind `roofline` come from a SEPARATE pass of the same
+    # step, run right after the timed region (same batch, same overlap with the post-process stream) and reported with its own wall time.
     post.device_ms_log = []
     nbox = {t: 0 for t in tags}
     events = []
@@ -481,10 +493,22 @@ def run_det(args, rank, local, world, device):
     ev_end.record()
     _sync_all(world)
     dt = time.perf_counter() - t0
-    prof, labels = ops.PROFILE, ops.PROFILE_LABELS
-    ops.PROFILE = ops.PROFILE_LABELS = None
     post_ms = post.device_ms_log
     post.device_ms_log = None
+    prof_steps = max(1, min(args.steps, PROFILE_PASS_STEPS))
+    ops.PROFILE = [] if rank == 0 else None
+    ops.PROFILE_LABELS = [] if rank == 0 else None
+    pending = []
+    tp0 = time.perf_counter()
+    for _ in range(prof_steps):
+        pending, _, _ = step(pending)
+    for f in pending:
+        f.result()
+    torch.cuda.synchronize()
+    dt_prof = time.perf_counter() - tp0
+    prof, labels = ops.PROFILE, ops.PROFILE_LABELS
+    ops.PROFILE = ops.PROFILE_LABELS = None
+    _sync_all(world)
     per_rank = _per_rank(B * args.steps / dt, world, device)
     dt = _max_over_ranks(dt, world, device)
     if rank != 0:
@@ -492,7 +516,7 @@ def run_det(args, rank, local, world, device):
     events.append(ev_end)
     step_ms = [events[i].elapsed_time(events[i + 1]) for i in range(len(events) - 1)]
     conv_ms, n_launch, wino_ms, wino_flops, n_wino = _conv_profile(prof, labels)
-    conv_flops = (gflop_img - DET_TAIL_GFLOP_PER_IMG) * 1e9 * B * args.steps
+    conv_flops = (gflop_img - DET_TAIL_GFLOP_PER_IMG) * 1e9 * B * prof_steps
     # post-process stage: device time of every call (HIP events on the post-process stream, inside the timed region, i.e. while
     # the next batch's convolutions share the chip), and the same call alone on an idle chip
     by_tag = {t: post_ms[i::len(tags)] for i, t in enumerate(tags)} if tags else {}
@@ -557,9 +581,10 @@ def run_det(args, rank, local, world, device):
                 "mfma_tflops": round(gflop_img * 1e9 * B / (fms * 1e-3) / 1e12, 2),
                 "mfma_frac_of_bf16_peak": round(gflop_img * 1e9 * B / (fms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}
     else:
-        roof = _wino_roofline(wino_ms, wino_flops, n_wino, args.steps, "every 3x3/s1 layer")
+        roof = _wino_roofline(wino_ms, wino_flops, n_wino, prof_steps, "every 3x3/s1 layer")
+        roof["measured_in"] = _profile_pass_note(prof_steps, dt_prof, dt / args.steps)
     if not bf16:
-        roof["all_conv"] = {"launches_per_step": n_launch // max(args.steps, 1), "ms_per_step": round(conv_ms / max(args.steps, 1), 3),
+        roof["all_conv"] = {"launches_per_step": n_launch // max(prof_steps, 1), "ms_per_step": round(conv_ms / max(prof_steps, 1), 3),
                             "algorithmic_tflops": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2) if conv_ms > 0 else 0.0,
                             "kernels": "conv_wino4r_kernel / conv_wino_kernel (3x3 s1) + stem_conv_kernel (7x7 s2) + conv_pw64_kernel (FPN in2) + conv_mfma_v2_kernel (3x3 s2, other 1x1)"}
     return {
@@ -617,8 +642,6 @@ def run_crnn(args, rank, local, world, device):
         pending.result()
     pending = None
     _sync_all(world)
-    ops.PROFILE = [] if rank == 0 else None
-    ops.PROFILE_LABELS = [] if rank == 0 else None
     lstm0 = lstm_stats()
     nchar = 0
     events = []
@@ -633,20 +656,34 @@ def run_crnn(args, rank, local, world, device):
     ev_end.record()
     _sync_all(world)
     dt = time.perf_counter() - t0
+    lstm1 = lstm_stats()
+    # per-launch HIP events: a separate pass of the same step, outside the timed region (see run_det)
+    prof_steps = max(1, min(args.steps, PROFILE_PASS_STEPS))
+    ops.PROFILE = [] if rank == 0 else None
+    ops.PROFILE_LABELS = [] if rank == 0 else None
+    pending = None
+    tp0 = time.perf_counter()
+    for _ in range(prof_steps):
+        pending, _, _ = step(pending)
+    if pending is not None:
+        pending.result()
+    torch.cuda.synchronize()
+    dt_prof = time.perf_counter() - tp0
     prof, labels = ops.PROFILE, ops.PROFILE_LABELS
     ops.PROFILE = ops.PROFILE_LABELS = None
+    _sync_all(world)
     per_rank = _per_rank(B * args.steps / dt, world, device)
     dt = _max_over_ranks(dt, world, device)
     if rank != 0:
         return None
-    lstm1 = lstm_stats()
     events.append(ev_end)
     step_ms = [events[i].elapsed_time(events[i + 1]) for i in range(len(events) - 1)]
     conv_ms, n_launch, wino_ms, wino_flops, n_wino = _conv_profile(prof, labels)
-    roof = _wino_roofline(wino_ms, wino_flops, n_wino, args.steps, "VGG conv1..conv5")
+    roof = _wino_roofline(wino_ms, wino_flops, n_wino, prof_steps, "VGG conv1..conv5")
+    roof["measured_in"] = _profile_pass_note(prof_steps, dt_prof, dt / args.steps)
     roof["traffic"] = (_profile_json("crnn_traffic.json") or {}).get("hbm_bytes_per_launch")
     roof["whole_step_algorithmic_tflops"] = round(CRNN_GFLOP_PER_LINE * 1e9 * B * args.steps / dt / 1e12, 2)
-    roof["all_conv"] = {"launches_per_step": n_launch // max(args.steps, 1), "ms_per_step": round(conv_ms / max(args.steps, 1), 3)}
+    roof["all_conv"] = {"launches_per_step": n_launch // max(prof_steps, 1), "ms_per_step": round(conv_ms / max(prof_steps, 1), 3)}
     return {
         "metric": "CRNN text-lines/sec (vgg_v1_x1.0 + BiLSTM + CTC greedy, 32x320)",
         "value": round(world * B * args.steps / dt, 2), "unit": "text-lines/sec", "n_gpus": world, "steps": args.steps,

@@ -31,6 +31,21 @@ from pytorchocr_amd.utils.synth import synth_state_dict, synth_images, synth_tex
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
+
+def write_contract(path, contract):
+    """state_dict_contract.json through ONE fixed formatter (a model per block, a parameter per line, insertion order), so that a
+    regeneration is byte-identical whichever step of this script touched the file last"""
+    with open(path, "w") as f:
+        f.write("{\n")
+        for mi, (model, keys) in enumerate(contract.items()):
+            f.write(" %s: {\n" % json.dumps(model))
+            items = list(keys.items())
+            for ki, (k, (shape, dtype)) in enumerate(items):
+                f.write("  %s: [%s, %s]%s\n" % (json.dumps(k), json.dumps([int(v) for v in shape]), json.dumps(dtype), "," if ki + 1 < len(items) else ""))
+            f.write(" }%s\n" % ("," if mi + 1 < len(contract) else ""))
+        f.write("}\n")
+
+
 def _import_reference_models():
     tv = types.ModuleType("torchvision")
     tvm = types.ModuleType("torchvision.models")
@@ -137,8 +152,7 @@ def main():
                         idx=idx.astype(np.int32), prob=prob, cols=cols.astype(np.int32),
                         probs_cols=pn[:, :, cols], shape=np.array(pn.shape, np.int64))
 
-    with open(os.path.join(GOLD, "state_dict_contract.json"), "w") as f:
-        json.dump(contract, f, indent=0, sort_keys=False)
+    write_contract(os.path.join(GOLD, "state_dict_contract.json"), contract)
 
     # ---------------- CTCLabelDecode known answers from the reference class itself
     spec = importlib.util.spec_from_file_location("ref_rec_postprocess",
@@ -200,8 +214,7 @@ def gen_cls_vectors():
     path = os.path.join(GOLD, "state_dict_contract.json")
     contract = json.load(open(path))
     contract["cls_mbv3s"] = {k: [list(sh), d] for k, (sh, d) in shapes.items()}
-    with open(path, "w") as f:
-        json.dump(contract, f, indent=0, sort_keys=False)
+    write_contract(path, contract)
     fc_scale = 0.25                                 # synth_state_dict's fc (made for the CTC head: bias[0] = 13) saturates a 2-class
     with torch.no_grad():                           # softmax; with the bias zeroed and the weights scaled it discriminates
         m.head.fc.weight.mul_(fc_scale)
@@ -333,8 +346,7 @@ def gen_widen_vectors():
         hook.remove()
         np.savez_compressed(os.path.join(GOLD, "%s_2x1x32x160.npz" % name), seed=np.int64(seed), probs=pr.numpy(), backbone=feats["b"].numpy())
         print("%s: T %d, backbone %s" % (name, pr.shape[0], tuple(feats["b"].shape)))
-    with open(path, "w") as f:
-        json.dump(contract, f, indent=0, sort_keys=False)
+    write_contract(path, contract)
 
 
 def gen_clipper_vectors():
