@@ -370,9 +370,16 @@ int ptocr_lstm_bidir_f32(const float *d_xproj, const float *d_whh, float *d_out,
  * d_out is correct either way, without a host round trip.  PTOCR_LSTM_SPLIT=0 selects the exchange-free form outright. */
 /* split-form calls so far / how many of them were recomputed by the repair pass (synchronises) */
 int ptocr_lstm_stats(int *split_calls, int *repaired);
-/* split-form calls whose four workgroups per (16 lines, direction) sat on ONE XCD (checked at run time with HW_REG_XCC_ID) and exchanged h
- * through that XCD's L2; the others used the write-through exchange, with the same results */
+/* split-form calls in which EVERY workgroup of EVERY (16 lines, direction) pair found its three partners on its own XCD (checked at run
+ * time with HW_REG_XCC_ID) and exchanged h through that XCD's L2; a workgroup that did not uses the write-through exchange, with the
+ * same results (counted per call by the repair launch that follows every split call on its stream) */
 int ptocr_lstm_same_xcd_calls(int *calls);
+/* the same per workgroup: workgroups of split calls (current device) that took the same-XCD exchange / workgroups those calls had */
+int ptocr_lstm_fast_workgroups(long long *fast, long long *all);
+/* test hook: placement of the split form's workgroups.  -1 = PTOCR_LSTM_COLOCATE (default: on); 0 = round-4 layout, write-through
+ * exchange; 1 = the four parts of a pair on one XCD; 3 = as 1, but part 1 of every pair is forced onto the write-through stores, so a
+ * pair mixes both kinds of store (what a workgroup that finds foreign XCC ids among its partners does) */
+void ptocr_lstm_set_colocate(int mode);
 /* test hook: polls of one exchange before a workgroup gives up (0 = default 65536); 1 = give up at the first miss AND one of
  * the four workgroups withholds its slice, which forces the time-out and so the repair path */
 void ptocr_lstm_set_spin_limit(unsigned polls);

@@ -1964,35 +1964,52 @@ __device__ int clipper_union_cut(F2 *P, int n, F2 *q, int *chain) {
     return n;
 }
 
-// ------------------------------------------------------------------------------------------ quad-lane geometry
+// ------------------------------------------------------------------------------------------ group-lane geometry
 // The sequential float32 / double geometry of a border (Sklansky's chains, the caliper walk, Clipper's round offset) run by a WHOLE
 // wave for one border keeps 63 lanes idle: at ~4 600 borders per batch of 32 maps that is what the stage costs (unclip: 43 us for
-// one border alone on its SIMD, 89 us with five waves per SIMD).  Here FOUR LANES own a border and a wave owns sixteen: the four
-// Sklansky chains of a hull run one per lane, the four corners of the Clipper offset one per lane (the k-chain of OffsetPoint's early
-// return is resolved first, from the normals alone), edge tables / extremes / rank sort are split four ways, and the caliper walk --
-// whose steps depend on each other -- is executed identically by the four lanes (no cross-lane traffic inside the loop).  Same float
-// operations in the same order as the sequential forms above, which stay as the reference for the full-size pass.
-constexpr int Q_PTS = 64;                 // hull candidates / offset points a quad handles; more -> the full-size pass
+// one border alone on its SIMD, 89 us with five waves per SIMD).  Here a wave owns FOUR borders, SIXTEEN LANES each (round 6; rounds
+// 4-5 gave a border four lanes and left lanes 16..63 of the wave idle):
+//   * everything that is independent per point or per edge -- reading the candidates, the edge table of the caliper walk (a double
+//     sqrt and a double division per edge), the extreme scans, the rank sort of the offset polygon, the hull's output copy -- runs one
+//     element per lane over the sixteen lanes;
+//   * the four Sklansky chains of a hull run one per lane on lanes 0..3 of the group, the four corners of the Clipper offset one per
+//     lane (the k-chain of OffsetPoint's early return is resolved first, from the normals alone);
+//   * the caliper walk -- whose steps depend on each other -- runs ONE CALIPER PER LANE (round 6; before, every lane carried all four):
+//     a lane computes its own caliper's cosine, the quad agrees on the winner through DPP quad permutes (a cross-lane operand of the
+//     instruction itself: no LDS, no extra latency), only the winner advances.  Lanes 4..15 of the group repeat lanes 0..3 (same
+//     instructions, same values): nothing in the walk diverges.
+// Same float operations in the same order as the sequential forms above, which stay as the reference for the full-size pass.
+constexpr int Q_PTS = 64;                 // hull candidates / offset points a group handles; more -> the full-size pass
+constexpr int GL = 16;                    // lanes per border
 struct __attribute__((aligned(16))) QuadArena {                        // LDS of one border
     F2 pts[Q_PTS];                        // the point list sorted by (x, y)
     F2 hull[Q_PTS];                       // the unsorted offset polygon, later the convex hull
-    float4 ev[Q_PTS];                     // caliper table: edge vector, inverse length
-    int stack[4][Q_PTS + 2];              // the four Sklansky chains
+    union {                               // never alive together: the chains end before the caliper table (or the sort keys) is built
+        int stack[4][Q_PTS + 2];          // the four Sklansky chains
+        float4 ev[Q_PTS];                 // caliper table: edge vector, inverse length; the rank sort's 64-bit keys
+    };
     long long cl_ws[24];                  // Clipper: de-duplicated path (4 x 2), normals (2 x 4), input path (4 x 2)
 };
 
-__device__ __forceinline__ void quad_first_extreme(float v, int idx, bool want_max, int *out_idx) {
+// quad permutes as DPP operands (dpp_ctrl = p0 | p1 << 2 | p2 << 4 | p3 << 6): lane q of every aligned quad reads lane p_q of it
+template <int CTRL> __device__ __forceinline__ int qperm_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL> __device__ __forceinline__ float qperm(float v) { return __builtin_bit_cast(float, qperm_i<CTRL>(__builtin_bit_cast(int, v))); }
+constexpr int QP_SWAP1 = 0xB1, QP_SWAP2 = 0x4E;           // [1,0,3,2], [2,3,0,1]: the two butterfly steps of a reduction over a quad
+constexpr int QP_B0 = 0x00, QP_B1 = 0x55, QP_B2 = 0xAA, QP_B3 = 0xFF;      // broadcasts of lane 0 / 1 / 2 / 3
+
+// (value, index) candidates of the sixteen lanes -> index of the extreme, lowest index among equals, on all sixteen
+__device__ __forceinline__ void group_first_extreme(float v, int idx, bool want_max, int *out_idx) {
 #pragma unroll
-    for (int o = 1; o <= 2; o <<= 1) {
-        const float v2 = __shfl_xor(v, o, 4);
-        const int i2 = __shfl_xor(idx, o, 4);
+    for (int o = 1; o < GL; o <<= 1) {
+        const float v2 = __shfl_xor(v, o, GL);
+        const int i2 = __shfl_xor(idx, o, GL);
         const bool better = i2 >= 0 && (idx < 0 || (want_max ? v2 > v : v2 < v) || (v2 == v && i2 < idx));
         if (better) { v = v2; idx = i2; }
     }
     *out_idx = idx;
 }
 
-// sklansky() for one lane of a quad: the chain's three running points live in registers (one LDS read per step for the new point,
+// sklansky() for one lane of a group: the chain's three running points live in registers (one LDS read per step for the new point,
 // two when a point is popped) instead of five dependent reads per step; same comparisons and float operations
 __device__ int sklansky_reg(const F2 *a, int start, int end, int *stack, int nsign, int sign2) {
     const int incr = end > start ? 1 : -1;
@@ -2038,25 +2055,26 @@ __device__ int sklansky_reg(const F2 *a, int start, int end, int *stack, int nsi
     return --stacksize;
 }
 
-// convex_hull_sorted() with one Sklansky chain per lane; returns the hull size on the four lanes
+// convex_hull_sorted() with one Sklansky chain per lane (lanes 0..3 of the group); returns the hull size on the sixteen lanes
 __device__ int convex_hull_sorted_q4(const F2 *a, int n, F2 *hull, int (*stack)[Q_PTS + 2]) {
-    const int c = threadIdx.x & 3;
+    const int g = threadIdx.x & (GL - 1);
     float ylo = 0, yhi = 0;
     int ilo = -1, ihi = -1;
-    for (int i = c; i < n; i += 4) {                            // strict comparisons keep the first index of my subsequence
+    for (int i = g; i < n; i += GL) {                           // strict comparisons keep the first index of my subsequence
         const float y = a[i].y;
         if (ilo < 0 || y < ylo) { ylo = y; ilo = i; }
         if (ihi < 0 || y > yhi) { yhi = y; ihi = i; }
     }
     int miny_ind, maxy_ind;
-    quad_first_extreme(ylo, ilo, false, &miny_ind);
-    quad_first_extreme(yhi, ihi, true, &maxy_ind);
-    if (a[0].x == a[n - 1].x && a[0].y == a[n - 1].y) { if (c == 0) hull[0] = a[0]; wave_sync(); return 1; }
+    group_first_extreme(ylo, ilo, false, &miny_ind);
+    group_first_extreme(yhi, ihi, true, &maxy_ind);
+    if (a[0].x == a[n - 1].x && a[0].y == a[n - 1].y) { if (g == 0) hull[0] = a[0]; wave_sync(); return 1; }
     // lane 0: top-left chain, 1: top-right, 2: bottom-left, 3: bottom-right (convex_hull_sorted's four calls)
-    const int cnt = sklansky_reg(a, (c & 1) ? n - 1 : 0, c < 2 ? maxy_ind : miny_ind, stack[c], c < 2 ? -1 : 1, (c == 0 || c == 3) ? 1 : -1);
+    int cnt = 0;
+    if (g < 4) cnt = sklansky_reg(a, (g & 1) ? n - 1 : 0, g < 2 ? maxy_ind : miny_ind, stack[g], g < 2 ? -1 : 1, (g == 0 || g == 3) ? 1 : -1);
     wave_sync();
-    const int tl_count = __shfl(cnt, 0, 4), tr_count = __shfl(cnt, 1, 4);
-    int bl_count = __shfl(cnt, 3, 4), br_count = __shfl(cnt, 2, 4);       // the reference swaps the two bottom chains before it uses them
+    const int tl_count = __shfl(cnt, 0, GL), tr_count = __shfl(cnt, 1, GL);
+    int bl_count = __shfl(cnt, 3, GL), br_count = __shfl(cnt, 2, GL);     // the reference swaps the two bottom chains before it uses them
     const int *tl_stack = stack[0], *tr_stack = stack[1], *bl_stack = stack[3], *br_stack = stack[2];
     const int stop_idx = tr_count > 2 ? tr_stack[1] : tl_count > 2 ? tl_stack[tl_count - 2] : -1;
     if (stop_idx >= 0) {
@@ -2068,23 +2086,34 @@ __device__ int convex_hull_sorted_q4(const F2 *a, int n, F2 *hull, int (*stack)[
     }
     const int n0 = tl_count > 1 ? tl_count - 1 : 0, n1 = tr_count > 1 ? tr_count - 1 : 0;
     const int n2 = bl_count > 1 ? bl_count - 1 : 0, n3 = br_count > 1 ? br_count - 1 : 0;
-    if (c == 0) for (int i = 0; i < n0; i++) hull[i] = a[tl_stack[i]];
-    if (c == 1) for (int i = 0; i < n1; i++) hull[n0 + i] = a[tr_stack[tr_count - 1 - i]];
-    if (c == 2) for (int i = 0; i < n2; i++) hull[n0 + n1 + i] = a[bl_stack[i]];
-    if (c == 3) for (int i = 0; i < n3; i++) hull[n0 + n1 + n2 + i] = a[br_stack[br_count - 1 - i]];
+    const int total = n0 + n1 + n2 + n3;
+    // output element t of the hull, one per lane: the chain it belongs to and its place there (top-left forwards, top-right backwards,
+    // bottom-left forwards, bottom-right backwards)
+    for (int t = g; t < total; t += GL) {
+        int src;
+        if (t < n0) src = tl_stack[t];
+        else if (t < n0 + n1) src = tr_stack[tr_count - 1 - (t - n0)];
+        else if (t < n0 + n1 + n2) src = bl_stack[t - n0 - n1];
+        else src = br_stack[br_count - 1 - (t - n0 - n1 - n2)];
+        hull[t] = a[src];
+    }
     wave_sync();
-    return n0 + n1 + n2 + n3;
+    return total;
 }
 
-// rotating_calipers(): tables, extremes and orientation split over the four lanes; the walk itself identical on all four.  The
-// table holds (edge x, edge y, 1 / length, -) and the vertex side by side; a caliper's SUCCESSOR entry sits in registers, so the one
-// read a step needs (the new successor of the caliper that moved) is issued a whole step before its first possible use.
+// rotating_calipers(): tables, extremes and orientation split over the sixteen lanes; the walk ONE CALIPER PER LANE.  Caliper c (0 bottom,
+// 1 right, 2 top, 3 left) sees the base vector turned by c quarter turns: dp[c] = ca * vx + cb * vy with (ca, cb) = (a, b), (-b, a),
+// (-a, -b), (b, -a) -- the reference's four expressions term by term (a negation is exact and x - y == x + (-y)).  The winner is the FIRST
+// caliper that attains the largest cosine (the reference's strict `>` scan from 0).  The winner alone computes the new base from its
+// edge -- (lx, ly), (ly, -lx), (-lx, -ly), (-ly, lx) by caliper -- and the quad takes it as a bit pattern OR-ed across the lanes (the
+// others contribute zero bits: exact, signed zeros included).  A caliper's SUCCESSOR entry sits in registers, so the one read a step
+// needs (the new successor of the caliper that moved) is issued a whole step before its first possible use.
 struct CalEntry { float vx, vy, il, px, py; };
 __device__ void rotating_calipers_q4(const F2 *points, int n, float4 *ev, float *out) {
-    const int c = threadIdx.x & 3;
+    const int g = threadIdx.x & (GL - 1), c = g & 3;
     float lx = 0, rx = 0, ty = 0, by = 0;
     int li = -1, ri = -1, ti = -1, bi = -1;
-    for (int i = c; i < n; i += 4) {
+    for (int i = g; i < n; i += GL) {
         const F2 pt0 = points[i];
         if (li < 0 || pt0.x < lx) { lx = pt0.x; li = i; }
         if (ri < 0 || pt0.x > rx) { rx = pt0.x; ri = i; }
@@ -2095,66 +2124,74 @@ __device__ void rotating_calipers_q4(const F2 *points, int n, float4 *ev, float 
         ev[i] = make_float4((float)dx, (float)dy, (float)(1. / sqrt(dx * dx + dy * dy)), 0.f);
     }
     int left, right, top, bottom;
-    quad_first_extreme(lx, li, false, &left);
-    quad_first_extreme(rx, ri, true, &right);
-    quad_first_extreme(ty, ti, true, &top);
-    quad_first_extreme(by, bi, false, &bottom);
+    group_first_extreme(lx, li, false, &left);
+    group_first_extreme(rx, ri, true, &right);
+    group_first_extreme(ty, ti, true, &top);
+    group_first_extreme(by, bi, false, &bottom);
     wave_sync();
     // orientation: sign of the first non-zero turn (edge i-1 -> edge i), i = 0 .. n-1
     int first = 0x7fffffff;
     float orientation = 0;
-    for (int i = c; i < n && first == 0x7fffffff; i += 4) {
+    for (int i = g; i < n && first == 0x7fffffff; i += GL) {
         const float4 a = ev[i ? i - 1 : n - 1], b = ev[i];
         const double convexity = (double)a.x * (double)b.y - (double)a.y * (double)b.x;
         if (convexity != 0) { first = i; orientation = convexity > 0 ? 1.f : -1.f; }
     }
 #pragma unroll
-    for (int o = 1; o <= 2; o <<= 1) {
-        const int f2 = __shfl_xor(first, o, 4);
-        const float s2 = __shfl_xor(orientation, o, 4);
+    for (int o = 1; o < GL; o <<= 1) {
+        const int f2 = __shfl_xor(first, o, GL);
+        const float s2 = __shfl_xor(orientation, o, GL);
         if (f2 < first) { first = f2; orientation = s2; }
     }
     auto entry = [&](int i) { const float4 e = ev[i]; const F2 p = points[i]; CalEntry r; r.vx = e.x; r.vy = e.y; r.il = e.z; r.px = p.x; r.py = p.y; return r; };
     auto succ = [&](int i) { return i + 1 == n ? 0 : i + 1; };
+    auto bits = [](float v) { return __builtin_bit_cast(int, v); };
+    auto flt = [](int v) { return __builtin_bit_cast(float, v); };
+    // this lane's quarter turn: which of (a, b) it multiplies with vx / vy and with which sign; which of (lx, ly) its new base takes
+    const bool swap = (c & 1) != 0;
+    const int sgn_ca = (c == 1 || c == 2) ? (int)0x80000000 : 0, sgn_cb = c >= 2 ? (int)0x80000000 : 0;
+    const int sgn_na = c >= 2 ? (int)0x80000000 : 0, sgn_nb = (c == 1 || c == 2) ? (int)0x80000000 : 0;
+    const int my_bit = 1 << c, lower = my_bit - 1;
     float minarea = 3.402823466e+38f;
     float base_a = orientation, base_b = 0;
-    float buf_a = 0, buf_w = 0, buf_b = 0, buf_h = 0, bl_x = 0, bl_y = 0, bb_x = 0, bb_y = 0;
-    int s0 = bottom, s1 = right, s2 = top, s3 = left;
-    CalEntry e0 = entry(s0), e1 = entry(s1), e2 = entry(s2), e3 = entry(s3);
-    CalEntry n0 = entry(succ(s0)), n1 = entry(succ(s1)), n2 = entry(succ(s2)), n3 = entry(succ(s3));
+    float buf_a = 0, buf_w = 0, buf_b = 0, buf_h = 0, bpx = 0, bpy = 0;       // bpx / bpy: MY caliper's vertex at the best step
+    int s = c == 0 ? bottom : c == 1 ? right : c == 2 ? top : left;
+    CalEntry e = entry(s), nx = entry(succ(s));
     for (int k = 0; k < n; k++) {
-        float dp[4];
-        dp[0] = +base_a * e0.vx + base_b * e0.vy;
-        dp[1] = -base_b * e1.vx + base_a * e1.vy;
-        dp[2] = -base_a * e2.vx - base_b * e2.vy;
-        dp[3] = +base_b * e3.vx - base_a * e3.vy;
-        float maxcos = dp[0] * e0.il;
-        int main_element = 0;
-        { const float cc = dp[1] * e1.il; if (cc > maxcos) { main_element = 1; maxcos = cc; } }
-        { const float cc = dp[2] * e2.il; if (cc > maxcos) { main_element = 2; maxcos = cc; } }
-        { const float cc = dp[3] * e3.il; if (cc > maxcos) { main_element = 3; maxcos = cc; } }
-        const CalEntry em = main_element == 0 ? e0 : main_element == 1 ? e1 : main_element == 2 ? e2 : e3;
-        const float lead_x = em.vx * em.il, lead_y = em.vy * em.il;
-        base_a = main_element == 0 ? lead_x : main_element == 1 ? lead_y : main_element == 2 ? -lead_x : -lead_y;
-        base_b = main_element == 0 ? lead_y : main_element == 1 ? -lead_x : main_element == 2 ? -lead_y : lead_x;
-        const int sm = succ(main_element == 0 ? s0 : main_element == 1 ? s1 : main_element == 2 ? s2 : s3);
-        const CalEntry fresh = entry(succ(sm));                  // consumed in a later step at the earliest
-        if (main_element == 0) { s0 = sm; e0 = n0; n0 = fresh; }
-        else if (main_element == 1) { s1 = sm; e1 = n1; n1 = fresh; }
-        else if (main_element == 2) { s2 = sm; e2 = n2; n2 = fresh; }
-        else { s3 = sm; e3 = n3; n3 = fresh; }
-        float dx = e1.px - e3.px;
-        float dy = e1.py - e3.py;
+        const float ca = flt(bits(swap ? base_b : base_a) ^ sgn_ca), cb = flt(bits(swap ? base_a : base_b) ^ sgn_cb);
+        const float dp = ca * e.vx + cb * e.vy;
+        const float cosv = dp * e.il;
+        float m = cosv;
+        { const float o = qperm<QP_SWAP1>(m); m = o > m ? o : m; }
+        { const float o = qperm<QP_SWAP2>(m); m = o > m ? o : m; }
+        int eq = cosv == m ? my_bit : 0;
+        int mask = eq | qperm_i<QP_SWAP1>(eq);
+        mask |= qperm_i<QP_SWAP2>(mask);
+        const bool win = eq != 0 && (mask & lower) == 0;         // the first caliper at the maximum
+        const float lead_x = e.vx * e.il, lead_y = e.vy * e.il;
+        int na = win ? bits(swap ? lead_y : lead_x) ^ sgn_na : 0;
+        int nb = win ? bits(swap ? lead_x : lead_y) ^ sgn_nb : 0;
+        na |= qperm_i<QP_SWAP1>(na); na |= qperm_i<QP_SWAP2>(na);
+        nb |= qperm_i<QP_SWAP1>(nb); nb |= qperm_i<QP_SWAP2>(nb);
+        base_a = flt(na); base_b = flt(nb);
+        if (win) {
+            s = succ(s);
+            e = nx;
+            nx = entry(succ(s));                                 // consumed in a later step at the earliest
+        }
+        float dx = qperm<QP_B1>(e.px) - qperm<QP_B3>(e.px);
+        float dy = qperm<QP_B1>(e.py) - qperm<QP_B3>(e.py);
         const float width = dx * base_a + dy * base_b;
-        dx = e2.px - e0.px;
-        dy = e2.py - e0.py;
+        dx = qperm<QP_B2>(e.px) - qperm<QP_B0>(e.px);
+        dy = qperm<QP_B2>(e.py) - qperm<QP_B0>(e.py);
         const float height = -dx * base_b + dy * base_a;
         const float area = width * height;
         if (area <= minarea) {
             minarea = area;
-            bl_x = e3.px; bl_y = e3.py; buf_a = base_a; buf_w = width; buf_b = base_b; buf_h = height; bb_x = e0.px; bb_y = e0.py;
+            bpx = e.px; bpy = e.py; buf_a = base_a; buf_w = width; buf_b = base_b; buf_h = height;
         }
     }
+    const float bl_x = qperm<QP_B3>(bpx), bl_y = qperm<QP_B3>(bpy), bb_x = qperm<QP_B0>(bpx), bb_y = qperm<QP_B0>(bpy);
     const float A1 = buf_a, B1 = buf_b, A2 = -buf_b, B2 = buf_a;
     const float C1 = A1 * bl_x + bl_y * B1;
     const float C2 = A2 * bb_x + bb_y * B2;
@@ -2165,7 +2202,7 @@ __device__ void rotating_calipers_q4(const F2 *points, int n, float4 *ev, float 
     out[4] = A2 * buf_h; out[5] = B2 * buf_h;
 }
 
-// minAreaRect of A.pts[0 .. n) (sorted by (x, y)); the result is valid on all four lanes
+// minAreaRect of A.pts[0 .. n) (sorted by (x, y)); the result is valid on all sixteen lanes
 __device__ __forceinline__ void stamp(long long *st, int i) {
     if (st && (threadIdx.x & 63) == 0) st[i] = (long long)__builtin_amdgcn_s_memtime();
 }
@@ -2175,7 +2212,7 @@ __device__ __forceinline__ void stamp_rt(long long *st, int i) {
 }
 __device__ RRect min_area_rect_q4(QuadArena &A, int n, long long *st = nullptr) {
     RRect box; box.cx = box.cy = box.w = box.h = box.angle = 0.f;
-    if (n <= 0) return box;                                     // uniform over the quad
+    if (n <= 0) return box;                                     // uniform over the group
     const int hn = convex_hull_sorted_q4(A.pts, n, A.hull, A.stack);
     stamp(st, 0);
     if (hn > 2) {
@@ -2201,12 +2238,12 @@ __device__ RRect min_area_rect_q4(QuadArena &A, int n, long long *st = nullptr) 
     return box;
 }
 
-// clipper_offset_round() with one corner per lane.  OffsetPoint(j, k) names the previous corner k, and its early return (edges almost
-// in line) leaves k where it was: that chain is walked first, on the normals alone, by every lane; then lane j rounds corner j -- its
-// own atan2, its own X/Y recurrence, step after step as the reference -- and the lanes store their points behind each other.
+// clipper_offset_round() with one corner per lane (lanes 0..3 of the group).  OffsetPoint(j, k) names the previous corner k, and its early
+// return (edges almost in line) leaves k where it was: that chain is walked first, on the normals alone, by every lane; then lane j rounds
+// corner j -- its own atan2, its own X/Y recurrence, step after step as the reference -- and the lanes store their points behind each other.
 // Returns the number of points (> cap: nothing usable stored).
 __device__ int clipper_offset_round_q4(const CPt *path4, double delta, F2 *out, int cap, long long *ws) {
-    const int c = threadIdx.x & 3;
+    const int c = threadIdx.x & (GL - 1);                       // lanes 4..15 own no corner (c >= len below)
     const double pi = 3.141592653589793238, two_pi = pi * 2, def_arc = 0.25, arc_tol = 0.25;
     CPt *src = reinterpret_cast<CPt *>(ws);
     double *nx = reinterpret_cast<double *>(ws + 8), *ny = nx + 4;
@@ -2226,7 +2263,7 @@ __device__ int clipper_offset_round_q4(const CPt *path4, double delta, F2 *out, 
         }
     }
     wave_sync();
-    len = __shfl(len, 0, 4);
+    len = __shfl(len, 0, GL);
     if (len == 0) return 0;
     if (delta > -1.0e-20 && delta < 1.0e-20) {
         if (c == 0) for (int i = 0; i < len && i < cap; i++) { out[i].x = (float)src[i].X; out[i].y = (float)src[i].Y; }
@@ -2289,7 +2326,7 @@ __device__ int clipper_offset_round_q4(const CPt *path4, double delta, F2 *out, 
     int off = 0, total = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const int cq = __shfl(cnt, q, 4);
+        const int cq = __shfl(cnt, q, GL);
         if (q < c) off += cq;
         total += cq;
     }
@@ -2795,7 +2832,7 @@ struct StageArgs {
 //     `score < box_thresh` filter (db_postprocess.cpp:272); a mask's rows are independent (the crossing parity never leaves a row).
 // border_stage_kernel runs all three as ROLES of one launch, in grid order: hull blocks, quad blocks, score blocks.
 //   * hull role: one wave per border; the candidates go out as device-scope stores, then the border's ready word.
-//   * quad role: four lanes per border, four borders per wave; a quad polls its border's ready word (written by a block that was
+//   * quad role: sixteen lanes per border, four borders per wave; a quad polls its border's ready word (written by a block that was
 //     dispatched BEFORE it -- workgroups are dispatched in grid order, so what a quad waits for is running or done; the wait is
 //     bounded all the same: a quad that gives up defers its border to the full-size pass) and starts while other hulls and the
 //     scores are still being computed: the launch lasts about as long as hull + geometry of one border, not hull of all, then score
@@ -2921,18 +2958,18 @@ __device__ __forceinline__ void score_band_item(const StageArgs &a, const Dbpost
     if (band == 0 || nb > 1) stamp_rt(ts, 1);
 }
 
-// ---- quad role: FOUR LANES per border, QUADS borders per wave (quad-lane primitives above); lanes beyond the quads leave at once
+// ---- quad role: SIXTEEN LANES per border, QUADS borders per wave (group-lane primitives above)
 __device__ __forceinline__ void border_quad_body(const StageArgs &a, const DbpostDims &d, int img, int group, QuadArena *arena) {
     const int num = min(a.totals[img], MAX_CAND);
-    const int c = threadIdx.x & 3, qi = threadIdx.x >> 2;
+    const int c = threadIdx.x & (GL - 1), qi = threadIdx.x / GL;       // c: lane of the border's group
     const int k = group * QUADS + qi;
-    if (qi >= QUADS || k >= num) return;                        // whole quads leave; nothing below spans quads
+    if (qi >= QUADS || k >= num) return;                        // whole groups leave; nothing below spans groups
     const long bi = (long)img * MAX_CAND + k;
     // wait for the hull role's word of this call: epoch << 9 | count << 2 | state; state 1 = candidates are out, 2 = the border ended there
     int word = 0, spins = 0;
     for (;;) {
         if (c == 0) word = __hip_atomic_load(&a.ready[bi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        word = __shfl(word, 0, 4);
+        word = __shfl(word, 0, GL);
         if ((word >> 9) == a.epoch) break;
         if (++spins > READY_SPINS) break;
         __builtin_amdgcn_s_sleep(32);
@@ -2951,7 +2988,7 @@ __device__ __forceinline__ void border_quad_body(const StageArgs &a, const Dbpos
     // recomputes it from its states: a violated hand-off costs time, never a wrong box and never an index out of range.
     const int n = (word >> 2) & 127;
     bool bad = n > Q_PTS;
-    for (int i = c; i < n && !bad; i += 4) {
+    for (int i = c; i < n && !bad; i += GL) {
         const unsigned long long *src = reinterpret_cast<const unsigned long long *>(a.hin + bi * S_MH + i);
         unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int tries = 0; (unsigned)(v >> 32) != (unsigned)a.epoch && tries < POINT_SPINS; tries++) {
@@ -2961,7 +2998,7 @@ __device__ __forceinline__ void border_quad_body(const StageArgs &a, const Dbpos
         if ((unsigned)(v >> 32) != (unsigned)a.epoch) bad = true;
         A.pts[i].x = (float)(int)((unsigned)v & 0xffffu); A.pts[i].y = (float)(int)(((unsigned)v >> 16) & 0xffffu);
     }
-    bad = ((__ballot(bad) >> (4 * qi)) & 0xfull) != 0;          // any lane of this quad (the quads are lanes 0 .. 4 QUADS - 1 of the wave)
+    bad = ((__ballot(bad) >> (GL * qi)) & 0xffffull) != 0;      // any lane of this group
     if (bad) {
         if (c == 0) { res->status = ST_DEFER; atomicOr(&a.flags[img], 8); }
         return;
@@ -2999,24 +3036,26 @@ __device__ __forceinline__ void border_quad_body(const StageArgs &a, const Dbpos
         if (np > 0 && np <= Q_PTS && distance < UNION_MAX_DISTANCE) {              // Execute's union: sub-pixel slivers only
             if (c == 0) np = clipper_union_cut(raw, np, A.pts, &A.stack[0][0]);
             wave_sync();
-            np = __shfl(np, 0, 4);
+            np = __shfl(np, 0, GL);
         }
         if (np > Q_PTS) { status = ST_DEFER; if (c == 0) atomicOr(&a.flags[img], 8); }
         else {
-            // sort by (x, y) like cv::convexHull: every lane ranks a quarter of the points.  The offset polygon has integer vertices, so a
+            // sort by (x, y) like cv::convexHull: every lane ranks up to four of the points.  The offset polygon has integer vertices, so a
             // point packs into one 64-bit key (x + 2^20) << 40 | (y + 2^20) << 8 | index -- the index makes equal points keep their order
             // (they are identical anyway) -- and its rank is the number of smaller keys: one compare and one add per pair
             {
                 unsigned long long *keys = reinterpret_cast<unsigned long long *>(A.ev);      // the caliper table is not in use yet
-                for (int i = c; i < np; i += 4) {
+                for (int i = c; i < np; i += GL) {
                     const F2 t = raw[i];
                     keys[i] = ((unsigned long long)((int)t.x + (1 << 20)) << 40) | ((unsigned long long)((int)t.y + (1 << 20)) << 8) | (unsigned)i;
                 }
                 wave_sync();
-                for (int i0 = c; i0 < np; i0 += 16) {
+                static_assert(4 * GL >= Q_PTS, "a lane ranks at most four keys");
+                {
+                    const int i0 = c < np ? c : 0;               // (a lane beyond the list ranks key 0 again and stores nothing)
                     unsigned long long t[4]; int rank[4] = {0, 0, 0, 0};
 #pragma unroll
-                    for (int u = 0; u < 4; u++) t[u] = keys[i0 + 4 * u < np ? i0 + 4 * u : i0];
+                    for (int u = 0; u < 4; u++) t[u] = keys[i0 + GL * u < np ? i0 + GL * u : i0];
                     for (int j0 = 0; j0 < np; j0 += 8) {
                         unsigned long long o[8];
 #pragma unroll
@@ -3027,7 +3066,7 @@ __device__ __forceinline__ void border_quad_body(const StageArgs &a, const Dbpos
                             for (int u = 0; u < 4; u++) rank[u] += o[v] < t[u] ? 1 : 0;
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; u++) if (i0 + 4 * u < np) A.pts[rank[u]] = raw[i0 + 4 * u];
+                    for (int u = 0; u < 4; u++) if (c + GL * u < np) A.pts[rank[u]] = raw[c + GL * u];
                 }
             }
             wave_sync();
@@ -3045,8 +3084,11 @@ __device__ __forceinline__ void border_quad_body(const StageArgs &a, const Dbpos
 
 // One launch, three roles, in grid order: N * STAGE_GRID hull blocks, N * QUAD_BLOCKS quad blocks, N * SCORE_GRID score blocks.
 // (the hull role needs 32 VGPRs and the 8 KB column tables, the score role 2 KB and registers for loads in flight, the quad role
-// 13 KB and ~150 VGPRs: one LDS block and three waves per SIMD for all)
-__global__ __launch_bounds__(WAVE_NT) void border_stage_kernel(StageArgs a, DbpostDims d) {
+// 9 KB: one LDS block for all)
+#ifndef PT_STAGE_WAVES
+#define PT_STAGE_WAVES 4                    // waves per SIMD the stage kernel is compiled for (128 VGPRs): the launch is bound by wave slots
+#endif
+__global__ __launch_bounds__(WAVE_NT, PT_STAGE_WAVES) void border_stage_kernel(StageArgs a, DbpostDims d) {
     constexpr int ARENA_BYTES = (int)(QUADS * sizeof(QuadArena)) > 8 * W_MW ? (int)(QUADS * sizeof(QuadArena)) : 8 * W_MW;
     static_assert(8 * W_MW >= 8 * BAND_WORDS, "the column tables hold the two mask planes of a band");
     __shared__ __attribute__((aligned(16))) unsigned char arena_raw[ARENA_BYTES];

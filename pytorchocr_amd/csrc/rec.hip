@@ -45,9 +45,16 @@ __device__ __forceinline__ float tanhf_(float x) { return tanhf(x); }
 // timed-out exchange (*only_if != 0) and then recomputes the whole layer; otherwise every workgroup exits at once.
 __global__ __launch_bounds__(256) void lstm_bidir_kernel(const float *__restrict__ xproj, const float *__restrict__ whh,
                                                          float *__restrict__ out, int T, int B, long x_bytes,
-                                                         const int *__restrict__ only_if, int *__restrict__ repaired) {
+                                                         const int *__restrict__ only_if, int *__restrict__ repaired, int expect_fast) {
     __shared__ __attribute__((aligned(16))) float hbuf[2][LROWS][HLD];
     if (only_if) {
+        // book-keeping of the split call this launch follows on the stream: only_if[1] = workgroups that took the same-XCD exchange;
+        // a call counts as "same XCD" when EVERY workgroup of EVERY pair did (repaired[1]), and the workgroups are added up (repaired[2])
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+            const int nf = __hip_atomic_load(only_if + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (nf == expect_fast) __hip_atomic_fetch_add(repaired + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(repaired + 2, nf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (__hip_atomic_load(only_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
         if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
             __hip_atomic_fetch_add(repaired, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -225,7 +232,8 @@ __device__ __forceinline__ void lstm_split_part(const float *__restrict__ xproj,
         u64 *xid = hx + (long)npairs * 2 * LROWS * LH + (long)g2 * LPARTS;
         const unsigned mine = (unsigned)__builtin_amdgcn_s_getreg(LSTM_XCC_GETREG) & 15u;
         __hip_atomic_store(xid + part, (1ull << 32) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int fast = colocate;
+        int fast = colocate & 1;
+        if ((colocate & 2) && part == 1) fast = 0;                          // test hook: one part of every pair on the write-through stores
         for (int q = 0; q < LPARTS && fast; q++) {
             u64 v = 0;
             for (unsigned spins = 0; spins < (spin_limit < 4096u ? spin_limit : 4096u); spins++) {
@@ -236,7 +244,7 @@ __device__ __forceinline__ void lstm_split_part(const float *__restrict__ xproj,
             if (!(v >> 32) || (unsigned)v != mine) fast = 0;
         }
         wg_fast = fast;
-        if (fast && part == 0 && g2 == 0) atomicAdd(stats + 1, 1);          // (one word per call: pair 0 stands for the launch)
+        if (fast) __hip_atomic_fetch_add(err + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // per call; the repair launch behind it does the book-keeping
     }
     float c[4] = {0.f, 0.f, 0.f, 0.f};
     f32x4 xnext[4];
@@ -435,7 +443,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bidir_split_kernel(const float *_
     __shared__ int wg_failed, wg_fast;
     if (threadIdx.x == 0) wg_failed = 0;
     int part, g2;
-    if (colocate) {
+    if (colocate & 1) {
         const int slot = blockIdx.x >> 3;
         g2 = (slot >> 2) * 8 + (int)(blockIdx.x & 7);
         part = slot & 3;
@@ -527,6 +535,7 @@ std::map<std::pair<int, void *>, LstmCtx> g_lstm_ctx;
 std::map<int, int> g_lstm_ncu;
 std::map<int, int *> g_lstm_repaired;      // per device: device word counting split calls recomputed by the exchange-free pass
 int g_lstm_split_calls = 0;
+std::map<int, long long> g_lstm_split_wgs;  // per device: workgroups of the split calls so far
 unsigned g_lstm_spin_limit = 1u << 16;     // polls of one exchange before a workgroup gives up (~0.1 s)
 #ifdef LSTM_STAMPS
 constexpr size_t LSTM_STAMP_BYTES = 4096 * 16 * 8 * 8;      // up to 4096 steps x 16 waves x 8 stamps
@@ -565,6 +574,22 @@ extern "C" int ptocr_lstm_stats(int *split_calls, int *repaired) {
 
 // split-form calls (since the library was loaded, on the current device) whose workgroups found their partners on their own XCD and exchanged
 // h through that XCD's L2 (exact once the streams those calls went to have been synchronised)
+int g_lstm_colocate = -1;                   // -1: PTOCR_LSTM_COLOCATE (default on); 0 / 1; 3: on, part 1 of every pair forced onto the write-through stores
+extern "C" void ptocr_lstm_set_colocate(int mode) { g_lstm_colocate = mode; }
+
+// workgroups of split-form calls (current device) that exchanged h through their XCD's L2, and how many workgroups those calls had
+extern "C" int ptocr_lstm_fast_workgroups(long long *fast, long long *all) {
+    PT_CHECK(fast && all, "ptocr_lstm_fast_workgroups: null argument");
+    std::lock_guard<std::mutex> lk(g_lstm_mu);
+    *fast = 0;
+    int dev = 0, v = 0;
+    PT_HIP(hipGetDevice(&dev));
+    *all = g_lstm_split_wgs[dev];
+    auto it = g_lstm_repaired.find(dev);
+    if (it != g_lstm_repaired.end() && it->second) { PT_HIP(hipMemcpy(&v, it->second + 2, sizeof(int), hipMemcpyDeviceToHost)); *fast = v; }
+    return 0;
+}
+
 extern "C" int ptocr_lstm_same_xcd_calls(int *calls) {
     PT_CHECK(calls, "ptocr_lstm_same_xcd_calls: null argument");
     std::lock_guard<std::mutex> lk(g_lstm_mu);
@@ -621,18 +646,20 @@ extern "C" int ptocr_lstm_bidir_f32(const float *d_xproj, const float *d_whh, fl
         }
         PT_HIP(hipMemsetAsync(c.hx, 0, sizeof(u64) * ((size_t)groups * 2 * 2 * LROWS * LH + (size_t)groups * 2 * LPARTS), s));       // tags must not survive a call
         PT_HIP(hipMemsetAsync(c.err, 0, 64, s));
-        static const int colocate = !(getenv("PTOCR_LSTM_COLOCATE") && atoi(getenv("PTOCR_LSTM_COLOCATE")) == 0);
+        static const int colocate_env = !(getenv("PTOCR_LSTM_COLOCATE") && atoi(getenv("PTOCR_LSTM_COLOCATE")) == 0);
+        const int colocate = g_lstm_colocate < 0 ? colocate_env : g_lstm_colocate;
         const int npairs = groups * 2;
+        g_lstm_split_wgs[dev] += (long long)npairs * LPARTS;
         hipLaunchKernelGGL(lstm_bidir_split_kernel, dim3((unsigned)(cdiv(npairs, 8) * 8 * LPARTS)), dim3(256), 0, s, d_xproj, d_whh, d_out, c.hx, c.err, T, B,
                            x_bytes, g_lstm_spin_limit, npairs, colocate, d_stats);
         if (int e = launch_ok("lstm_bidir_split_kernel")) return e;
         hipLaunchKernelGGL(lstm_bidir_kernel, dim3(groups, 2), dim3(256), 0, s, d_xproj, d_whh, d_out, T, B, x_bytes,
-                           (const int *)c.err, d_stats);
+                           (const int *)c.err, d_stats, npairs * LPARTS);
         g_lstm_split_calls++;
         return launch_ok("lstm_bidir_kernel (repair pass)");
     }
     hipLaunchKernelGGL(lstm_bidir_kernel, dim3(groups, 2), dim3(256), 0, s, d_xproj, d_whh, d_out, T, B, x_bytes,
-                       (const int *)nullptr, (int *)nullptr);
+                       (const int *)nullptr, (int *)nullptr, 0);
     return launch_ok("lstm_bidir_kernel");
 }
 

@@ -115,6 +115,59 @@ def test_lstm_split_exchange_timeout_is_repaired_on_the_stream():
     ops_mod.lstm_check()
 
 
+def test_lstm_split_placements_agree_and_the_fast_path_is_taken():
+    """The split LSTM on its three exchange forms -- default (the four parts of a pair on one XCD, workgroup-scope stores into that XCD's
+    L2), PTOCR_LSTM_COLOCATE=0 (round-4 layout, write-through stores) and the mixed form (part 1 of every pair forced onto the
+    write-through stores: what a workgroup that finds a foreign XCC id among its partners does) -- must give bit-equal outputs, equal to
+    the exchange-free kernel within its summation order (2e-5), with no repair; and the default run must actually TAKE the same-XCD path
+    on every workgroup of every pair (the counter is per workgroup, not pair 0 only)."""
+    import ctypes as C
+    from pytorchocr_amd import _lib
+    from pytorchocr_amd.modeling.necks.rnn import BidirectionalLSTM
+    L = _lib.lib()
+    L.ptocr_lstm_set_colocate.restype = None
+
+    def stats():
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        f, n = C.c_longlong(0), C.c_longlong(0)
+        torch.cuda.synchronize()
+        _lib.check(L.ptocr_lstm_stats(C.byref(a), C.byref(b)))
+        _lib.check(L.ptocr_lstm_same_xcd_calls(C.byref(c)))
+        _lib.check(L.ptocr_lstm_fast_workgroups(C.byref(f), C.byref(n)))
+        return a.value, b.value, c.value, f.value, n.value
+
+    torch.manual_seed(5)
+    B, T, nin = 512, 40, 256                      # 32 groups x 2 directions x 4 parts = 256 workgroups: every CU
+    blk = BidirectionalLSTM(nin, 256, 256).eval()
+    p = blk.pack(torch.device("cuda:0"))
+    xb_big = torch.randn(B + 16, T, nin).cuda()   # 33 groups do not fit the chip four ways: the exchange-free kernel runs
+    xb = xb_big[:B].contiguous().reshape(B * T, nin)
+    s0 = stats()
+    free = BidirectionalLSTM.run(p, xb_big.reshape((B + 16) * T, nin), B + 16, T).reshape(B + 16, T, 256)[:B]
+    s1 = stats()
+    assert s1[0] == s0[0], "the 33-group call was expected on the exchange-free kernel"
+    outs = {}
+    try:
+        for mode in (1, 0, 3):
+            L.ptocr_lstm_set_colocate(mode)
+            before = stats()
+            outs[mode] = BidirectionalLSTM.run(p, xb, B, T).reshape(B, T, 256).clone()
+            after = stats()
+            assert after[0] == before[0] + 1 and after[1] == before[1], "mode %d: not a split call, or repaired" % mode
+            wgs, fast, same = after[4] - before[4], after[3] - before[3], after[2] - before[2]
+            assert wgs == 256
+            if mode == 1:
+                assert fast == 256 and same == 1, "default placement: %d of 256 workgroups on the same-XCD exchange (calls counted %d)" % (fast, same)
+            elif mode == 0:
+                assert fast == 0 and same == 0
+            else:
+                assert fast == 192 and same == 0, "mixed form: %d workgroups fast" % fast
+    finally:
+        L.ptocr_lstm_set_colocate(-1)
+    assert torch.equal(outs[1], outs[0]) and torch.equal(outs[1], outs[3]), "the exchange forms differ"
+    assert (outs[1] - free).abs().max().item() <= 2e-5
+
+
 def test_crnn_matches_reference_golden(gold_dir, contract):
     g = np.load(os.path.join(gold_dir, "crnn_3x1x32x320.npz"))
     m, _ = _model(contract)
