@@ -2011,7 +2011,7 @@ __device__ __forceinline__ void group_first_extreme(float v, int idx, bool want_
 
 // sklansky() for one lane of a group: the chain's three running points live in registers (one LDS read per step for the new point,
 // two when a point is popped) instead of five dependent reads per step; same comparisons and float operations
-__device__ int sklansky_reg(const F2 *a, int start, int end, int *stack, int nsign, int sign2) {
+__device__ __forceinline__ int sklansky_reg(const F2 *a, int start, int end, int *stack, int nsign, int sign2) {
     const int incr = end > start ? 1 : -1;
     int pprev = start, pcur = pprev + incr, pnext = pcur + incr;
     int stacksize = 3;
@@ -2056,7 +2056,7 @@ __device__ int sklansky_reg(const F2 *a, int start, int end, int *stack, int nsi
 }
 
 // convex_hull_sorted() with one Sklansky chain per lane (lanes 0..3 of the group); returns the hull size on the sixteen lanes
-__device__ int convex_hull_sorted_q4(const F2 *a, int n, F2 *hull, int (*stack)[Q_PTS + 2]) {
+__device__ __forceinline__ int convex_hull_sorted_q4(const F2 *a, int n, F2 *hull, int (*stack)[Q_PTS + 2]) {
     const int g = threadIdx.x & (GL - 1);
     float ylo = 0, yhi = 0;
     int ilo = -1, ihi = -1;
@@ -2109,7 +2109,7 @@ __device__ int convex_hull_sorted_q4(const F2 *a, int n, F2 *hull, int (*stack)[
 // others contribute zero bits: exact, signed zeros included).  A caliper's SUCCESSOR entry sits in registers, so the one read a step
 // needs (the new successor of the caliper that moved) is issued a whole step before its first possible use.
 struct CalEntry { float vx, vy, il, px, py; };
-__device__ void rotating_calipers_q4(const F2 *points, int n, float4 *ev, float *out) {
+__device__ __forceinline__ void rotating_calipers_q4(const F2 *points, int n, float4 *ev, float *out) {
     const int g = threadIdx.x & (GL - 1), c = g & 3;
     float lx = 0, rx = 0, ty = 0, by = 0;
     int li = -1, ri = -1, ti = -1, bi = -1;
@@ -2210,7 +2210,7 @@ __device__ __forceinline__ void stamp(long long *st, int i) {
 __device__ __forceinline__ void stamp_rt(long long *st, int i) {
     if (st && (threadIdx.x & 63) == 0) st[i] = (long long)__builtin_amdgcn_s_memrealtime();
 }
-__device__ RRect min_area_rect_q4(QuadArena &A, int n, long long *st = nullptr) {
+__device__ __forceinline__ RRect min_area_rect_q4(QuadArena &A, int n, long long *st = nullptr) {
     RRect box; box.cx = box.cy = box.w = box.h = box.angle = 0.f;
     if (n <= 0) return box;                                     // uniform over the group
     const int hn = convex_hull_sorted_q4(A.pts, n, A.hull, A.stack);
@@ -2242,7 +2242,7 @@ __device__ RRect min_area_rect_q4(QuadArena &A, int n, long long *st = nullptr) 
 // return (edges almost in line) leaves k where it was: that chain is walked first, on the normals alone, by every lane; then lane j rounds
 // corner j -- its own atan2, its own X/Y recurrence, step after step as the reference -- and the lanes store their points behind each other.
 // Returns the number of points (> cap: nothing usable stored).
-__device__ int clipper_offset_round_q4(const CPt *path4, double delta, F2 *out, int cap, long long *ws) {
+__device__ __forceinline__ int clipper_offset_round_q4(const CPt *path4, double delta, F2 *out, int cap, long long *ws) {
     const int c = threadIdx.x & (GL - 1);                       // lanes 4..15 own no corner (c >= len below)
     const double pi = 3.141592653589793238, two_pi = pi * 2, def_arc = 0.25, arc_tol = 0.25;
     CPt *src = reinterpret_cast<CPt *>(ws);
@@ -2274,8 +2274,9 @@ __device__ int clipper_offset_round_q4(const CPt *path4, double delta, F2 *out, 
     if (arc_tol > fabs(delta) * def_arc) yv = fabs(delta) * def_arc; else yv = arc_tol;
     double steps = pi / acos(1 - yv / fabs(delta));
     if (steps > fabs(delta) * pi) steps = fabs(delta) * pi;
-    double m_sin = sin(two_pi / steps);
-    const double m_cos = cos(two_pi / steps);
+    // (one range reduction for both: the device libm's sincos is bit-identical to its sin and cos -- tools/dbg/sincos_probe.hip, 2^28 arguments)
+    double m_sin, m_cos;
+    sincos(two_pi / steps, &m_sin, &m_cos);
     const double steps_per_rad = steps / two_pi;
     if (delta < 0.0) m_sin = -m_sin;
     if (c < len) {
@@ -2333,21 +2334,26 @@ __device__ int clipper_offset_round_q4(const CPt *path4, double delta, F2 *out, 
     if (total > cap) return total;
     if (c < len) {
         int pos = off;
-#define PT_PUSHQ(px, py) do { out[pos].x = (float)(px); out[pos].y = (float)(py); pos++; } while (0)
-        if (kind == 0) PT_PUSHQ(cl_round(src[j].X + nx[k] * delta), cl_round(src[j].Y + ny[k] * delta));
+        // cl_round() and the float store of a coordinate: v -> (long long)(v -+ 0.5) -> float.  The coordinates are bounded by the map
+        // (|v| < 2^20), so the truncation to int (one instruction; the 64-bit conversions are emulated: ~30 each) gives the same integer
+        // and the same float; the corner as doubles once, not per point
+        auto rf = [](double v) { return (float)(int)(v < 0 ? v - 0.5 : v + 0.5); };
+        const double sx = (double)src[j].X, sy = (double)src[j].Y;
+#define PT_PUSHQ(px, py) do { out[pos].x = (px); out[pos].y = (py); pos++; } while (0)
+        if (kind == 0) PT_PUSHQ(rf(sx + nx[k] * delta), rf(sy + ny[k] * delta));
         else if (kind == 1) {
-            PT_PUSHQ(cl_round(src[j].X + nx[k] * delta), cl_round(src[j].Y + ny[k] * delta));
-            PT_PUSHQ(src[j].X, src[j].Y);
-            PT_PUSHQ(cl_round(src[j].X + nx[j] * delta), cl_round(src[j].Y + ny[j] * delta));
+            PT_PUSHQ(rf(sx + nx[k] * delta), rf(sy + ny[k] * delta));
+            PT_PUSHQ((float)sx, (float)sy);
+            PT_PUSHQ(rf(sx + nx[j] * delta), rf(sy + ny[j] * delta));
         } else {
             double X = nx[k], Y = ny[k], X2;
             for (int s = 0; s < nsteps; ++s) {
-                PT_PUSHQ(cl_round(src[j].X + X * delta), cl_round(src[j].Y + Y * delta));
+                PT_PUSHQ(rf(sx + X * delta), rf(sy + Y * delta));
                 X2 = X;
                 X = X * m_cos - m_sin * Y;
                 Y = X2 * m_sin + Y * m_cos;
             }
-            PT_PUSHQ(cl_round(src[j].X + nx[j] * delta), cl_round(src[j].Y + ny[j] * delta));
+            PT_PUSHQ(rf(sx + nx[j] * delta), rf(sy + ny[j] * delta));
         }
 #undef PT_PUSHQ
     }
@@ -2469,6 +2475,9 @@ __device__ void score_mask(const unsigned *st, int n, int xmin, int ymin, int bw
             // UF of them are in flight per lane.  The stage is a chain of memory round trips, not bytes (round 4: a 256-word band took a
             // wave eight dependent trips at UF = 4, 7 us median and 47 us in the tail), so the loads are straight-line code -- every
             // lane loads, from a harmless address when its nibble is empty -- and the word index advances without a division.
+            // (round 6, measured and dropped: the first round's loads requested by geometry BEFORE the mask is built, so that the item's two
+            // memory round trips -- states, then pixels -- overlap: 8 loads ahead 72.5 -> 76.0 us for the stage launch, 16 ahead 97 us; the
+            // role is bound by the scattered 16-byte requests it issues, and the nibbles outside the polygons are requests too)
             struct __attribute__((packed, aligned(4))) F4 { float v[4]; };
             const int grp = tid >> 3, q = tid & 7;
             const int ng = nt >> 3, nw = rows * pw;
@@ -2895,6 +2904,7 @@ __device__ __forceinline__ void border_hull_body(const StageArgs &a, const Dbpos
 }
 
 // ---- score role: one band of one border (one wave)
+template <int UF = SCORE_UF>
 __device__ __forceinline__ void score_band_item(const StageArgs &a, const DbpostDims &d, int img, int item, unsigned *planes) {
     const int tid = threadIdx.x;
     const int *off = a.sc_off + (long)img * MAX_CAND;
@@ -2913,7 +2923,7 @@ __device__ __forceinline__ void score_band_item(const StageArgs &a, const Dbpost
     long long *ts = a.stamps ? a.stamps + ((long)img * MAX_CAND + k) * 16 + 14 : nullptr;   // slots 14..15: band 0 of the border
     if (band == 0) stamp_rt(ts, 0);
     double total; int npix;
-    score_mask<SCORE_UF>(st, ac.nstates, ac.xmin, ac.ymin, bw, bh, band * R, min(bh, band * R + R), planes, planes + BAND_WORDS, BAND_WORDS, pimg, d.W, red_d, red_i,
+    score_mask<UF>(st, ac.nstates, ac.xmin, ac.ymin, bw, bh, band * R, min(bh, band * R + R), planes, planes + BAND_WORDS, BAND_WORDS, pimg, d.W, red_d, red_i,
                false, &total, &npix, (a.stamps && band < 2 && img >= 4) ? a.stamps + ((long)img * MAX_CAND + k) * 16 + band * 6 : nullptr);    // (records the quads do not use)
     if (a.stamps && band < 2 && img >= 4) stamp_rt(a.stamps + ((long)img * MAX_CAND + k) * 16 + band * 6, 5);
     if (nb > 1) {
@@ -2946,7 +2956,7 @@ __device__ __forceinline__ void score_band_item(const StageArgs &a, const Dbpost
     int tie = 0;
     if (fabs((double)score - (double)a.box_thresh) <= 1e-6) {   // uniform: within rounding of the filter -> cv::mean's raster order decides
         double t2; int dummy;
-        score_mask<SCORE_UF>(st, ac.nstates, ac.xmin, ac.ymin, bw, bh, 0, bh, planes, planes + BAND_WORDS, BAND_WORDS, pimg, d.W, red_d, red_i, true, &t2, &dummy);
+        score_mask<UF>(st, ac.nstates, ac.xmin, ac.ymin, bw, bh, 0, bh, planes, planes + BAND_WORDS, BAND_WORDS, pimg, d.W, red_d, red_i, true, &t2, &dummy);
         __shared__ double sh_tie;
         if (tid == 0) sh_tie = t2;
         __syncthreads();
@@ -3004,17 +3014,24 @@ __device__ __forceinline__ void border_quad_body(const StageArgs &a, const Dbpos
         return;
     }
     wave_sync();
-    // minAreaRect of the border, mini-box, first size filter (db_postprocess.cpp:259-265)
+    // minAreaRect of the border, mini-box, first size filter (db_postprocess.cpp:259-265); then UnClip and the minAreaRect of the offset
+    // polygon.  The two rectangles are the two passes of ONE loop, so that the whole geometry is inlined once and every table access is
+    // an LDS instruction (round 6: as a called function the arena was a generic pointer -- flat loads, each waited for at once).
     stamp(st, 1);
-    const RRect box = min_area_rect_q4(A, n, st ? st + 2 : nullptr);      // 2: hull, 3: calipers
-    stamp(st, 4);
-    float mini[4][2], ssid;
-    get_mini_boxes(box, mini, &ssid);
-    stamp(st, 5);
-    if (c == 0) { res->rect[0] = box.cx; res->rect[1] = box.cy; res->rect[2] = box.w; res->rect[3] = box.h; res->rect[4] = box.angle; }
-    int status;
-    if (ssid < 3) status = ST_SKIP_SSID;                        // min_size
-    else {
+    int status = -1;                                            // -1: the second rectangle decides (unclip_box)
+    int npts = n;
+    RRect box;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+        if (pass == 1 && npts <= 0) { box.cx = 0; box.cy = 0; box.w = 1; box.h = 1; box.angle = 0; }
+        else box = min_area_rect_q4(A, npts, st ? st + (pass ? 8 : 2) : nullptr);      // stamps 2 / 8: hull, 3 / 9: calipers
+        if (pass == 1) break;
+        stamp(st, 4);
+        float mini[4][2], ssid;
+        get_mini_boxes(box, mini, &ssid);
+        stamp(st, 5);
+        if (c == 0) { res->rect[0] = box.cx; res->rect[1] = box.cy; res->rect[2] = box.w; res->rect[3] = box.h; res->rect[4] = box.angle; }
+        if (ssid < 3) { status = ST_SKIP_SSID; break; }         // min_size
         // (the score filter of db_postprocess.cpp:272 sits here in the reference: compact_kernel applies it)
         // UnClip (db_postprocess.cpp:16-49): distance from the float mini-box, Clipper's round offset of its truncated vertices
         float area = 0.0f, dist = 0.0f;
@@ -3038,46 +3055,42 @@ __device__ __forceinline__ void border_quad_body(const StageArgs &a, const Dbpos
             wave_sync();
             np = __shfl(np, 0, GL);
         }
-        if (np > Q_PTS) { status = ST_DEFER; if (c == 0) atomicOr(&a.flags[img], 8); }
-        else {
-            // sort by (x, y) like cv::convexHull: every lane ranks up to four of the points.  The offset polygon has integer vertices, so a
-            // point packs into one 64-bit key (x + 2^20) << 40 | (y + 2^20) << 8 | index -- the index makes equal points keep their order
-            // (they are identical anyway) -- and its rank is the number of smaller keys: one compare and one add per pair
-            {
-                unsigned long long *keys = reinterpret_cast<unsigned long long *>(A.ev);      // the caliper table is not in use yet
-                for (int i = c; i < np; i += GL) {
-                    const F2 t = raw[i];
-                    keys[i] = ((unsigned long long)((int)t.x + (1 << 20)) << 40) | ((unsigned long long)((int)t.y + (1 << 20)) << 8) | (unsigned)i;
-                }
-                wave_sync();
-                static_assert(4 * GL >= Q_PTS, "a lane ranks at most four keys");
-                {
-                    const int i0 = c < np ? c : 0;               // (a lane beyond the list ranks key 0 again and stores nothing)
-                    unsigned long long t[4]; int rank[4] = {0, 0, 0, 0};
-#pragma unroll
-                    for (int u = 0; u < 4; u++) t[u] = keys[i0 + GL * u < np ? i0 + GL * u : i0];
-                    for (int j0 = 0; j0 < np; j0 += 8) {
-                        unsigned long long o[8];
-#pragma unroll
-                        for (int v = 0; v < 8; v++) o[v] = j0 + v < np ? keys[j0 + v] : ~0ull;
-#pragma unroll
-                        for (int v = 0; v < 8; v++)
-#pragma unroll
-                            for (int u = 0; u < 4; u++) rank[u] += o[v] < t[u] ? 1 : 0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) if (c + GL * u < np) A.pts[rank[u]] = raw[c + GL * u];
-                }
+        if (np > Q_PTS) { status = ST_DEFER; if (c == 0) atomicOr(&a.flags[img], 8); break; }
+        // sort by (x, y) like cv::convexHull: every lane ranks up to four of the points.  The offset polygon has integer vertices, so a
+        // point packs into one 64-bit key (x + 2^20) << 40 | (y + 2^20) << 8 | index -- the index makes equal points keep their order
+        // (they are identical anyway) -- and its rank is the number of smaller keys: one compare and one add per pair
+        {
+            unsigned long long *keys = reinterpret_cast<unsigned long long *>(A.ev);      // the caliper table is not in use yet
+            for (int i = c; i < np; i += GL) {
+                const F2 t = raw[i];
+                keys[i] = ((unsigned long long)((int)t.x + (1 << 20)) << 40) | ((unsigned long long)((int)t.y + (1 << 20)) << 8) | (unsigned)i;
             }
             wave_sync();
-            stamp(st, 7);
-            RRect ub;
-            if (np <= 0) { ub.cx = 0; ub.cy = 0; ub.w = 1; ub.h = 1; ub.angle = 0; }
-            else ub = min_area_rect_q4(A, np, st ? st + 8 : nullptr);                   // 8: hull, 9: calipers
-            stamp(st, 10);
-            if (c == 0) status = unclip_box(ub, res, a.src_wh[2 * img], a.src_wh[2 * img + 1], a.use_padding_resize, d);
-            stamp(st, 11);
+            static_assert(4 * GL >= Q_PTS, "a lane ranks at most four keys");
+            const int i0 = c < np ? c : 0;                       // (a lane beyond the list ranks key 0 again and stores nothing)
+            unsigned long long t[4]; int rank[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 4; u++) t[u] = keys[i0 + GL * u < np ? i0 + GL * u : i0];
+            for (int j0 = 0; j0 < np; j0 += 8) {
+                unsigned long long o[8];
+#pragma unroll
+                for (int v = 0; v < 8; v++) o[v] = j0 + v < np ? keys[j0 + v] : ~0ull;
+#pragma unroll
+                for (int v = 0; v < 8; v++)
+#pragma unroll
+                    for (int u = 0; u < 4; u++) rank[u] += o[v] < t[u] ? 1 : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (c + GL * u < np) A.pts[rank[u]] = raw[c + GL * u];
         }
+        wave_sync();
+        stamp(st, 7);
+        npts = np;
+    }
+    if (status < 0) {
+        stamp(st, 10);
+        if (c == 0) status = unclip_box(box, res, a.src_wh[2 * img], a.src_wh[2 * img + 1], a.use_padding_resize, d);
+        stamp(st, 11);
     }
     if (c == 0) res->status = status;
 }
@@ -3086,7 +3099,7 @@ __device__ __forceinline__ void border_quad_body(const StageArgs &a, const Dbpos
 // (the hull role needs 32 VGPRs and the 8 KB column tables, the score role 2 KB and registers for loads in flight, the quad role
 // 9 KB: one LDS block for all)
 #ifndef PT_STAGE_WAVES
-#define PT_STAGE_WAVES 4                    // waves per SIMD the stage kernel is compiled for (128 VGPRs): the launch is bound by wave slots
+#define PT_STAGE_WAVES 3                    // waves per SIMD the fused stage kernel is compiled for (4 = 128 VGPRs: the quad role's double-precision offset code spills, measured 74 against 73 us)
 #endif
 __global__ __launch_bounds__(WAVE_NT, PT_STAGE_WAVES) void border_stage_kernel(StageArgs a, DbpostDims d) {
     constexpr int ARENA_BYTES = (int)(QUADS * sizeof(QuadArena)) > 8 * W_MW ? (int)(QUADS * sizeof(QuadArena)) : 8 * W_MW;
@@ -3573,6 +3586,8 @@ static void run_chain(ptocr_dbpost *h, const float *d_maps, const uint8_t *d_bit
     a.sc_off = h->sc_off + (long)i0 * MAX_CAND; a.sc_n = h->sc_n + i0; a.sc_item = h->sc_item + (long)i0 * h->sc_cap; a.sc_part = h->sc_part + (long)i0 * h->sc_cap; a.sc_cap = h->sc_cap;
     a.sc_done = h->sc_done + (long)i0 * MAX_CAND;
     a.stamps = h->stamps ? h->stamps + (long)i0 * MAX_CAND * 16 : nullptr;
+    // (round 6, measured and dropped: the hull + score roles and the quad role as TWO launches on two streams, so that the first could hold five
+    // waves per SIMD beside the quads' 168 registers -- the launches did not overlap usefully, 0.281 against 0.224 ms per call)
     hipLaunchKernelGGL(border_stage_kernel, dim3((unsigned)N * (STAGE_GRID + QUAD_BLOCKS + SCORE_GRID)), dim3(WAVE_NT), 0, s, a, d);
     hipLaunchKernelGGL(contour_big_kernel, dim3(BIG_GRID, N), dim3(BIG_THREADS), 0, s, a, d);
     hipLaunchKernelGGL(compact_kernel, dim3(N), dim3(1024), 0, s, a.results, w_totals, h->boxes + (long)i0 * max_boxes * 8, h->counts + i0, max_boxes,
