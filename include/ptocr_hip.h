@@ -214,6 +214,15 @@ int ptocr_asf_scale_spatial_f32(const float *d_y, float *d_fuse, const float *d_
  * (the reference interpolates the 1x1 score map bilinearly to the map size: a constant). */
 int ptocr_asf_scale_channel_f32(const float *d_y, float *d_fuse, const float *d_w1, const float *d_b1, const float *d_w2, float *d_work,
                                 int N, int H, int W, void *stream);
+/* The three ASF forms on a PYRAMID: the four 64-channel features are read from their own-resolution planes (d_pyr, off[4], shift[4],
+ * pyr_floats exactly as ptocr_conv3x3_wino4r_pyramid_f32, which computes d_y from the same planes) and the re-weighted concat is
+ * written to d_out f32[N,H,W,256] -- cat(up8(p5), up4(p4), up2(p3), p2) of pytocr/modeling/necks/fpn.py:118-131 is never
+ * materialised; bit-identical to the in-place forms on the materialised concat (pytocr/modeling/necks/asf.py:146-162).
+ * type 0 scale_channel_spatial: d_w_a = cw1, d_w_b = cw2, d_w_sp3, w_sp1, d_w_att; 1 scale_spatial: d_w_sp3, w_sp1, d_w_att
+ * (d_w_a / d_w_b unused); 2 scale_channel: d_w_a = w1 (BN folded), d_w_b = b1, d_w_att = w2 (d_w_sp3 unused). */
+int ptocr_asf_pyramid_f32(int type, const float *d_y, const float *d_pyr, const long long *off, const int *shift, long long pyr_floats,
+                          float *d_out, const float *d_w_a, const float *d_w_b, const float *d_w_sp3, float w_sp1, const float *d_w_att,
+                          float *d_work, int N, int H, int W, void *stream);
 
 /* ---- bf16 inference path of the MobileNetV3 detector (BASELINE configs[3]) ---------------------------------------------
  * Activations are bf16 NHWC with the channel count padded to a multiple of 16 (padding channels hold zeros); weights bf16,

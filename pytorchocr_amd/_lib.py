@@ -47,7 +47,7 @@ def lib():
 EXPORTS = [
     "ptocr_last_error", "ptocr_version", "ptocr_build_tag", "ptocr_device_arch", "ptocr_set_allocator", "ptocr_live_allocations",
     "ptocr_conv2d_f32", "ptocr_conv3x3_wino_f32", "ptocr_wino_set_timing_buffer", "ptocr_conv3x3_wino4_f32", "ptocr_conv3x3_wino4_split_f32", "ptocr_conv3x3_wino4_pool2_f32", "ptocr_conv3x3_wino4_patches", "ptocr_wino4_set_timing_buffer", "ptocr_conv3x3_wino4r_f32", "ptocr_conv3x3_wino4r_pool2_f32", "ptocr_conv3x3_wino4r_pyramid_f32", "ptocr_wino4r_set_timing_buffer", "ptocr_conv7x7s2_stem_f32", "ptocr_conv7x7s2_stem_nchw_f32", "ptocr_conv7x7s2_stem_relu_pool_f32", "ptocr_conv7x7s2_stem_relu_pool_nchw_f32", "ptocr_conv1x1_k64_f32", "ptocr_conv1x1_small_k_f32", "ptocr_conv3x3_small_relu_pool_f32", "ptocr_nchw_to_nhwc_f32", "ptocr_nhwc_to_nchw_f32", "ptocr_maxpool2d_f32",
-    "ptocr_convt2x2_sigmoid_f32", "ptocr_db_head_tail_f32", "ptocr_asf_scale_channel_spatial_f32", "ptocr_asf_work_floats", "ptocr_asf_scale_spatial_f32", "ptocr_asf_scale_channel_f32", "ptocr_dwconv_f32", "ptocr_dwconv2_f32", "ptocr_cls_head_f32", "ptocr_se_scale_f32", "ptocr_preprocess_u8_f32", "ptocr_warp_crops_u8",
+    "ptocr_convt2x2_sigmoid_f32", "ptocr_db_head_tail_f32", "ptocr_asf_scale_channel_spatial_f32", "ptocr_asf_work_floats", "ptocr_asf_scale_spatial_f32", "ptocr_asf_scale_channel_f32", "ptocr_asf_pyramid_f32", "ptocr_dwconv_f32", "ptocr_dwconv2_f32", "ptocr_cls_head_f32", "ptocr_se_scale_f32", "ptocr_preprocess_u8_f32", "ptocr_warp_crops_u8",
     "ptocr_pwconv_bf16", "ptocr_conv3x3_bf16", "ptocr_conv3x3_lat_bf16", "ptocr_conv3x3_planes_bf16", "ptocr_expand_dw3x3s2_bf16", "ptocr_dwconv_bf16", "ptocr_dwconv_bf16_nblk", "ptocr_se_fc_f32", "ptocr_se_fc_t_f32", "ptocr_se_fc_split_f32", "ptocr_stem3x3s2_bf16", "ptocr_db_head_tail_bf16",
     "ptocr_dbpost_create", "ptocr_dbpost_destroy", "ptocr_db_postprocess", "ptocr_db_postprocess_ex", "ptocr_dbpost_debug_results", "ptocr_dbpost_debug_states", "ptocr_dbpost_debug_labels", "ptocr_dbpost_debug_stamps", "ptocr_dbpost_debug_plant", "ptocr_dbpost_set_route", "ptocr_dbpost_last_device_ms",
     "ptocr_linear_f32", "ptocr_lstm_bidir_f32", "ptocr_lstm_check", "ptocr_lstm_stats", "ptocr_lstm_same_xcd_calls", "ptocr_lstm_fast_workgroups", "ptocr_lstm_set_colocate", "ptocr_lstm_set_spin_limit", "ptocr_ctc_greedy_f32", "ptocr_linear_ctc_greedy_f32", "ptocr_softmax_rows_f32",

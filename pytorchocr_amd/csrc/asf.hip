@@ -20,6 +20,18 @@ constexpr int POOL_PIX = 2048;     // pixels per partial-sum block
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
 
+// Where the four 64-channel features come from.  pyr == nullptr: the concat tensor itself (fuse[n, y, x, 64 i + c], re-weighted in place).
+// Otherwise a PYRAMID (round 6; ops.Pyramid / ptocr_conv3x3_wino4r_pyramid_f32): level i stored at its own resolution,
+// pyr[off[i] + ((n (H >> shift[i]) + (y >> shift[i])) (W >> shift[i]) + (x >> shift[i])) 64 + c] -- the nearest-upsampled copies of
+// fpn.py:118-131 are never written; the re-weighting reads the planes and writes the concat ONCE.
+struct AsfSrc { const float *pyr; long long off[ASF_F]; int shift[ASF_F]; };
+// 16 consecutive channels [16 q, 16 q + 16) of level `level` at pixel (n, py, px) -> address of the source
+__device__ __forceinline__ const float *asf_src(const AsfSrc &src, const float *fuse, long pix, int n, int py, int px, int H, int W, int level, int q) {
+    if (!src.pyr) return fuse + pix * (ASF_F * ASF_C) + level * ASF_C + q * 16;
+    const int sh = src.shift[level];
+    return src.pyr + src.off[level] + (((long)n * (H >> sh) + (py >> sh)) * (W >> sh) + (px >> sh)) * ASF_C + q * 16;
+}
+
 // block (256 threads) = 16 channel-quads x 16 pixel lanes; deterministic tree reduction
 __global__ __launch_bounds__(256) void asf_pool_kernel(const float *__restrict__ y, float *__restrict__ partial, int HW, int nblk) {
     const int n = blockIdx.y, blk = blockIdx.x;
@@ -76,15 +88,16 @@ __global__ __launch_bounds__(256) void asf_mean_kernel(const float *__restrict__
 
 __global__ __launch_bounds__(256) void asf_apply_kernel(const float *__restrict__ y, const float *__restrict__ ca, const float *__restrict__ smean,
                                                         const float *__restrict__ w3 /*[9]*/, float w1x1, const float *__restrict__ wa /*[4][64]*/,
-                                                        float *__restrict__ fuse, int H, int W, long npix) {
+                                                        float *__restrict__ fuse, int H, int W, long npix, AsfSrc src) {
     const int sub = threadIdx.x & 15;
     const long pix = blockIdx.x * 16L + (threadIdx.x >> 4);
     const int HW = H * W;
     float sc[ASF_F] = {0.f, 0.f, 0.f, 0.f};
+    int n = 0, py = 0, px = 0;
     if (pix < npix) {
-        const int n = (int)(pix / HW);
+        n = (int)(pix / HW);
         const int rem = (int)(pix - (long)n * HW);
-        const int py = rem / W, px = rem - py * W;
+        py = rem / W; px = rem - py * W;
         float conv = 0.f;
 #pragma unroll
         for (int dy = -1; dy <= 1; dy++)
@@ -114,9 +127,10 @@ __global__ __launch_bounds__(256) void asf_apply_kernel(const float *__restrict_
         // lane `sub` scales channels [16*sub, 16*sub+16) of the 256-channel pixel: level = sub / 4
         const float score = sigm(sc[sub >> 2]);
         float *f = fuse + pix * (ASF_F * ASF_C) + sub * 16;
+        const float *g = asf_src(src, fuse, pix, n, py, px, H, W, sub >> 2, sub & 3);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            f32x4 t = *reinterpret_cast<f32x4 *>(f + 4 * k);
+            f32x4 t = *reinterpret_cast<const f32x4 *>(g + 4 * k);
             t *= score;
             *reinterpret_cast<f32x4 *>(f + 4 * k) = t;
         }
@@ -155,13 +169,22 @@ __global__ __launch_bounds__(64) void asf_channel_softmax_kernel(const float *__
 }
 
 // fuse[n, :, :, 64 i : 64 i + 64] *= score[n][i]: the bilinear interpolation of a 1x1 score map (asf.py:154) is that constant
-__global__ __launch_bounds__(256) void asf_scale_levels_kernel(float *__restrict__ fuse, const float *__restrict__ score, int HW, long nquads) {
+__global__ __launch_bounds__(256) void asf_scale_levels_kernel(float *__restrict__ fuse, const float *__restrict__ score, int H, int W, long nquads,
+                                                               AsfSrc src) {
     const long q = blockIdx.x * 256L + threadIdx.x;             // one 16-byte piece of a 256-channel pixel
     if (q >= nquads) return;
     const long pix = q >> 6;
-    const int level = (int)(q & 63) >> 4;
-    const float sc = score[(pix / HW) * ASF_F + level];
-    f32x4 t = *reinterpret_cast<f32x4 *>(fuse + q * 4);
+    const int level = (int)(q & 63) >> 4, piece = (int)(q & 15);
+    const int HW = H * W;
+    const int n = (int)(pix / HW);
+    const float sc = score[n * ASF_F + level];
+    const float *g = fuse + q * 4;
+    if (src.pyr) {
+        const int rem = (int)(pix - (long)n * HW);
+        const int py = rem / W, px = rem - py * W;
+        g = asf_src(src, fuse, pix, n, py, px, H, W, level, 0) + piece * 4;
+    }
+    f32x4 t = *reinterpret_cast<const f32x4 *>(g);
     t *= sc;
     *reinterpret_cast<f32x4 *>(fuse + q * 4) = t;
 }
@@ -170,9 +193,24 @@ __global__ __launch_bounds__(256) void asf_scale_levels_kernel(float *__restrict
 
 using namespace ptocr;
 
-extern "C" int ptocr_asf_scale_channel_spatial_f32(const float *d_y, float *d_fuse, const float *d_w_cw1, const float *d_w_cw2,
-                                                   const float *d_w_sp3, float w_sp1, const float *d_w_att, float *d_work,
-                                                   int N, int H, int W, void *stream) {
+// fills `src` from the host arrays of a pyramid (nullptr: the concat tensor in place) and checks it against the allocation
+static int asf_source(AsfSrc *src, const float *d_pyr, const long long *off, const int *shift, long long pyr_floats, int N, int H, int W) {
+    src->pyr = d_pyr;
+    for (int j = 0; j < ASF_F; j++) { src->off[j] = 0; src->shift[j] = 0; }
+    if (!d_pyr) return 0;
+    PT_CHECK(off && shift && pyr_floats > 0, "ptocr_asf_*_pyramid_f32: null plane tables");
+    for (int j = 0; j < ASF_F; j++) {
+        const int sh = shift[j];
+        PT_CHECK(sh >= 0 && sh <= 3 && H % (1 << sh) == 0 && W % (1 << sh) == 0, "ptocr_asf_*_pyramid_f32: plane %d: shift %d does not divide %d x %d", j, sh, H, W);
+        const long long need = (long long)N * (H >> sh) * (W >> sh) * ASF_C;
+        PT_CHECK(off[j] >= 0 && off[j] % 4 == 0 && off[j] + need <= pyr_floats, "ptocr_asf_*_pyramid_f32: plane %d lies outside the allocation", j);
+        src->off[j] = off[j]; src->shift[j] = sh;
+    }
+    return 0;
+}
+
+static int asf_channel_spatial(const float *d_y, float *d_fuse, const AsfSrc &src, const float *d_w_cw1, const float *d_w_cw2,
+                               const float *d_w_sp3, float w_sp1, const float *d_w_att, float *d_work, int N, int H, int W, void *stream) {
     PT_CHECK(d_y && d_fuse && d_w_cw1 && d_w_cw2 && d_w_sp3 && d_w_att && d_work && N >= 1 && N <= 65535, "ptocr_asf: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     const int HW = H * W;
@@ -185,13 +223,13 @@ extern "C" int ptocr_asf_scale_channel_spatial_f32(const float *d_y, float *d_fu
     hipLaunchKernelGGL(asf_channel_kernel, dim3(N), dim3(64), 0, s, partial, d_w_cw1, d_w_cw2, ca, HW, nblk);
     hipLaunchKernelGGL(asf_mean_kernel, dim3((unsigned)cdiv((int)((npix + 15) / 16 * 16), 16)), dim3(256), 0, s, d_y, ca, smean, HW, npix);
     hipLaunchKernelGGL(asf_apply_kernel, dim3((unsigned)cdiv((int)((npix + 15) / 16 * 16), 16)), dim3(256), 0, s, d_y, ca, smean, d_w_sp3, w_sp1,
-                       d_w_att, d_fuse, H, W, npix);
+                       d_w_att, d_fuse, H, W, npix, src);
     return launch_ok("asf kernels");
 }
 
 // attention_type "scale_spatial" (asf.py:78-107): the data flow above with no channel gate (ca = 0: mean_c(y), g = sa + y)
-extern "C" int ptocr_asf_scale_spatial_f32(const float *d_y, float *d_fuse, const float *d_w_sp3, float w_sp1, const float *d_w_att, float *d_work,
-                                           int N, int H, int W, void *stream) {
+static int asf_spatial(const float *d_y, float *d_fuse, const AsfSrc &src, const float *d_w_sp3, float w_sp1, const float *d_w_att, float *d_work,
+                       int N, int H, int W, void *stream) {
     PT_CHECK(d_y && d_fuse && d_w_sp3 && d_w_att && d_work && N >= 1 && N <= 65535, "ptocr_asf_scale_spatial_f32: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     const int HW = H * W;
@@ -201,13 +239,13 @@ extern "C" int ptocr_asf_scale_spatial_f32(const float *d_y, float *d_fuse, cons
     PT_HIP(hipMemsetAsync(ca, 0, sizeof(float) * N * ASF_C, s));
     hipLaunchKernelGGL(asf_mean_kernel, dim3((unsigned)cdiv((int)((npix + 15) / 16 * 16), 16)), dim3(256), 0, s, d_y, ca, smean, HW, npix);
     hipLaunchKernelGGL(asf_apply_kernel, dim3((unsigned)cdiv((int)((npix + 15) / 16 * 16), 16)), dim3(256), 0, s, d_y, ca, smean, d_w_sp3, w_sp1,
-                       d_w_att, d_fuse, H, W, npix);
+                       d_w_att, d_fuse, H, W, npix, src);
     return launch_ok("asf scale_spatial kernels");
 }
 
 // attention_type "scale_channel" (asf.py:9-29, 146-162): d_w1 f32[32][64] and d_b1 f32[32] = fc1 with its BatchNorm folded in, d_w2 f32[4][32]
-extern "C" int ptocr_asf_scale_channel_f32(const float *d_y, float *d_fuse, const float *d_w1, const float *d_b1, const float *d_w2, float *d_work,
-                                           int N, int H, int W, void *stream) {
+static int asf_channel(const float *d_y, float *d_fuse, const AsfSrc &src, const float *d_w1, const float *d_b1, const float *d_w2, float *d_work,
+                       int N, int H, int W, void *stream) {
     PT_CHECK(d_y && d_fuse && d_w1 && d_b1 && d_w2 && d_work && N >= 1 && N <= 65535, "ptocr_asf_scale_channel_f32: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     const int HW = H * W;
@@ -218,8 +256,45 @@ extern "C" int ptocr_asf_scale_channel_f32(const float *d_y, float *d_fuse, cons
     hipLaunchKernelGGL(asf_channel_softmax_kernel, dim3(N), dim3(64), 0, s, partial, d_w1, d_b1, d_w2, score, HW, nblk);
     const long nquads = (long)N * HW * (ASF_F * ASF_C / 4);
     PT_CHECK(nquads < (1L << 31) * 256L, "ptocr_asf_scale_channel_f32: tensor too large");
-    hipLaunchKernelGGL(asf_scale_levels_kernel, dim3((unsigned)((nquads + 255) / 256)), dim3(256), 0, s, d_fuse, score, HW, nquads);
+    hipLaunchKernelGGL(asf_scale_levels_kernel, dim3((unsigned)((nquads + 255) / 256)), dim3(256), 0, s, d_fuse, score, H, W, nquads, src);
     return launch_ok("asf scale_channel kernels");
+}
+
+extern "C" int ptocr_asf_scale_channel_spatial_f32(const float *d_y, float *d_fuse, const float *d_w_cw1, const float *d_w_cw2,
+                                                   const float *d_w_sp3, float w_sp1, const float *d_w_att, float *d_work,
+                                                   int N, int H, int W, void *stream) {
+    AsfSrc src;
+    (void)asf_source(&src, nullptr, nullptr, nullptr, 0, N, H, W);
+    return asf_channel_spatial(d_y, d_fuse, src, d_w_cw1, d_w_cw2, d_w_sp3, w_sp1, d_w_att, d_work, N, H, W, stream);
+}
+
+extern "C" int ptocr_asf_scale_spatial_f32(const float *d_y, float *d_fuse, const float *d_w_sp3, float w_sp1, const float *d_w_att, float *d_work,
+                                           int N, int H, int W, void *stream) {
+    AsfSrc src;
+    (void)asf_source(&src, nullptr, nullptr, nullptr, 0, N, H, W);
+    return asf_spatial(d_y, d_fuse, src, d_w_sp3, w_sp1, d_w_att, d_work, N, H, W, stream);
+}
+
+extern "C" int ptocr_asf_scale_channel_f32(const float *d_y, float *d_fuse, const float *d_w1, const float *d_b1, const float *d_w2, float *d_work,
+                                           int N, int H, int W, void *stream) {
+    AsfSrc src;
+    (void)asf_source(&src, nullptr, nullptr, nullptr, 0, N, H, W);
+    return asf_channel(d_y, d_fuse, src, d_w1, d_b1, d_w2, d_work, N, H, W, stream);
+}
+
+// The same three on a PYRAMID (round 6): the four features are read from their own-resolution planes (d_pyr, off[4], shift[4], pyr_floats as
+// ptocr_conv3x3_wino4r_pyramid_f32, which computes d_y from the same planes) and the re-weighted concat is WRITTEN to d_out f32[N,H,W,256];
+// bit-identical to the in-place forms on the materialised concat.  type: 0 scale_channel_spatial (w_a = cw1, w_b = cw2, w_sp3, w_sp1, w_att),
+// 1 scale_spatial (w_sp3, w_sp1, w_att), 2 scale_channel (w_a = w1, w_b = b1, w_att = w2).
+extern "C" int ptocr_asf_pyramid_f32(int type, const float *d_y, const float *d_pyr, const long long *off, const int *shift, long long pyr_floats,
+                                     float *d_out, const float *d_w_a, const float *d_w_b, const float *d_w_sp3, float w_sp1, const float *d_w_att,
+                                     float *d_work, int N, int H, int W, void *stream) {
+    PT_CHECK(d_pyr && d_out && type >= 0 && type <= 2, "ptocr_asf_pyramid_f32: bad arguments");
+    AsfSrc src;
+    if (int e = asf_source(&src, d_pyr, off, shift, pyr_floats, N, H, W)) return e;
+    if (type == 0) return asf_channel_spatial(d_y, d_out, src, d_w_a, d_w_b, d_w_sp3, w_sp1, d_w_att, d_work, N, H, W, stream);
+    if (type == 1) return asf_spatial(d_y, d_out, src, d_w_sp3, w_sp1, d_w_att, d_work, N, H, W, stream);
+    return asf_channel(d_y, d_out, src, d_w_a, d_w_b, d_w_att, d_work, N, H, W, stream);
 }
 
 extern "C" long ptocr_asf_work_floats(int N, int H, int W) {

@@ -91,3 +91,26 @@ class ScaleFeatureSelection(nn.Module):
                                                              _lib.ptr(p["sp3"]), C.c_float(p["sp1"]), _lib.ptr(p["att"]), _lib.ptr(work),
                                                              N, H, W, _lib.cur_stream()), "ptocr_asf_scale_channel_spatial_f32")
         return fuse
+
+    @staticmethod
+    def run_pyramid(p, pyr):
+        """The same on an ops.Pyramid (round 6): the 3x3 conv reads the four planes in place (ptocr_conv3x3_wino4r_pyramid_f32), the
+        re-weighting reads them again and WRITES the concat once -- the upsampled copies the in-place form re-weights never exist.
+        Returns the re-weighted f32[N,H,W,256]; bit-identical to run(p, pyr.materialize())."""
+        N, H, W = pyr.N, pyr.H, pyr.W
+        y = ops.conv3x3_pyramid(pyr, p["conv"])
+        L = _lib.lib()
+        L.ptocr_asf_work_floats.restype = C.c_long
+        work = torch.empty(L.ptocr_asf_work_floats(N, H, W), dtype=torch.float32, device=pyr.buf.device)
+        out = torch.empty((N, H, W, 256), dtype=torch.float32, device=pyr.buf.device)
+        off, sh = (C.c_longlong * 4)(*pyr.offs), (C.c_int * 4)(*pyr.shifts)
+        kind = {"scale_channel_spatial": 0, "scale_spatial": 1, "scale_channel": 2}[p["type"]]
+        null = C.c_void_p(0)
+        if kind == 2:
+            wa, wb, w3, w1x1, watt = _lib.ptr(p["w1"]), _lib.ptr(p["b1"]), null, 0.0, _lib.ptr(p["w2"])
+        else:
+            wa, wb = (_lib.ptr(p["cw1"]), _lib.ptr(p["cw2"])) if kind == 0 else (null, null)
+            w3, w1x1, watt = _lib.ptr(p["sp3"]), p["sp1"], _lib.ptr(p["att"])
+        _lib.check(L.ptocr_asf_pyramid_f32(kind, _lib.ptr(y), _lib.ptr(pyr.buf), off, sh, C.c_longlong(pyr.buf.numel()), _lib.ptr(out), wa, wb, w3,
+                                           C.c_float(w1x1), watt, _lib.ptr(work), N, H, W, _lib.cur_stream()), "ptocr_asf_pyramid_f32")
+        return out

@@ -65,14 +65,18 @@ class FPN(ops.PackedModule):
         out2 = ops.conv2d(c2, p["in2"], res=out3, res_mode=ops.RES_ADD_UP2_POST_RELU)
         N, H4, W4, _ = c2.shape
         sm = self.out_channels // 4
-        if pyramid_for is not None and not self.use_asf and sm == 64 and ops.pyramid_conv_ok(pyramid_for, N, H4, W4):
-            # Round 5: the four smoothing convs store at their OWN resolution into one allocation and the consumer (the head's first conv)
-            # reads the pyramid in place: the x8 / x4 / x2 upsampled copies (3 x 482 MB per 32 images at 736x1280) are never written
+        # Round 5: the four smoothing convs store at their OWN resolution into one allocation and the consumer reads the pyramid in place:
+        # the x8 / x4 / x2 upsampled copies (3 x 482 MB per 32 images at 736x1280) are never written.  The consumer is the head's first conv
+        # (DB) or -- round 6 -- the ASF (DB++): its 3x3 conv reads the planes, its re-weighting reads them again and writes the concat once.
+        consumer = p["asf"]["conv"] if self.use_asf else pyramid_for
+        if consumer is not None and sm == 64 and ops.pyramid_conv_ok(consumer, N, H4, W4):
             pyr = ops.Pyramid(N, H4, W4, (3, 2, 1, 0), c2.device)
             ops.conv2d(in5, p["out5"], out=pyr.plane(0), store=sm)
             ops.conv2d(out4, p["out4"], out=pyr.plane(1), store=sm)
             ops.conv2d(out3, p["out3"], out=pyr.plane(2), store=sm)
             ops.conv2d(out2, p["out2"], out=pyr.plane(3), store=sm)
+            if self.use_asf:
+                return self.concat_attention.run_pyramid(p["asf"], pyr)
             return pyr
         fuse = torch.empty((N, H4, W4, self.out_channels), dtype=torch.float32, device=c2.device)
         ops.conv2d(in5, p["out5"], out=fuse, out_up=8, out_coff=0, store=sm)

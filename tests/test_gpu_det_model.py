@@ -368,3 +368,40 @@ def test_detector_with_the_fpn_pyramid_equals_the_concat_path(contract):
     finally:
         ops.USE_PYRAMID = keep
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("attention", ["scale_channel_spatial", "scale_spatial", "scale_channel"])
+def test_dbpp_on_the_fpn_pyramid_equals_the_concat_path(attention, contract):
+    """DB++ (round 6): the ASF's 3x3 conv reads the four own-resolution planes in place and its re-weighting writes the concat once
+    (pytocr/modeling/necks/fpn.py:118-131 + asf.py:146-162 without the upsampled copies); with PTOCR_FPN_PYRAMID=0 the round-1 form
+    (upsampling stores into the concat, re-weighted in place).  Same neck output and same maps, bit for bit, for all three attention types."""
+    from pytorchocr_amd.modeling import ops
+    from pytorchocr_amd.modeling.architectures import build_model
+    name = {"scale_channel_spatial": "detpp_r18_db", "scale_spatial": "detpp_r18_db_spatial", "scale_channel": "detpp_r18_db_channel"}[attention]
+    m = build_model(dict(DET_R18, Neck=dict(DET_R18["Neck"], use_asf=True, attention_type=attention)))
+    sd = synth_state_dict(contract[name])
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.to("cuda:0").eval()
+    x = torch.from_numpy(synth_images(3, 3, 256, 448, seed=8)).to("cuda:0")
+    keep = ops.USE_PYRAMID
+    calls = []
+    orig = ops.conv3x3_pyramid
+    try:
+        ops.USE_PYRAMID = True
+        ops.conv3x3_pyramid = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        with torch.no_grad():
+            a = m(x)["maps"]
+            feats = m.backbone.forward_from_nchw(x)
+            neck_a = m._neck_nhwc(feats)
+        assert calls, "the pyramid path was not taken at 64 x 112 (H / 4 x W / 4)"
+        ops.USE_PYRAMID = False
+        n_before = len(calls)
+        with torch.no_grad():
+            b = m(x)["maps"]
+            neck_b = m._neck_nhwc(feats)
+        assert len(calls) == n_before
+    finally:
+        ops.USE_PYRAMID = keep
+        ops.conv3x3_pyramid = orig
+    assert torch.is_tensor(neck_a) and torch.equal(neck_a, neck_b)
+    assert torch.equal(a, b)
