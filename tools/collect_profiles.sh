@@ -4,7 +4,7 @@
 # be judged into profiles/.   usage: collect_profiles.sh [round tag, default r02]
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r05}
+TAG=${1:-r06}
 O=$R/gpurun_out/profiles_new
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
