@@ -3588,6 +3588,11 @@ static void run_chain(ptocr_dbpost *h, const float *d_maps, const uint8_t *d_bit
     a.stamps = h->stamps ? h->stamps + (long)i0 * MAX_CAND * 16 : nullptr;
     // (round 6, measured and dropped: the hull + score roles and the quad role as TWO launches on two streams, so that the first could hold five
     // waves per SIMD beside the quads' 168 registers -- the launches did not overlap usefully, 0.281 against 0.224 ms per call)
+    // (round 6, measured and dropped: the three roles fed by per-image ticket queues from a fixed number of resident waves instead of the
+    // grid order -- hull items first, then quad groups, then score items: 150 us against 72.8 for the launch; with every role's body inside a
+    // ticket loop the allocator spills in all of them, and a ticket is a 0.7-us returning atomic per item, tools/dbg/queue_probe.hip)
+    // (... and the score role as a launch of its own on a side stream beside a hull + quad launch: 0.279 against 0.225 ms per call -- the
+    // two launches slow each other down more than the grid order costs: 81 + 53 us against 72.7 fused)
     hipLaunchKernelGGL(border_stage_kernel, dim3((unsigned)N * (STAGE_GRID + QUAD_BLOCKS + SCORE_GRID)), dim3(WAVE_NT), 0, s, a, d);
     hipLaunchKernelGGL(contour_big_kernel, dim3(BIG_GRID, N), dim3(BIG_THREADS), 0, s, a, d);
     hipLaunchKernelGGL(compact_kernel, dim3(N), dim3(1024), 0, s, a.results, w_totals, h->boxes + (long)i0 * max_boxes * 8, h->counts + i0, max_boxes,
