@@ -1437,12 +1437,8 @@ extern "C" int ptocr_conv3x3_planes_bf16(const void *d_x, const void *d_w, const
     C3Args p;
     p.x = (const __bf16 *)d_x; p.w = (const __bf16 *)d_w; p.bias = d_bias; p.y = (__bf16 *)d_y; p.M = (long)N * H * W; p.H = H; p.W = W; p.Cin = 96;
     p.cstore = cstore; p.act = act; p.out_up = 1; p.out_ldc = out_ldc; p.out_coff = 0;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        PT_HIP(hipGetDevice(&dev));
-        PT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    int n_cu = 0;
+    if (int e_ = current_device_cus(&n_cu)) return e_;
     const int tiles_x = cdiv(W, C3_TW), tpi = tiles_x * cdiv(H, 8);
     const long total = (long)N * tpi;
     PT_CHECK(total < (1L << 31) && (long)H * W * 96 * 2 < (1L << 31), "ptocr_conv3x3_planes_bf16: too many tiles / image larger than 2 GiB");
@@ -1466,12 +1462,8 @@ extern "C" int ptocr_conv3x3_bf16(const void *d_x, const void *d_w, const float 
     PT_CHECK(blocks < (1L << 31), "ptocr_conv3x3_bf16: too many pixels");
     static const bool use_lds = !(getenv("PTOCR_BF16_C3_LDS") && atoi(getenv("PTOCR_BF16_C3_LDS")) == 0);
     if (use_lds && Cin == 96 && cstore % 8 == 0 && out_coff % 8 == 0 && out_ldc % 8 == 0) {     // the FPN / head convs of the mbv3 detector
-        static int n_cu = 0;
-        if (!n_cu) {
-            int dev = 0;
-            PT_HIP(hipGetDevice(&dev));
-            PT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        }
+        int n_cu = 0;
+        if (int e_ = current_device_cus(&n_cu)) return e_;
         const int th = 8;
         const int tiles_x = cdiv(W, C3_TW), tpi = tiles_x * cdiv(H, th);
         const long total = (long)N * tpi;
@@ -1509,12 +1501,8 @@ extern "C" int ptocr_conv3x3_lat_bf16(const void *d_x2, const void *d_wl, const 
     q.c.x = nullptr; q.c.w = (const __bf16 *)d_w3; q.c.bias = d_b3; q.c.y = (__bf16 *)d_y; q.c.M = (long)N * H * W; q.c.H = H; q.c.W = W; q.c.Cin = 96;
     q.c.cstore = cstore; q.c.act = act; q.c.out_up = out_up; q.c.out_ldc = out_ldc; q.c.out_coff = out_coff;
     q.x2 = (const __bf16 *)d_x2; q.wl = (const __bf16 *)d_wl; q.td = (const __bf16 *)d_td; q.bl = d_bl; q.td_ldc = td_ldc;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        PT_HIP(hipGetDevice(&dev));
-        PT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    int n_cu = 0;
+    if (int e_ = current_device_cus(&n_cu)) return e_;
     const int tiles_x = cdiv(W, C3_TW), tpi = tiles_x * cdiv(H, 8);
     const long total = (long)N * tpi;
     PT_CHECK(total < (1L << 31), "ptocr_conv3x3_lat_bf16: too many tiles");
@@ -1558,11 +1546,8 @@ extern "C" int ptocr_expand_dw3x3s2_bf16(const void *d_x, const void *d_we, cons
     const dim3 grid(tiles_x * tiles_y, N);
 #define PT_XD(CC, E) do { \
         constexpr int lds = 9 * 33 * (2 * CC + 16); \
-        static bool attr_set = false; \
-        if (!attr_set) { \
-            PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&expand_dw3x3s2_bf16_kernel<CC, E, E>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
-            attr_set = true; \
-        } \
+        static DynLds dyn; \
+        if (int e_ = raise_dyn_lds(dyn, reinterpret_cast<const void *>(&expand_dw3x3s2_bf16_kernel<CC, E, E>), lds)) return e_; \
         hipLaunchKernelGGL((expand_dw3x3s2_bf16_kernel<CC, E, E>), grid, dim3(XD_THREADS), (size_t)lds, (hipStream_t)stream, p, tiles_x, tiles_y); \
     } while (0)
 #define PT_XD_C(E) do { \
@@ -1614,12 +1599,8 @@ extern "C" int ptocr_db_head_tail_bf16(const void *d_x, const float *d_w1, const
     }
     PT_CHECK(total < (1L << 31), "ptocr_db_head_tail_bf16: too many pixels");
     const long groups = (total + 127) / 128;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        PT_HIP(hipGetDevice(&dev));
-        PT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    int n_cu = 0;
+    if (int e_ = current_device_cus(&n_cu)) return e_;
     // few, long-lived waves (the per-lane weight registers are set up once per wave): three workgroups per CU is what the kernel's 150
     // registers allow -- 1024 workgroups ran as one full round and a second one a third full
     const unsigned grid = (unsigned)(groups < 3L * n_cu ? groups : 3L * n_cu);

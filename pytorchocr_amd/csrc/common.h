@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdarg>
 #include <cstring>
+#include <mutex>
 #include "../../include/ptocr_hip.h"
 
 namespace ptocr {
@@ -29,6 +30,35 @@ inline int launch_ok(const char *what) {
 }
 
 constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Per-device launch state (round 6).  A kernel that needs more dynamic LDS than the default has the limit raised once per (kernel,
+// DEVICE) -- hipFuncSetAttribute is a per-device setting -- and a persistent kernel sizes its grid by the CU count of the CURRENT device.
+// Both used to be function statics set by whichever thread and device came first: a second device in the process launched without the
+// attribute, a concurrent first call raced.  Now: looked up per device under a mutex (a launch costs one hipGetDevice more).
+constexpr int PT_MAX_DEVICES = 64;
+struct DynLds { std::mutex mu; bool done[PT_MAX_DEVICES] = {}; };
+inline int raise_dyn_lds(DynLds &st, const void *fn, int bytes) {
+    int dev = 0;
+    PT_HIP(hipGetDevice(&dev));
+    PT_CHECK(dev >= 0 && dev < PT_MAX_DEVICES, "device ordinal %d beyond the %d this library keeps launch state for", dev, PT_MAX_DEVICES);
+    std::lock_guard<std::mutex> lk(st.mu);
+    if (!st.done[dev]) {
+        PT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        st.done[dev] = true;
+    }
+    return 0;
+}
+inline int current_device_cus(int *n_cu) {
+    static std::mutex mu;
+    static int cus[PT_MAX_DEVICES] = {};
+    int dev = 0;
+    PT_HIP(hipGetDevice(&dev));
+    PT_CHECK(dev >= 0 && dev < PT_MAX_DEVICES, "device ordinal %d beyond the %d this library keeps launch state for", dev, PT_MAX_DEVICES);
+    std::lock_guard<std::mutex> lk(mu);
+    if (!cus[dev]) PT_HIP(hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev));
+    *n_cu = cus[dev];
+    return 0;
+}
 
 // Device memory the LIBRARY owns (post-process workspaces, the LSTM exchange buffers) comes from the allocator installed with
 // ptocr_set_allocator (include/ptocr_hip.h), hipMalloc / hipFree by default.

@@ -161,17 +161,10 @@ __global__ __launch_bounds__(512, 1) void conv_pw64_kernel(Pw64Args p) {
 template <int PW_K, int NMT>
 static int launch_pw64(const Pw64Args &a, hipStream_t stream) {
     const size_t lds = sizeof(float) * (PW_K * NMT * 32 + 2 * PW_TM * (PW_K + 4) + NMT * 32);
-    static bool attr_set = false;
-    if (!attr_set) {
-        PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pw64_kernel<PW_K, NMT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        PT_HIP(hipGetDevice(&dev));
-        PT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    static DynLds dyn;
+    if (int e_ = raise_dyn_lds(dyn, reinterpret_cast<const void *>(&conv_pw64_kernel<PW_K, NMT>), (int)lds)) return e_;
+    int n_cu = 0;
+    if (int e_ = current_device_cus(&n_cu)) return e_;
     const int grid = a.ntiles < 2 * n_cu ? (a.ntiles + 1) / 2 : n_cu;        // one persistent workgroup per CU, two tile streams (teams) in each
     hipLaunchKernelGGL((conv_pw64_kernel<PW_K, NMT>), dim3((unsigned)grid), dim3(512), lds, stream, a);
     return launch_ok("conv_pw64_kernel");
@@ -286,17 +279,10 @@ __global__ __launch_bounds__(256, 1) void conv_pw128_kernel(Pw64Args p, int cout
 static int launch_pw128(const Pw64Args &a, int cout_total, hipStream_t stream) {
     constexpr int NMT = 4;
     const size_t lds = sizeof(float) * (128 * NMT * 32 + PW_TM * (128 + 4) + NMT * 32);
-    static bool attr_set = false;
-    if (!attr_set) {
-        PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pw128_kernel<NMT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        PT_HIP(hipGetDevice(&dev));
-        PT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    static DynLds dyn;
+    if (int e_ = raise_dyn_lds(dyn, reinterpret_cast<const void *>(&conv_pw128_kernel<NMT>), (int)lds)) return e_;
+    int n_cu = 0;
+    if (int e_ = current_device_cus(&n_cu)) return e_;
     const int nsplit = cout_total / (NMT * 32);
     int per = n_cu / nsplit;                                     // persistent workgroups per output-channel block
     if (per > a.ntiles) per = a.ntiles;

@@ -176,18 +176,11 @@ static int stem_launch(const float *d_x, const float *d_w, const float *d_bias, 
     PT_CHECK(total < (1L << 31) && a.x_bytes < (1L << 31), "%s: tensor larger than 2 GiB", who);
     a.total = (int)total; a.relu = relu;
     const size_t lds = sizeof(float) * (ST_K * 64 + 2 * ST_PATCH);
-    static bool attr_set = false;
-    if (!attr_set) {
-        PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&stem_conv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&stem_conv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        PT_HIP(hipGetDevice(&dev));
-        PT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    static DynLds dyn0, dyn1;
+    if (int e_ = raise_dyn_lds(dyn0, reinterpret_cast<const void *>(&stem_conv_kernel<false>), (int)lds)) return e_;
+    if (int e_ = raise_dyn_lds(dyn1, reinterpret_cast<const void *>(&stem_conv_kernel<true>), (int)lds)) return e_;
+    int n_cu = 0;
+    if (int e_ = current_device_cus(&n_cu)) return e_;
     const int grid = a.total < 2 * n_cu ? a.total : 2 * n_cu;    // two persistent workgroups per CU
     if (nchw) hipLaunchKernelGGL(stem_conv_kernel<true>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(stem_conv_kernel<false>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a);

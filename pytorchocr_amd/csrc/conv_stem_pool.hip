@@ -215,18 +215,11 @@ static int stem_pool_launch(const float *d_x, const float *d_w, const float *d_b
     PT_CHECK(total < (1L << 31) && a.x_bytes < (1L << 31), "%s: tensor larger than 2 GiB", who);
     a.total = (int)total;
     const size_t lds = sizeof(float) * (SP_K * 64 + 2 * SP_PATCH + 8 * SP_EX + 2 * SP_EX);
-    static bool attr_set = false;
-    if (!attr_set) {
-        PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&stem_pool_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&stem_pool_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        PT_HIP(hipGetDevice(&dev));
-        PT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    static DynLds dyn0, dyn1;
+    if (int e_ = raise_dyn_lds(dyn0, reinterpret_cast<const void *>(&stem_pool_kernel<false>), (int)lds)) return e_;
+    if (int e_ = raise_dyn_lds(dyn1, reinterpret_cast<const void *>(&stem_pool_kernel<true>), (int)lds)) return e_;
+    int n_cu = 0;
+    if (int e_ = current_device_cus(&n_cu)) return e_;
     const int nstrips = N * a.strips;
     const int grid = nstrips < n_cu ? nstrips : n_cu;            // one persistent workgroup per CU, whole strips each
     if (nchw) hipLaunchKernelGGL(stem_pool_kernel<true>, dim3((unsigned)grid), dim3(SP_THREADS), lds, (hipStream_t)stream, a);

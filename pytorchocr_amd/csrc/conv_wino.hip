@@ -340,12 +340,8 @@ static int launch_wino(WinoArgs a, hipStream_t stream) {
     PT_CHECK(total < (1L << 31), "ptocr_conv3x3_wino_f32: too many patches");
     a.total = (int)total;
     const size_t lds = sizeof(float) * (4 * W_V + 2 * wino_raw_floats(TXN, TYN));
-    static bool attr_set = false;
-    if (!attr_set) {
-        const void *fn = reinterpret_cast<const void *>(&conv_wino_kernel<TXN, TYN, DBG>);
-        PT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static DynLds dyn;
+    if (int e_ = raise_dyn_lds(dyn, reinterpret_cast<const void *>(&conv_wino_kernel<TXN, TYN, DBG>), (int)lds)) return e_;
     hipLaunchKernelGGL((conv_wino_kernel<TXN, TYN, DBG>), dim3((unsigned)a.total), dim3(512), lds, stream, a);
     return launch_ok("conv_wino_kernel");
 }

@@ -452,12 +452,8 @@ static int launch_wino4m(Wino4Args a, hipStream_t stream) {
     PT_CHECK(total < (1L << 31), "ptocr_conv3x3_wino4_f32: too many patches");
     a.total = (int)total;
     const size_t lds = sizeof(float) * (2 * W4_V + 2 * w4_raw_floats(TXN, TYN, TN));
-    static bool attr_set = false;
-    if (!attr_set) {
-        const void *fn = reinterpret_cast<const void *>(&conv_wino4_kernel<TXN, TYN, TN, MODE, SPLIT>);
-        PT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static DynLds dyn;
+    if (int e_ = raise_dyn_lds(dyn, reinterpret_cast<const void *>(&conv_wino4_kernel<TXN, TYN, TN, MODE, SPLIT>), (int)lds)) return e_;
     hipLaunchKernelGGL((conv_wino4_kernel<TXN, TYN, TN, MODE, SPLIT>), dim3((unsigned)a.total), dim3(W4_THREADS), lds, stream, a);
     return launch_ok("conv_wino4_kernel");
 }

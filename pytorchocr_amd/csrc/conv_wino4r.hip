@@ -512,16 +512,10 @@ static int launch_wino4rm(Wino4RArgs a, hipStream_t stream) {
     PT_CHECK(total < (1L << 29), "ptocr_conv3x3_wino4r_f32: too many patches");
     a.total = (int)total;
     const size_t lds = sizeof(float) * (r4_lds_floats(TXN, TYN, TN) + R4_BIAS_LDS);
-    static bool attr_set = false;
-    static int n_cu = 0;
-    if (!attr_set) {
-        const void *fn = reinterpret_cast<const void *>(&conv_wino4r_kernel<TXN, TYN, TN, MODE, PYR>);
-        PT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        int dev = 0;
-        PT_HIP(hipGetDevice(&dev));
-        PT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        attr_set = true;
-    }
+    static DynLds dyn;                                            // (one per template instance; per device inside)
+    if (int e_ = raise_dyn_lds(dyn, reinterpret_cast<const void *>(&conv_wino4r_kernel<TXN, TYN, TN, MODE, PYR>), (int)lds)) return e_;
+    int n_cu = 0;
+    if (int e_ = current_device_cus(&n_cu)) return e_;
     // one persistent workgroup per CU (150 KB of LDS each: one fits); consecutive patch ids still go round the eight XCDs
     static const int per_cu = getenv("PTOCR_WINO4R_GRID") ? atoi(getenv("PTOCR_WINO4R_GRID")) : 1;
     const long want = (long)n_cu * (per_cu > 0 ? per_cu : 1);

@@ -156,17 +156,10 @@ extern "C" int ptocr_db_head_tail_f32(const float *d_x, const float *d_w1, const
     PT_CHECK(x_bytes < (1L << 31), "ptocr_db_head_tail_f32: tensor larger than 2 GiB");
     const int ntiles = (int)((npix + HT_PIX - 1) / HT_PIX);
     const size_t lds = sizeof(float) * (256 * HT_LD + 4 * HT_C + 256);
-    static bool attr_set = false;
-    if (!attr_set) {
-        PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(db_head_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        PT_HIP(hipGetDevice(&dev));
-        PT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    static DynLds dyn;
+    if (int e_ = raise_dyn_lds(dyn, reinterpret_cast<const void *>(db_head_tail_kernel), (int)lds)) return e_;
+    int n_cu = 0;
+    if (int e_ = current_device_cus(&n_cu)) return e_;
     const int grid = ntiles < 2 * n_cu ? ntiles : 2 * n_cu;
     hipLaunchKernelGGL(db_head_tail_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, d_x, d_w1, d_b1, d_w2, b2, d_maps, H, W,
                        npix, ntiles, x_bytes);

@@ -120,6 +120,7 @@ class PackedConv:
             self.stem_b = b.float().contiguous().to(device)
         # Winograd F(2x2,3x3) form of the same weights for 3x3 / s1 / p1 layers: U = G g G^T, packed [Cout/64][Cin/4][16][64][4]
         self.wino_u = self.wino4_u = None
+        self.wino4_ok = False                                   # an F(4x4,3x3) form of the weights exists (wino4r_u, or wino4_u for the first cut)
         if (kh, kw) == (3, 3) and self.stride == 1 and (self.pad_h, self.pad_w) == (1, 1) and cin % 16 == 0 and cout % 4 == 0 \
                 and cin_pad == cin and self.relu in (ACT_NONE, ACT_RELU):
             G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64)
@@ -136,11 +137,16 @@ class PackedConv:
             # wave w owns xi = 3w + e; lane (n = lane & 31, h = lane >> 5) holds {nb, t} -> U[xi][4 chunk + 2h + t][64 ct + 32 nb + n]
             G6 = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
                                [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float64)
-            U6 = torch.zeros(cw, cin, 36, dtype=torch.float64)
-            U6[:cout] = torch.einsum("ar,ocrs,bs->ocab", G6, w, G6).reshape(cout, cin, 36)
-            U6 = U6.reshape(cw // 64, 2, 32, cin // 4, 2, 2, 12, 3)               # [ct, nb, n, chunk, h, t, w, e]
-            U6 = U6.permute(0, 3, 6, 7, 4, 2, 1, 5)                                # [ct, chunk, w, e, h, n, nb, t]
-            self.wino4_u = U6.contiguous().float().to(device)
+            # (round 6: packed only where the first cut runs -- PTOCR_WINO4R=0, or the split experiment, which shares its layout; each F(4x4)
+            # form is 4x the conv weights and its own fp64 einsum)
+            self.wino4_ok = True
+            U6 = None
+            if not WINO4R or WINO_SPLIT:
+                U6 = torch.zeros(cw, cin, 36, dtype=torch.float64)
+                U6[:cout] = torch.einsum("ar,ocrs,bs->ocab", G6, w, G6).reshape(cout, cin, 36)
+                U6 = U6.reshape(cw // 64, 2, 32, cin // 4, 2, 2, 12, 3)               # [ct, nb, n, chunk, h, t, w, e]
+                U6 = U6.permute(0, 3, 6, 7, 4, 2, 1, 5)                                # [ct, chunk, w, e, h, n, nb, t]
+                self.wino4_u = U6.contiguous().float().to(device)
             # round-5 re-cut (conv_wino4r.hip): wave (wh, wi) owns the frequency row xi = 6 wi + j for the output channels 32 wh + n;
             # packed [ct][chunk][wh][wi][q][kh][n][jj][t] = U[xi = 6 wi + 2 q + jj][cin = 4 chunk + 2 kh + t][cout = 64 ct + 32 wh + n]
             self.wino4r_u = None
@@ -255,7 +261,7 @@ def conv2d(x, pc, res=None, res_mode=RES_NONE, out=None, out_up=1, out_coff=0, s
             and out_up <= 8 and (store if store is not None else pc.c_tensor) % 4 == 0 and N * H * W * Cin * 4 < 2 ** 31 \
             and (store if store is not None else pc.c_tensor) <= pc.wino_cout:
         cs = store if store is not None else pc.c_tensor      # columns written: zero weights / bias beyond the real channels
-        four = pc.wino4_u is not None and _wino4_wins(H, W, Cin) and out.numel() * 4 < 2 ** 31 and (res is None or res.numel() * 4 < 2 ** 31)
+        four = getattr(pc, "wino4_ok", getattr(pc, "wino4_u", None) is not None) and _wino4_wins(H, W, Cin) and out.numel() * 4 < 2 ** 31 and (res is None or res.numel() * 4 < 2 ** 31)
         if PROFILE is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -484,7 +490,7 @@ def conv2d_relu_pool2(x, pc):
     Winograd kernel (its epilogue takes the maxima of the 2x2 windows inside each 4x4 output tile), conv2d + maxpool2d otherwise"""
     _require_cuda(x, "conv2d_relu_pool2")
     N, H, W, Cin = x.shape
-    fused = (CONV_POOL_FUSE and USE_WINOGRAD and getattr(pc, "wino4_u", None) is not None and getattr(pc, "wino4_us", None) is None and pc.relu
+    fused = (CONV_POOL_FUSE and USE_WINOGRAD and getattr(pc, "wino4_ok", False) and getattr(pc, "wino4_us", None) is None and pc.relu
              and pc.kh == 3 and pc.kw == 3 and pc.stride == 1 and pc.pad_h == 1 and pc.pad_w == 1 and not pc.convt
              and H % 2 == 0 and W % 2 == 0 and pc.c_tensor % 4 == 0 and pc.c_tensor <= pc.wino_cout
              and _wino4_wins(H, W, Cin) and N * H * W * max(Cin, pc.c_tensor) * 4 < 2 ** 31)

@@ -285,7 +285,7 @@ def test_winograd_3x3_matches_torch(case, mode, monkeypatch):
         ref = F.relu(bn(conv(x)))
         ref_res = F.relu(bn(conv(x)) + res)
     pc = ops.PackedConv(conv, bn, dev, relu=True, cin_pad=Cin)
-    assert pc.wino_u is not None and pc.wino4_u is not None
+    assert pc.wino_u is not None and pc.wino4_ok
     xd = _nhwc(x).to(dev)
     tol = 3e-5 * max(1.0, ref.abs().max().item())
     monkeypatch.setattr(ops, "PROFILE", [])
@@ -540,3 +540,38 @@ def test_conv_random_shapes_against_torch(seed):
             exp = ref.repeat_interleave(up, 2).repeat_interleave(up, 3)
             assert (big[..., 32:32 + Cout].permute(0, 3, 1, 2) - exp).abs().max().item() <= tol, ("up", up, N, H, W, Cin, Cout)
             assert float((big[..., :32] - 3).abs().max()) == 0 and float((big[..., 32 + Cout:] - 3).abs().max()) == 0
+
+
+def test_first_cut_winograd_kernel_still_agrees(monkeypatch):
+    """PTOCR_WINO4R=0 keeps conv_wino4_kernel (the first cut of the F(4x4,3x3) kernel) selectable: its weights are packed only then
+    (round 6), and it must still agree with the re-cut and with torch -- plain, residual and fused-pool forms."""
+    from pytorchocr_amd.modeling import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    N, Cin, Cout, H, W = 3, 64, 64, 40, 72
+    conv = torch.nn.Conv2d(Cin, Cout, 3, 1, 1, bias=False)
+    bn = torch.nn.BatchNorm2d(Cout).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(Cout) * 0.4 + 1); bn.bias.copy_(torch.randn(Cout) * 0.2)
+        bn.running_mean.copy_(torch.randn(Cout) * 0.2); bn.running_var.copy_(torch.rand(Cout) * 0.5 + 1)
+    x, res = torch.randn(N, Cin, H, W), torch.randn(N, Cout, H, W)
+    with torch.no_grad():
+        ref = F.relu(bn(conv(x)))
+        ref_res = F.relu(bn(conv(x)) + res)
+        ref_pool = F.max_pool2d(ref, 2, 2)
+    xd, rd = x.permute(0, 2, 3, 1).contiguous().to(dev), res.permute(0, 2, 3, 1).contiguous().to(dev)
+    monkeypatch.setattr(ops, "WINO4_MODE", "1")
+    outs = {}
+    for recut in (True, False):
+        monkeypatch.setattr(ops, "WINO4R", recut)
+        pc = ops.PackedConv(conv, bn, dev, relu=True, cin_pad=Cin)
+        assert pc.wino4_ok and (pc.wino4r_u is not None) == recut and (pc.wino4_u is not None) == (not recut)
+        monkeypatch.setattr(ops, "PROFILE", [])
+        monkeypatch.setattr(ops, "PROFILE_LABELS", [])
+        outs[recut] = (ops.conv2d(xd, pc), ops.conv2d(xd, pc, res=rd, res_mode=ops.RES_ADD_PRE_RELU), ops.conv2d_relu_pool2(xd, pc))
+        assert all(l.startswith("wino43x3") for l in ops.PROFILE_LABELS[:2])
+    tol = 3e-5 * max(1.0, ref_res.abs().max().item())
+    for got, want in zip(outs[False], (ref, ref_res, ref_pool)):
+        assert (got.cpu().permute(0, 3, 1, 2) - want).abs().max().item() <= tol
+    for a, b in zip(outs[True], outs[False]):                      # the two cuts share transforms and summation order per tile
+        assert (a - b).abs().max().item() <= tol

@@ -28,7 +28,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 80):
         if up > 1:
             r2 = F.interpolate(r2, scale_factor=up, mode="nearest")
     pc = ops.PackedConv(conv, None, dev, relu=relu, cin_pad=cin)
-    assert pc.wino4_u is not None, (cin, cout)
+    assert pc.wino4_ok, (cin, cout)
     xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
     kw = {}
     if res is not None:
