@@ -79,6 +79,13 @@ __global__ __launch_bounds__(256) void pw_bf16_kernel(PwArgs p) {
         for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
     const __bf16 *wrow = p.w + ((long)t0 * 32 + r) * p.Cin + 8 * h;
     const int nks = p.Cin >> 4;
+    // (round 6) The bias of the workgroup's NT * 32 output channels goes to LDS HERE, before the K loop.  It used to be read from global
+    // memory inside the epilogue, a 16-byte load per (tile, channel group), each followed by `s_waitcnt vmcnt(0)` -- and the vector-memory
+    // counter is in order and counts STORES: every one of those twelve loads waited for its own round trip AND for the acknowledgement of
+    // the tile's stores issued before it (the pattern DESIGN 3.0 found in the Winograd epilogue; here it was most of a small-map launch).
+    __shared__ float sbias[NT * 32];
+    if (threadIdx.x < NT * 32) { const int c = t0 * 32 + (int)threadIdx.x; sbias[threadIdx.x] = c < p.cstore ? p.bias[c] : 0.f; }
+    __syncthreads();
     // K loop in groups of four slices, all loads of a group issued before its first MFMA, no branch inside: the small maps have one or
     // two waves per SIMD and Cin up to 576 -- with one slice per iteration every MFMA waited for its own operands' round trip to L2
     // (36 dependent round trips for the 576-channel layers).  GRP = 1 (Cin < 64) keeps the one-slice loop: the 64 extra registers of the
@@ -144,6 +151,34 @@ __global__ __launch_bounds__(256) void pw_bf16_kernel(PwArgs p) {
         oy0 = rem / p.W; ox0 = rem - oy0 * p.W;
     }
     const int ch = lane & 3;
+    // (round 6) RES: the residual pieces of ALL tiles are requested here, before the first store of the epilogue -- read inside the
+    // write-back phase, each load's wait was also a wait for the stores issued before it (in-order counter), once per tile and round
+    bf16x4 rres[RES ? NT : 1][2][2];
+    if constexpr (RES) {
+#pragma unroll
+        for (int round = 0; round < 2; round++) {
+            const int pr = (lane >> 2) + 16 * round;
+            const long mm = mw0 + pr;
+            const __bf16 *rpix;
+            if (p.res_mode == 1) rpix = p.res + mm * p.res_ldc;
+            else {
+                int n = n0, oy = oy0, ox = ox0 + pr;
+                while (ox >= p.W) { ox -= p.W; oy++; }
+                while (oy >= p.H) { oy -= p.H; n++; }
+                rpix = p.res + (((long)n * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) * p.res_ldc;
+            }
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const int tbase = (t0 + t) * 32, tend = min(p.cstore, tbase + 32), c = tbase + ch * 8;
+                // (straight-line loads from addresses that are always valid -- the tensor's first bytes where the piece does not exist, its
+                // value is never used --, so that all of them are in flight together: one round trip)
+                const bool on = t0 + t < p.ntile && c < tend && mm < p.M;
+                const __bf16 *a0 = on ? rpix + c : p.res, *a1 = (on && c + 8 <= tend) ? rpix + c + 4 : a0;
+                rres[t][round][0] = *reinterpret_cast<const bf16x4 *>(a0);
+                rres[t][round][1] = *reinterpret_cast<const bf16x4 *>(a1);
+            }
+        }
+    }
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         const int tbase = (t0 + t) * 32, tend = min(p.cstore, tbase + 32);
@@ -153,7 +188,7 @@ __global__ __launch_bounds__(256) void pw_bf16_kernel(PwArgs p) {
             const int c = tbase + 8 * g + 4 * h;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (c < tend) {
-                const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + c);
+                const f32x4 bias = *reinterpret_cast<const f32x4 *>(&sbias[32 * t + 8 * g + 4 * h]);
 #pragma unroll
                 for (int j = 0; j < 4; j++) v[j] = acc[t][4 * g + j] + bias[j];
                 if (!RES) {
@@ -182,16 +217,7 @@ __global__ __launch_bounds__(256) void pw_bf16_kernel(PwArgs p) {
             if (c >= tend || mm >= p.M) continue;
             __bf16 *dst = p.y + mm * p.out_ldc + p.out_coff + c;
             if constexpr (RES) {
-                const __bf16 *rsrc;
-                if (p.res_mode == 1) rsrc = p.res + mm * p.res_ldc + c;
-                else {
-                    int n = n0, oy = oy0, ox = ox0 + pr;
-                    while (ox >= p.W) { ox -= p.W; oy++; }
-                    while (oy >= p.H) { oy -= p.H; n++; }
-                    rsrc = p.res + (((long)n * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) * p.res_ldc + c;
-                }
-                bf16x4 r0 = *reinterpret_cast<const bf16x4 *>(rsrc), r1 = r0;
-                if (full) r1 = *reinterpret_cast<const bf16x4 *>(rsrc + 4);
+                const bf16x4 r0 = rres[t][round][0], r1 = rres[t][round][1];
                 const f32x4 v0 = *reinterpret_cast<const f32x4 *>(&tile[wave][pr][ch * 8]), v1 = *reinterpret_cast<const f32x4 *>(&tile[wave][pr][ch * 8 + 4]);
                 bf16x8 o;
 #pragma unroll
