@@ -83,9 +83,10 @@ __global__ __launch_bounds__(256) void pw_bf16_kernel(PwArgs p) {
     // memory inside the epilogue, a 16-byte load per (tile, channel group), each followed by `s_waitcnt vmcnt(0)` -- and the vector-memory
     // counter is in order and counts STORES: every one of those twelve loads waited for its own round trip AND for the acknowledgement of
     // the tile's stores issued before it (the pattern DESIGN 3.0 found in the Winograd epilogue; here it was most of a small-map launch).
+    // (requested here, parked in LDS behind the K loop: the load's round trip overlaps the loop's)
     __shared__ float sbias[NT * 32];
-    if (threadIdx.x < NT * 32) { const int c = t0 * 32 + (int)threadIdx.x; sbias[threadIdx.x] = c < p.cstore ? p.bias[c] : 0.f; }
-    __syncthreads();
+    float bias_mine = 0.f;
+    if (threadIdx.x < NT * 32) { const int c = t0 * 32 + (int)threadIdx.x; if (c < p.cstore) bias_mine = p.bias[c]; }
     // K loop in groups of four slices, all loads of a group issued before its first MFMA, no branch inside: the small maps have one or
     // two waves per SIMD and Cin up to 576 -- with one slice per iteration every MFMA waited for its own operands' round trip to L2
     // (36 dependent round trips for the 576-channel layers).  GRP = 1 (Cin < 64) keeps the one-slice loop: the 64 extra registers of the
@@ -100,21 +101,21 @@ __global__ __launch_bounds__(256) void pw_bf16_kernel(PwArgs p) {
         return b;
     };
     int ks = 0;
-    if constexpr (GRP == 4)
-    for (; ks + 4 <= nks; ks += 4) {
-        bf16x8 b[4], a[NT][4];
+    if constexpr (GRP > 1)
+    for (; ks + GRP <= nks; ks += GRP) {
+        bf16x8 b[GRP], a[NT][GRP];
 #pragma unroll
-        for (int u = 0; u < 4; u++) b[u] = *reinterpret_cast<const bf16x8 *>(xrow + ((PW_DBG & 2) ? u : ks + u) * 16);
+        for (int u = 0; u < GRP; u++) b[u] = *reinterpret_cast<const bf16x8 *>(xrow + ((PW_DBG & 2) ? u : ks + u) * 16);
 #pragma unroll
         for (int t = 0; t < NT; t++)
 #pragma unroll
-            for (int u = 0; u < 4; u++) a[t][u] = *reinterpret_cast<const bf16x8 *>(wr[t] + ((PW_DBG & 1) ? u : ks + u) * 16);
+            for (int u = 0; u < GRP; u++) a[t][u] = *reinterpret_cast<const bf16x8 *>(wr[t] + ((PW_DBG & 1) ? u : ks + u) * 16);
         if (srow && !(PW_DBG & 4)) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) b[u] = scaled(b[u], ks + u);
+            for (int u = 0; u < GRP; u++) b[u] = scaled(b[u], ks + u);
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+        for (int u = 0; u < GRP; u++)
 #pragma unroll
             for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][u], b[u], acc[t], 0, 0, 0);
     }
@@ -143,6 +144,8 @@ __global__ __launch_bounds__(256) void pw_bf16_kernel(PwArgs p) {
     constexpr int TW = RES ? 32 + 4 : 32 + 8;                   // tile row stride in elements (16-byte padded: conflict-free 16-B accesses)
     typedef typename std::conditional<RES, float, __bf16>::type tile_t;
     __shared__ __attribute__((aligned(16))) tile_t tile[4][32][TW];
+    if (threadIdx.x < NT * 32) sbias[threadIdx.x] = bias_mine;
+    __syncthreads();
     const long mw0 = ((long)blockIdx.x * 4 + wave) * 32;
     int n0 = 0, oy0 = 0, ox0 = 0;
     if (RES && p.res_mode == 2) {
@@ -1446,6 +1449,9 @@ extern "C" int ptocr_pwconv_bf16(const void *d_x, const void *d_w, const float *
         } } while (0)
 #define PT_PW1(A) PT_PW_G(A, 1)
 #define PT_PW4(A) PT_PW_G(A, 4)
+    // (round 6, measured: groups of TWO slices for 64 <= Cin < 160 -- three waves per SIMD instead of two -- change nothing: 20.8 against
+    // 21.5 us for 96 -> 576 channels at 23x40; nor does a split-K form with four times the workgroups: these launches are not bound by the K
+    // loop's round trips or by wave slots)
     if (Cin >= 64) PT_ACT_SWITCH(act, PT_PW4); else PT_ACT_SWITCH(act, PT_PW1);
 #undef PT_PW1
 #undef PT_PW4
