@@ -248,7 +248,10 @@ __device__ __forceinline__ int uf_find(int *lab, int v) {
 // concurrent find -- parent read before that store, written after it -- would put a stale ancestor back)
 __device__ __forceinline__ int uf_root(const int *lab, int v) {
     while (v >= 0) {
-        const int p = __hip_atomic_load(&lab[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (round 6: a CACHED load -- workgroup scope.  The agent-scope form went past this XCD's L2 for every step of every chase; nothing here
+        // needs another XCD's latest store: the links were made by earlier launches, and a label a concurrent lane has already flattened or
+        // not yet flattened leads to the same root)
+        const int p = __hip_atomic_load(&lab[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (p == v) break;
         v = p;
     }
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(256) void ccl_merge_rows_kernel(const unsigned *__r
     const int y = ps.y_first + ((on ? idx : idx0) / d.WW + 1) * ps.row_step, wi = (on ? idx : idx0) % d.WW;
     const unsigned *bimg = bits + (long)img * d.H * d.WW;
     int *lab = labels + (long)img * d.HW;
-    __shared__ WaveItems items[4];
+    __shared__ WaveItems items[4][4];                           // [wave][kind of link]
     __shared__ unsigned s_cs[4][64], s_us[4][64];
     const unsigned *row = bimg + (long)y * d.WW, *up = row - d.WW;   // y >= row_step > 0
     WordCtx c = {0u, 0u, 0u, 0u}, u = {0u, 0u, 0u, 0u};
@@ -439,26 +442,30 @@ __global__ __launch_bounds__(256) void ccl_merge_rows_kernel(const unsigned *__r
         const unsigned unext = (wi + 1 < d.WW) ? (up[wi + 1] & 1u) : 0u;
         m_ne = fgbg & c.ends & ((u.w >> 1) | (unext << 31));
     }
-#pragma unroll
-    for (int kind = 0; kind < 4; kind++) {
-        const int G = wave_items_publish(items[wv], kind == 0 ? m_f : kind == 1 ? m_v : kind == 2 ? m_nw : m_ne);
-        for (int base = 0; base < G; base += 64) {
-            const int it = base + lane;
-            if (it < G) {
-                int L, i;
-                wave_item(items[wv], it, L, i);
-                const int idxL = idx0 + L;
-                const int yL = ps.y_first + (idxL / d.WW + 1) * ps.row_step, wL = idxL % d.WW, xL = wL * 32;
-                const unsigned *rowL = bimg + (long)yL * d.WW, *upL = rowL - d.WW;
-                const unsigned cs = s_cs[wv][L], us = s_us[wv][L];
-                const int cur = (cs >> i) & 1u ? yL * d.W + xL + i : yL * d.W + run_start(rowL, xL + i);      // run start of the current row at bit i
-                if (kind == 0) uf_union(lab, cur, FRAME);
-                else if (kind == 1) uf_union(lab, cur, (us >> i) & 1u ? (yL - 1) * d.W + xL + i : (yL - 1) * d.W + run_start(upL, xL + i));
-                else if (kind == 2) uf_union(lab, yL * d.W + xL + i, (yL - 1) * d.W + run_start(upL, xL + i - 1));
-                else uf_union(lab, cur, (yL - 1) * d.W + xL + i + 1);      // up(x) = 0, up(x + 1) = 1: a run start
+    // (round 6) ALL links of the wave's 64 words in ONE walk, one link per lane whatever its kind: the four kinds used to be four walks one
+    // after the other, each a union's chain of dependent loads and an atomic (~4 round trips) -- the unions commute, their order is free
+    const int G0 = wave_items_publish(items[wv][0], m_f), G1 = G0 + wave_items_publish(items[wv][1], m_v);
+    const int G2 = G1 + wave_items_publish(items[wv][2], m_nw), G = G2 + wave_items_publish(items[wv][3], m_ne);
+    for (int base = 0; base < G; base += 64) {
+        const int it = base + lane;
+        if (it < G) {
+            const int kind = it < G0 ? 0 : it < G1 ? 1 : it < G2 ? 2 : 3;
+            int L, i;
+            wave_item(items[wv][kind], it - (kind == 0 ? 0 : kind == 1 ? G0 : kind == 2 ? G1 : G2), L, i);
+            const int idxL = idx0 + L;
+            const int yL = ps.y_first + (idxL / d.WW + 1) * ps.row_step, wL = idxL % d.WW, xL = wL * 32;
+            const unsigned *rowL = bimg + (long)yL * d.WW, *upL = rowL - d.WW;
+            const unsigned cs = s_cs[wv][L], us = s_us[wv][L];
+            int a, b;
+            if (kind == 2) { a = yL * d.W + xL + i; b = (yL - 1) * d.W + run_start(upL, xL + i - 1); }
+            else {
+                a = (cs >> i) & 1u ? yL * d.W + xL + i : yL * d.W + run_start(rowL, xL + i);      // run start of the current row at bit i
+                if (kind == 0) b = FRAME;
+                else if (kind == 1) b = (us >> i) & 1u ? (yL - 1) * d.W + xL + i : (yL - 1) * d.W + run_start(upL, xL + i);
+                else b = (yL - 1) * d.W + xL + i + 1;              // up(x) = 0, up(x + 1) = 1: a run start
             }
+            uf_union(lab, a, b);
         }
-        wave_lds_sync();                                        // the item table is reused by the next kind
     }
 }
 
@@ -662,7 +669,7 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(const unsigned *__rest
     int *lab = labels + (long)img * d.HW;
     const unsigned starts = on ? word_ctx(row, wi, d).starts : 0u;
     __shared__ WaveItems items[4];
-    __shared__ int s_r0[4][64];
+    __shared__ int s_r0[4][64], s_rlast[4][64];                 // root of the run that starts at bit 0 of the word / at the word's LAST run start
     const int G = wave_items_publish(items[wv], starts);
     // one run start per lane (a word of a ragged edge holds a dozen, each a chase to its root)
     for (int base = 0; base < G; base += 64) {
@@ -675,6 +682,7 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(const unsigned *__rest
             const int r = uf_root(lab, s);
             lab[s] = r;
             if (i == 0) s_r0[wv][L] = r;
+            if ((items[wv].mask[L] >> i) <= 1u) s_rlast[wv][L] = r;     // no run start above bit i in this word
             if (r == s) {                                        // a border start: counted and listed per chunk
                 const long ch = (long)img * d.nchunks + s / CHUNK;
                 const int pos = atomicAdd(&chunk_cnt[ch], 1);
@@ -684,7 +692,16 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(const unsigned *__rest
     }
     wave_lds_sync();
     if (on) {
-        const int r0 = (starts & 1u) ? s_r0[wv][lane] : uf_root(lab, y * d.W + run_start(row, wi * 32));       // the run reaches in from the left
+        // The run that covers bit 0 of a word starts at the LAST run start of the nearest word to the left that has one (a row's first word
+        // always has: x = 0 starts a run, so the search never leaves the row) -- whose root the loop above has just found.  Round 6: taken
+        // from there (one ballot, one LDS read).  It used to be a walk to the left through the row's words, a dependent load per word, and
+        // then the label chase again -- for every background word of the map, i.e. most of them, all chasing the same few roots.  Only a
+        // word whose run reaches in from before the wave's first word still walks.
+        const unsigned long long has = __ballot(starts != 0u) & ((1ull << lane) - 1ull);
+        int r0;
+        if (starts & 1u) r0 = s_r0[wv][lane];
+        else if (has) r0 = s_rlast[wv][63 - __clzll((long long)has)];
+        else r0 = uf_root(lab, y * d.W + run_start(row, wi * 32));
         word_lab[((long)img * d.H + y) * d.WW + wi] = r0;
     }
 }
