@@ -128,12 +128,11 @@ __global__ __launch_bounds__(256) void asf_apply_kernel(const float *__restrict_
         const float score = sigm(sc[sub >> 2]);
         float *f = fuse + pix * (ASF_F * ASF_C) + sub * 16;
         const float *g = asf_src(src, fuse, pix, n, py, px, H, W, sub >> 2, sub & 3);
+        f32x4 t[4];                                             // all four loads before the first store: a load behind a store waits for its acknowledgement
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            f32x4 t = *reinterpret_cast<const f32x4 *>(g + 4 * k);
-            t *= score;
-            *reinterpret_cast<f32x4 *>(f + 4 * k) = t;
-        }
+        for (int k = 0; k < 4; k++) t[k] = *reinterpret_cast<const f32x4 *>(g + 4 * k);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { t[k] *= score; *reinterpret_cast<f32x4 *>(f + 4 * k) = t[k]; }
     }
 }
 
