@@ -50,7 +50,22 @@ __global__ __launch_bounds__(SP_THREADS, 1) void stem_pool_kernel(StemPoolArgs p
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.x_bytes, 0x00020000);
     const unsigned oob = 0x80000000u;
 
+    // Round 6: the weights sit in LDS as [k / 2][cout][k & 1] -- the two k of an MFMA step side by side.  A lane (c, kh) reads W[2 s + kh][c]:
+    // in the [k][64] layout of the packed tensor the kh = 0 and kh = 1 halves of the wave fell on the SAME 32 banks (a row is 64 floats),
+    // a two-way conflict on every weight read; here the 64 lanes read 64 consecutive floats.
+#ifndef STEM_W_PAIRS
+#define STEM_W_PAIRS 1
+#endif
+#if STEM_W_PAIRS
+    for (int i = tid; i < SP_K * 64 / 4; i += SP_THREADS) {
+        const f32x4 v = reinterpret_cast<const f32x4 *>(p.w)[i];
+        const int k = (4 * i) >> 6, co = (4 * i) & 63;
+        float *dst = Wl + (((k >> 1) * 64 + co) << 1) + (k & 1);
+        dst[0] = v[0]; dst[2] = v[1]; dst[4] = v[2]; dst[6] = v[3];
+    }
+#else
     for (int i = tid; i < SP_K * 64 / 4; i += SP_THREADS) reinterpret_cast<f32x4 *>(Wl)[i] = reinterpret_cast<const f32x4 *>(p.w)[i];
+#endif
     if (tid < 2 * SP_PR) Pb[(tid / SP_PR) * SP_PATCH + (tid % SP_PR) * SP_RS + SP_RS - 1] = 0.f;
 
     // tile index g -> image n, strip u, tile row t (consecutive g of a workgroup = one strip top to bottom, then its next strip)
@@ -62,6 +77,8 @@ __global__ __launch_bounds__(SP_THREADS, 1) void stem_pool_kernel(StemPoolArgs p
         oy0 = trow * SP_TH; ox0 = (s - n * p.strips) * SP_SX - 1;
     };
     f32x4 preg[SP_PIECES];
+    // (round 6, measured and dropped: the NCHW planes read as 16-byte pieces of four pixels instead of a dword at a time -- 4 loads per thread
+    // and tile instead of 15 -- ran 1.64 ms against 1.55: the pieces start at odd pixels, i.e. are never 16-byte aligned)
     auto gload = [&]() {                        // patch of the tile last decoded; outside the image -> zeros (range-checked load)
 #pragma unroll
         for (int r = 0; r < SP_PIECES; r++) {
@@ -94,7 +111,11 @@ __global__ __launch_bounds__(SP_THREADS, 1) void stem_pool_kernel(StemPoolArgs p
     };
 
     const int c = lane & 31, kh = lane >> 5;
-    const int wb = kh * 64 + c;                                  // weights: W[2s + kh][32 mt + c]
+#if STEM_W_PAIRS
+    const int wb = 2 * c + kh;                                   // weights: W[2s + kh][32 mt + c] at ((s * 64 + 32 mt + c) * 2 + kh)
+#else
+    const int wb = kh * 64 + c;
+#endif
     const int xb = (4 * wave) * SP_RS + 6 * c + kh;              // pixels: patch[2 (2w + nt) + ky][6c + 2s' + kh]
 
     f32x4 bias4[2][4];
@@ -129,7 +150,11 @@ __global__ __launch_bounds__(SP_THREADS, 1) void stem_pool_kernel(StemPoolArgs p
         for (int ky = 0; ky < 7; ky++) {
 #pragma unroll
             for (int s = 0; s < SP_KR / 2; s++) {
+#if STEM_W_PAIRS
+                const float a0 = wp[s * 128], a1 = wp[s * 128 + 64];
+#else
                 const float a0 = wp[(2 * s) * 64], a1 = wp[(2 * s) * 64 + 32];
+#endif
                 const float b0 = xp[2 * s], b1 = xp[2 * SP_RS + 2 * s];
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
@@ -137,7 +162,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void stem_pool_kernel(StemPoolArgs p
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
             }
             xp += SP_RS;
-            wp += SP_KR * 64;
+            wp += SP_KR * 64;                                    // (= (SP_KR / 2) * 128 in the paired layout)
         }
 
         // ---- epilogue.  Lane (c, kh) holds, for stem pixel (row 2w + nt, column c_ox0 + c), channels 32 mt + 8 g + 4 kh + {0..3}.
