@@ -55,7 +55,25 @@ __global__ __launch_bounds__(512, 1) void conv_pw64_kernel(Pw64Args p) {
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.x_bytes, 0x00020000);
     constexpr int COUT = NMT * 32;
 
+// Weights in LDS as [k / 2][cout][k & 1] (round 6): with the [k][COUT] layout the kh = 0 / kh = 1 halves of a wave read the same 32 banks
+// (COUT % 64 == 0), a two-way conflict on every weight read.  Measured on one box, alternating builds: conv_pw128 (in3, with the top-down
+// rows) 0.4375 -> 0.425 ms; conv_pw64 (in2) 0.834 -> 0.842 ms -- its two teams already keep the LDS pipe's turns apart -- so: off there.
+#ifndef PW64_W_PAIRS
+#define PW64_W_PAIRS 0
+#endif
+#ifndef PW128_W_PAIRS
+#define PW128_W_PAIRS 1
+#endif
+#if PW64_W_PAIRS
+    for (int i = threadIdx.x; i < PW_K * COUT / 4; i += 512) {
+        const f32x4 v = reinterpret_cast<const f32x4 *>(p.w)[i];
+        const int k = (4 * i) / COUT, co = (4 * i) - k * COUT;
+        float *dst = Wl + (((k >> 1) * COUT + co) << 1) + (k & 1);
+        dst[0] = v[0]; dst[2] = v[1]; dst[4] = v[2]; dst[6] = v[3];
+    }
+#else
     for (int i = threadIdx.x; i < PW_K * COUT / 4; i += 512) reinterpret_cast<f32x4 *>(Wl)[i] = reinterpret_cast<const f32x4 *>(p.w)[i];
+#endif
     if (threadIdx.x < COUT) Bl[threadIdx.x] = p.bias[threadIdx.x];
 
     // tile loader: 128 pixels x QPP float4 pieces, NPC per thread of the team; piece f = tid + 256 r -> pixel f / QPP, quad f % QPP
@@ -78,7 +96,11 @@ __global__ __launch_bounds__(512, 1) void conv_pw64_kernel(Pw64Args p) {
     };
 
     const int c = lane & 31, kh = lane >> 5;
+#if PW64_W_PAIRS
+    const float *wp = Wl + 2 * c + kh;                           // W[2s + kh][32 mt + c] at ((s COUT + 32 mt + c) 2 + kh)
+#else
     const float *wp = Wl + kh * COUT + c;                        // W[2s + kh][32 mt + c]
+#endif
     const float *xp = Xt + (32 * wave + c) * PW_RS + kh;         // X[32w + c][2s + kh]
 
     f32x16 acc[MTP];
@@ -88,13 +110,13 @@ __global__ __launch_bounds__(512, 1) void conv_pw64_kernel(Pw64Args p) {
         for (int a = 0; a < MTP; a++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][r] = 0.f;
-        const float *wq = wp + 32 * MTP * pass;
+        const float *wq = wp + (PW64_W_PAIRS ? 64 : 32) * MTP * pass;
 #pragma unroll 4
         for (int s = 0; s < PW_K / 2; s++) {
             const float b = xp[2 * s];
 #pragma unroll
             for (int mt = 0; mt < MTP; mt++)
-                if (MTP * pass + mt < NMT) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[(2 * s) * COUT + 32 * mt], b, acc[mt], 0, 0, 0);
+                if (MTP * pass + mt < NMT) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[PW64_W_PAIRS ? s * 2 * COUT + 64 * mt : (2 * s) * COUT + 32 * mt], b, acc[mt], 0, 0, 0);
         }
         if (p.res_up2 && !(PW64_DBG & 2)) {                      // + nearest-upsampled coarser map, after the ReLU: used one phase later
             const long m = (long)tile * PW_TM + 32 * wave + c;
@@ -192,7 +214,13 @@ __global__ __launch_bounds__(256, 1) void conv_pw128_kernel(Pw64Args p, int cout
 
     for (int i = tid; i < K * COUT / 4; i += 256) {
         const int k = i / (COUT / 4), c4 = i - k * (COUT / 4);
-        reinterpret_cast<f32x4 *>(Wl)[i] = *reinterpret_cast<const f32x4 *>(p.w + (long)k * cout_total + cbase + c4 * 4);
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(p.w + (long)k * cout_total + cbase + c4 * 4);
+#if PW128_W_PAIRS
+        float *dst = Wl + (((k >> 1) * COUT + c4 * 4) << 1) + (k & 1);
+        dst[0] = v[0]; dst[2] = v[1]; dst[4] = v[2]; dst[6] = v[3];
+#else
+        reinterpret_cast<f32x4 *>(Wl)[i] = v;
+#endif
     }
     if (tid < COUT) Bl[tid] = p.bias[cbase + tid];
 
@@ -214,7 +242,11 @@ __global__ __launch_bounds__(256, 1) void conv_pw128_kernel(Pw64Args p, int cout
     };
 
     const int c = lane & 31, kh = lane >> 5;
+#if PW128_W_PAIRS
+    const float *wp = Wl + 2 * c + kh;
+#else
     const float *wp = Wl + kh * COUT + c;                        // W[2s + kh][32 mt + c]
+#endif
     const float *xp = Xb + (32 * wave + c) * RS + kh;            // X[32w + c][2s + kh]
 
     int tile = first;                                            // host launches gridDim.x / nsplit <= ntiles
@@ -248,7 +280,7 @@ __global__ __launch_bounds__(256, 1) void conv_pw128_kernel(Pw64Args p, int cout
             const float b = xp[2 * s];
 #pragma unroll
             for (int mt = 0; mt < NMT; mt++)
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp[(2 * s) * COUT + 32 * mt], b, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp[PW128_W_PAIRS ? s * 2 * COUT + 64 * mt : (2 * s) * COUT + 32 * mt], b, acc[mt], 0, 0, 0);
         }
         if (live) {
             float *yp = p.y + m * p.out_ldc + p.out_coff + cbase;
