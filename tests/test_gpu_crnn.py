@@ -157,11 +157,13 @@ def test_lstm_split_placements_agree_and_the_fast_path_is_taken():
             wgs, fast, same = after[4] - before[4], after[3] - before[3], after[2] - before[2]
             assert wgs == 256
             if mode == 1:
-                assert fast == 256 and same == 1, "default placement: %d of 256 workgroups on the same-XCD exchange (calls counted %d)" % (fast, same)
+                # (the placement rests on round-robin dispatch over the XCDs, which nobody promises: what MUST hold is that the fast path is
+                # taken at all and counted consistently -- on every box so far it was all 256 workgroups)
+                assert fast > 0 and (same == 1) == (fast == 256), "default placement: %d of 256 workgroups on the same-XCD exchange (calls counted %d)" % (fast, same)
             elif mode == 0:
                 assert fast == 0 and same == 0
             else:
-                assert fast == 192 and same == 0, "mixed form: %d workgroups fast" % fast
+                assert 0 < fast <= 192 and same == 0, "mixed form: %d workgroups fast" % fast
     finally:
         L.ptocr_lstm_set_colocate(-1)
     assert torch.equal(outs[1], outs[0]) and torch.equal(outs[1], outs[3]), "the exchange forms differ"
