@@ -1213,11 +1213,19 @@ __global__ __launch_bounds__(512) void stem3x3s2_bf16_pair_kernel(const float *_
     for (int c = 0; c < 3; c++)
 #pragma unroll
         for (int ky = 0; ky < 3; ky++) {
+            // (round 6) no branch around a row outside the image: its loads go to the nearest row inside and their values are replaced by zeros
+            // (the products then add +0: the sums are what they were).  With `continue` every (channel, kernel row) was a basic block of its
+            // own -- load, wait, multiply, nine times over (160 us = 60 of arithmetic + 50 of loads + 58 of stores, none hidden); as
+            // straight-line code the compiler keeps two rows' loads in flight under the multiplies: 133.6 -> 120.6 us.  (All eighteen loads
+            // of a thread requested before the first multiply: 132.7 us -- five waves per SIMD instead of eight.)
             const int iy = 2 * oy - 1 + ky;
-            if ((unsigned)iy >= (unsigned)H) continue;            // block-uniform
-            const float *row = x + ((n * 3 + c) * H + ((STEM_DBG & 1) ? 0 : iy)) * (long)W;
-            const f32x4 q = (STEM_DBG & 2) ? f32x4{(float)t, (float)iy, 1.f, 2.f} : *reinterpret_cast<const f32x4 *>(row + 4 * tl);
-            const float left = (STEM_DBG & 2) ? 3.f : tl > 0 ? row[4 * tl - 1] : 0.f;
+            const bool row_in = (unsigned)iy < (unsigned)H;         // block-uniform
+            const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
+            const float *row = x + ((n * 3 + c) * H + ((STEM_DBG & 1) ? 0 : iyc)) * (long)W;
+            f32x4 q = (STEM_DBG & 2) ? f32x4{(float)t, (float)iy, 1.f, 2.f} : *reinterpret_cast<const f32x4 *>(row + 4 * tl);
+            float left = (STEM_DBG & 2) ? 3.f : row[4 * (tl > 0 ? tl : 1) - 1];
+            if (tl == 0) left = 0.f;
+            if (!row_in) { q = f32x4{0.f, 0.f, 0.f, 0.f}; left = 0.f; }
             const f32x2 *wr = reinterpret_cast<const f32x2 *>(sw + ((c * 3 + ky) * 3) * 16);
             const float va[3] = {left, q[0], q[1]}, vb[3] = {q[1], q[2], q[3]};
 #pragma unroll
