@@ -29,6 +29,9 @@
 #ifndef R4_UAUX
 #define R4_UAUX 0           // cache-policy bits of the weight-fragment loads (1 sc0, 2 nt, 3 both): every element is read once per workgroup and patch
 #endif
+#ifndef R4_YAUX
+#define R4_YAUX 0           // cache-policy bits of the output stores (gfx950: 1 sc0, 2 nt, 16 sc1)
+#endif
 #ifndef R4_DBG
 #define R4_DBG 0            // timing experiments only (PTOCR_EXTRA_HIPCC_FLAGS=-DR4_DBG=n): 1 no global stores, 2 no consumer, 4 no exchange writes,
                             // 8 no input transform, 16 no weight-fragment loads, 32 no raw refill, 128 no next-patch prefetch, 256 stamps 1 / 2 on the 100 MHz clock (tools/dbg/r4_clock.py)
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(R4_THREADS) void conv_wino4r_kernel(Wino4RArgs p) {
                         for (int k = 0; k < 4; k++) m[k] = fmaxf(hold[h2][k], fmaxf(v[2 * h2][k], v[2 * h2 + 1][k]));
                         if ((R4_DBG & 1) && m[0] != 123.456f) continue;
                         const unsigned rowo = c_oy + 2 * h2 < p.H ? po + (unsigned)h2 * y_row : oob;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, m), yr, rowo, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, m), yr, rowo, 0, R4_YAUX);
                     }
                 }
                 return;
@@ -481,11 +484,11 @@ __global__ __launch_bounds__(R4_THREADS) void conv_wino4r_kernel(Wino4RArgs p) {
                 if ((R4_DBG & 1) && v[0] != 123.456f) continue;
                 const unsigned rowo = c_oy + a < p.H ? yo + (unsigned)(a * up) * y_row : oob;      // rows below the image: dropped by the range check
                 if (MODE != 2) {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), yr, rowo, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), yr, rowo, 0, R4_YAUX);
                 } else {                                        // nearest upsample: up x up replicas
                     for (int dy = 0; dy < up; dy++)
                         for (int dx = 0; dx < up; dx++)
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), yr, rowo + (unsigned)dy * y_row + (unsigned)(dx * p.out_ldc * 4), 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), yr, rowo + (unsigned)dy * y_row + (unsigned)(dx * p.out_ldc * 4), 0, R4_YAUX);
                 }
             }
         };
