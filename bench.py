@@ -565,11 +565,26 @@ def run_det(args, rank, local, world, device):
     if bf16:
         fms = median([a.elapsed_time(b) for a, b in fwd_events])
         gbps = fwd_bytes / (fms * 1e-3) / 1e9
+        # the same forward with NOTHING else on the chip (a pass of its own after the timed region: no post-process stream beside it) --
+        # `frac` above prices the forward as the timed step runs it, with the previous batch's post-process taking bandwidth from it
+        alone_ev = []
+        with torch.no_grad():
+            for _ in range(30):
+                a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a0.record()
+                model(x)
+                a1.record()
+                alone_ev.append((a0, a1))
+        torch.cuda.synchronize()
+        fms_alone = median([a.elapsed_time(b) for a, b in alone_ev[10:]])
         roof = {"bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
                 "traffic": (_profile_json("mbv3s_bf16_traffic.json") or {}).get("hbm_bytes_per_forward"),
                 "traffic_source": "profiles/mbv3s_bf16_traffic.json (rocprofv3 --pmc passes of this command with --det-model mbv3s --dtype bf16): "
                                   "copied from the committed profile, NOT measured in this run",
                 "launches_per_forward": fwd_launches,
+                "forward_alone": {"ms": round(fms_alone, 4), "achieved": round(fwd_bytes / (fms_alone * 1e-3) / 1e9, 1),
+                                  "frac": round(fwd_bytes / (fms_alone * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                                  "pass": "20 forwards back to back after the timed region, no post-process in flight (HIP events on the launch stream)"},
                 "kernel": "whole bf16 forward (stem, 1x1 MFMA convs, expansion + depthwise, depthwise + SE pool, SE gate, 3x3 MFMA convs with the lateral / four-plane "
                           "gather inside, head tail): "
                           "bytes every launch reads + writes once (activations, weights; %.1f MB per forward of %d images) / median forward time "

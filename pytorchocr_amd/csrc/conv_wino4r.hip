@@ -30,7 +30,10 @@
 #define R4_UAUX 0           // cache-policy bits of the weight-fragment loads (1 sc0, 2 nt, 3 both): every element is read once per workgroup and patch
 #endif
 #ifndef R4_YAUX
-#define R4_YAUX 0           // cache-policy bits of the output stores (gfx950: 1 sc0, 2 nt, 16 sc1)
+#define R4_YAUX 2           // cache-policy bits of the output stores (gfx950: 1 sc0, 2 nt, 16 sc1).  Round 6: nt -- nothing in the launch reads the output
+                            // again, and streamed past the L2 it leaves the weights and halo rows there: det forward 14.26 -> 14.12 ms (two alternating
+                            // runs each, tools/dbg/det_fwd_ab.sh; sc1 / sc0+sc1: no change).  The same policy on the other conv kernels' stores LOSES
+                            // (stem 1393 -> 1462 us, 3x3/s2 570 -> 587, in3 lateral 371 -> 426, in2 lateral 725 -> 2149: their stores are pieces of lines)
 #endif
 #ifndef R4_DBG
 #define R4_DBG 0            // timing experiments only (PTOCR_EXTRA_HIPCC_FLAGS=-DR4_DBG=n): 1 no global stores, 2 no consumer, 4 no exchange writes,
