@@ -22,6 +22,7 @@ namespace ptocr {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -603,6 +604,9 @@ struct C3LatArgs {
     int td_ldc;
 };
 
+#ifndef C3L_DBG
+#define C3L_DBG 0          // timing experiments only: 1 no lateral phase, 2 no 3x3 MFMAs, 4 no exchange of the channel halves, 8 no global stores, 16 no prefetch loads
+#endif
 template <int ACT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_lat_bf16_kernel(C3LatArgs q, int tiles_x, int tiles_per_img, int total) {
     constexpr int NCS = 6, TH = 8, HC = NCS / 2;
@@ -706,6 +710,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (;;) {
         const int c_n = n, c_ty0 = ty0, c_tx0 = tx0;
         // ---- the lateral: 11 groups of 32 patch pixels x 3 blocks of 32 channels, one (group, block) unit per wave and round
+        if (!(C3L_DBG & 1))
         for (int u = wave; u < 11 * 3; u += 8) {
             const int g = u / 3, cb = u - g * 3;
             const int pix = 32 * g + r;                          // this lane's patch pixel (MFMA column)
@@ -718,27 +723,42 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const bool inside = pix < NPX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             // top-down pixel of (iy, ix): (iy >> 1, ix >> 1), relative to the staged region's origin ((ty0 >> 1) - 1, (tx0 >> 1) - 1)
             const int tpy = ((c_ty0 + py + 1) >> 1) - (c_ty0 >> 1), tpx = ((c_tx0 + px + 1) >> 1) - (c_tx0 >> 1);     // = (iy >> 1) - origin, for iy >= -1
-            const unsigned char *tdp = tdl + (tpy * TDW + tpx) * TDS;
-            if (pix < NPX) {
+            const unsigned char *tdp = tdl + (tpy * TDW + tpx) * TDS + (32 * cb + 4 * h) * 2;
+            // Round 6 (knock-outs: this phase was 86 of the launch's 197 us): straight-line code -- the eight LDS operands of the unit are
+            // requested together (clamped pixel: every lane reads), bias + ReLU + top-down add on float pairs, ONE conversion instruction per
+            // pair, the padding pixels cleared by a select on the packed result, only the store predicated.  The compiler had turned the
+            // per-element `inside ? ... : 0` into seventeen exec-mask branches per unit, each behind its own LDS wait.
 #pragma unroll
-                for (int qd = 0; qd < 4; qd++) {
-                    const int co = 32 * cb + 8 * qd + 4 * h;
-                    const f32x4 bias = *reinterpret_cast<const f32x4 *>(s_bl + co);
-                    const bf16x4 t4 = *reinterpret_cast<const bf16x4 *>(tdp + co * 2);
-                    bf16x4 o;
+            for (int qh = 0; qh < 2; qh++) {                     // (two channel quads at a time: all four in flight spilled three registers)
+                f32x4 bias[2];
+                bf16x4 t4[2];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) o[j] = inside ? (__bf16)(fmaxf(la[4 * qd + j] + bias[j], 0.f) + (float)t4[j]) : (__bf16)0.f;
-                    *reinterpret_cast<bf16x4 *>(patch + pix * STRIDE + co * 2) = o;
+                for (int k = 0; k < 2; k++) {
+                    bias[k] = *reinterpret_cast<const f32x4 *>(s_bl + 32 * cb + 8 * (2 * qh + k) + 4 * h);
+                    t4[k] = *reinterpret_cast<const bf16x4 *>(tdp + 16 * (2 * qh + k));
+                }
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const int qd = 2 * qh + k;
+                    f32x4 v = f32x4{la[4 * qd], la[4 * qd + 1], la[4 * qd + 2], la[4 * qd + 3]} + bias[k];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v[j] = fmaxf(v[j], 0.f);
+                    v += __builtin_convertvector(t4[k], f32x4);
+                    const bf16x4 o = __builtin_convertvector(v, bf16x4);
+                    u32x2 ow = __builtin_bit_cast(u32x2, o);
+                    ow[0] = inside ? ow[0] : 0u; ow[1] = inside ? ow[1] : 0u;
+                    if (pix < NPX) *reinterpret_cast<u32x2 *>(patch + pix * STRIDE + (32 * cb + 8 * qd + 4 * h) * 2) = ow;
                 }
             }
         }
         __syncthreads();
         const int next = tile + tstep;
         const bool has_next = next < tend;
-        if (has_next) { decode(next); gload(); }                 // in flight during this tile's MFMAs
+        if (has_next) { decode(next); if (!(C3L_DBG & 16)) gload(); }                 // in flight during this tile's MFMAs
 
         f32x16 acc[2];
         acc[0] = (f32x16)(0.f); acc[1] = (f32x16)(0.f);
+        if (!(C3L_DBG & 2))
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
             const int dy = tap / 3, dx = tap % 3;
@@ -767,15 +787,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 *reinterpret_cast<bf16x4 *>(ob + ((2 * rw + j) * C3_TW + r) * 32 + 8 * g + 4 * h) = o;
             }
         };
-        if (half) give(acc[0]); else give(acc[1]);
+        if (!(C3L_DBG & 4)) { if (half) give(acc[0]); else give(acc[1]); }
         __syncthreads();
-        if (half) finish(acc[1], 1); else finish(acc[0], 0);
+        if (!(C3L_DBG & 4)) { if (half) finish(acc[1], 1); else finish(acc[0], 0); }
+        else if (acc[0][0] == 123.f) ob[threadIdx.x] = (__bf16)acc[1][3];
         __syncthreads();
 #pragma unroll
         for (int w = 0; w < NWB; w++) {
             const int oy = c_ty0 + (wb_yx[w] >> 16), ox = c_tx0 + (wb_yx[w] & 0xffff);
             if (wb_src[w] < 0 || oy >= p.H || ox >= p.W) continue;
             const bf16x8 v = *reinterpret_cast<const bf16x8 *>(ob + wb_src[w]);
+            if ((C3L_DBG & 8) && v[0] != (__bf16)123.f) continue;
             __bf16 *dst = p.y + (((long)c_n * p.H * U + oy * U) * ((long)p.W * U) + ox * U) * p.out_ldc + p.out_coff + wb_part[w];
             for (int uy = 0; uy < U; uy++)
                 for (int ux = 0; ux < U; ux++) *reinterpret_cast<bf16x8 *>(dst + ((long)uy * p.W * U + ux) * p.out_ldc) = v;
@@ -1349,17 +1371,22 @@ __global__ __launch_bounds__(256) void head_tail_bf16_mfma_kernel(const __bf16 *
         for (int ks = 0; ks < 2; ks++)
 #pragma unroll
             for (int j = 0; j < 8; j++) {
+                // (round 6: every load issued, from a clamped index, and the padding selected afterwards -- as `cond ? w1[...] : 0` the compiler
+                // made each of the 144 weight / bias loads of this prologue a branch with its own wait: seventy round trips one after the other
+                // in front of a loop of nineteen iterations)
                 const int ci = 16 * ks + 8 * h + j;
-                af[ab][ks][j] = (__bf16)((c < HT_C && ci < HT_C) ? w1[(ab * HT_C + ci) * HT_C + c] : 0.f);
+                const float wv = w1[(ab * HT_C + (ci < HT_C ? ci : 0)) * HT_C + (c < HT_C ? c : 0)];
+                af[ab][ks][j] = (__bf16)((c < HT_C && ci < HT_C) ? wv : 0.f);
             }
     // this lane's mid channels: co = (i & 3) + 8 (i >> 2) + 4 h; pairs (i, i + 1) and (q, q + 1) share packed fp32 instructions
     f32x2 lb1[8], lw2[16][2];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        const int co = (i & 3) + 8 * (i >> 2) + 4 * h;
-        lb1[i >> 1][i & 1] = co < HT_C ? b1[co] : 0.f;
+        const int co = (i & 3) + 8 * (i >> 2) + 4 * h, coc = co < HT_C ? co : 0;
+        const float bv = b1[coc];
+        lb1[i >> 1][i & 1] = co < HT_C ? bv : 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; q++) lw2[i][q >> 1][q & 1] = co < HT_C ? w2[q * HT_C + co] : 0.f;
+        for (int q = 0; q < 4; q++) { const float wv = w2[q * HT_C + coc]; lw2[i][q >> 1][q & 1] = co < HT_C ? wv : 0.f; }
     }
     const long nwave = (long)gridDim.x * 4, wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     auto load = [&](long p0, bf16x8 &q0, bf16x8 &q1) {

@@ -97,15 +97,23 @@ __global__ __launch_bounds__(256) void se_fc_kernel(const float *__restrict__ pa
 // the same gate from TRANSPOSED weights (w1t f32[C][S], w2t f32[S][C]): a thread per output whose loads are coalesced across the
 // threads and independent of each other -- with the row-major layouts above a thread walks its own row (576 dependent strided
 // loads: 74 us for a 32 x 576 vector); this form takes a few microseconds
-__global__ __launch_bounds__(256) void se_fc_t_kernel(const float *__restrict__ partial, const float *__restrict__ w1t, const float *__restrict__ b1,
+template <int NT>                                              // threads per block: 256, or 1024 for the wide layers (C >= 256: more K slices per output)
+__global__ __launch_bounds__(NT) void se_fc_t_kernel(const float *__restrict__ partial, const float *__restrict__ w1t, const float *__restrict__ b1,
                                                       const float *__restrict__ w2t, const float *__restrict__ b2, float *__restrict__ scale,
                                                       int HW, int C, int S, int nblk) {
     const int n = blockIdx.x;
     __shared__ float mean[1024], mid[256];
-    for (int c = threadIdx.x; c < C; c += 256) {                 // block sums in their fixed order, eight loads in flight
+    for (int c = threadIdx.x; c < C; c += NT) {                  // block sums in their fixed order, sixteen loads in flight
         const float *pp = partial + (long)n * nblk * C + c;
         float s = 0.f;
         int b = 0;
+        for (; b + 15 < nblk; b += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = pp[(long)(b + u) * C];
+#pragma unroll
+            for (int u = 0; u < 16; u++) s += v[u];
+        }
         for (; b + 7 < nblk; b += 8) {
             float v[8];
 #pragma unroll
@@ -117,40 +125,69 @@ __global__ __launch_bounds__(256) void se_fc_t_kernel(const float *__restrict__ 
         mean[c] = s / (float)HW;
     }
     __syncthreads();
-    // latency, not bandwidth, is what these tiny products cost (one block per image, a handful of waves per CU): sixteen independent
-    // loads in flight per thread and round
-    for (int j = threadIdx.x; j < S; j += 256) {
-        float a[16];
+    // Latency, not bandwidth, is what these tiny products cost (one block per image, a handful of waves per CU).  Round 6: an output is
+    // split over K SLICES (thread = (output, slice), NT / outputs of them; the slices meet in LDS and are added in a fixed order) with
+    // sixteen independent loads in flight per thread: a 240 -> 64 product was fifteen dependent rounds of L2 loads for 64 busy threads,
+    // now four for 256 (se_fc_t_kernel 8-16 us -> see DESIGN 3.5).
+    __shared__ float red[NT];
+    {
+        const int KS = NT / S;                                       // (S <= 256 <= NT: host check)
+        const int jl = threadIdx.x % S, ks = threadIdx.x / S;
+        float a = 0.f;
+        if (ks < KS) {
+            float acc[16];
 #pragma unroll
-        for (int u = 0; u < 16; u++) a[u] = 0.f;
-        int c = 0;
-        for (; c + 15 < C; c += 16) {
+            for (int u = 0; u < 16; u++) acc[u] = 0.f;
+            int c = ks;
+            for (; c + 15 * KS < C; c += 16 * KS) {
 #pragma unroll
-            for (int u = 0; u < 16; u++) a[u] += w1t[(c + u) * S + j] * mean[c + u];
+                for (int u = 0; u < 16; u++) acc[u] += w1t[(c + u * KS) * S + jl] * mean[c + u * KS];
+            }
+            for (; c < C; c += KS) acc[0] += w1t[c * S + jl] * mean[c];
+            #pragma unroll
+            for (int u = 8; u > 0; u >>= 1)
+#pragma unroll
+                for (int v = 0; v < u; v++) acc[v] += acc[v + u];
+            a = acc[0];
         }
-        for (; c < C; c++) a[0] += w1t[c * S + j] * mean[c];
-#pragma unroll
-        for (int u = 8; u > 0; u >>= 1)
-#pragma unroll
-            for (int v = 0; v < u; v++) a[v] += a[v + u];
-        mid[j] = fmaxf(a[0] + b1[j], 0.f);
+        red[threadIdx.x] = a;
+        __syncthreads();
+        if ((int)threadIdx.x < S) {
+            float sum = 0.f;
+            for (int k = 0; k < KS; k++) sum += red[k * S + threadIdx.x];
+            mid[threadIdx.x] = fmaxf(sum + b1[threadIdx.x], 0.f);
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float a[16];
+    for (int c0 = 0; c0 < C; c0 += NT) {                        // gate channels [c0, c0 + nc)
+        const int nc = C - c0 < NT ? C - c0 : NT;
+        const int KS = NT / nc;
+        const int cl = threadIdx.x % nc, ks = threadIdx.x / nc;
+        float a = 0.f;
+        if (ks < KS) {
+            float acc[16];
 #pragma unroll
-        for (int u = 0; u < 16; u++) a[u] = 0.f;
-        int j = 0;
-        for (; j + 15 < S; j += 16) {
+            for (int u = 0; u < 16; u++) acc[u] = 0.f;
+            int j = ks;
+            for (; j + 15 * KS < S; j += 16 * KS) {
 #pragma unroll
-            for (int u = 0; u < 16; u++) a[u] += w2t[(j + u) * C + c] * mid[j + u];
+                for (int u = 0; u < 16; u++) acc[u] += w2t[(j + u * KS) * C + c0 + cl] * mid[j + u * KS];
+            }
+            for (; j < S; j += KS) acc[0] += w2t[j * C + c0 + cl] * mid[j];
+            #pragma unroll
+            for (int u = 8; u > 0; u >>= 1)
+#pragma unroll
+                for (int v = 0; v < u; v++) acc[v] += acc[v + u];
+            a = acc[0];
         }
-        for (; j < S; j++) a[0] += w2t[j * C + c] * mid[j];
-#pragma unroll
-        for (int u = 8; u > 0; u >>= 1)
-#pragma unroll
-            for (int v = 0; v < u; v++) a[v] += a[v + u];
-        scale[(long)n * C + c] = fminf(fmaxf(a[0] + b2[c] + 3.f, 0.f), 6.f) * (1.f / 6.f);       // hardsigmoid
+        __syncthreads();                                         // (red: the previous round's readers are done)
+        red[threadIdx.x] = a;
+        __syncthreads();
+        if ((int)threadIdx.x < nc) {
+            float sum = 0.f;
+            for (int k = 0; k < KS; k++) sum += red[k * nc + threadIdx.x];
+            scale[(long)n * C + c0 + threadIdx.x] = fminf(fmaxf(sum + b2[c0 + threadIdx.x] + 3.f, 0.f), 6.f) * (1.f / 6.f);       // hardsigmoid
+        }
     }
 }
 
@@ -332,7 +369,10 @@ extern "C" int ptocr_se_fc_t_f32(const float *d_partial, const float *d_w1t, con
                                  float *d_scale, int N, int HW, int C, int S, int nblk, void *stream) {
     PT_CHECK(d_partial && d_w1t && d_b1 && d_w2t && d_b2 && d_scale && C <= 1024 && S <= 256 && N >= 1 && HW >= 1 && nblk >= 1,
              "ptocr_se_fc_t_f32: bad arguments (C <= 1024, S <= 256)");
-    hipLaunchKernelGGL(se_fc_t_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, d_partial, d_w1t, d_b1, d_w2t, d_b2, d_scale, HW, C, S, nblk);
+    // (round 6: ONE block of 1024 threads per image from 64 channels on -- sixteen K slices per hidden unit at 240 -> 64, seven at 576 -> 144: a product is one or
+    // two rounds of loads -- instead of 256 threads, and instead of the split pair of launches for the wide layers)
+    if (C >= 64) hipLaunchKernelGGL(se_fc_t_kernel<1024>, dim3(N), dim3(1024), 0, (hipStream_t)stream, d_partial, d_w1t, d_b1, d_w2t, d_b2, d_scale, HW, C, S, nblk);
+    else hipLaunchKernelGGL(se_fc_t_kernel<256>, dim3(N), dim3(256), 0, (hipStream_t)stream, d_partial, d_w1t, d_b1, d_w2t, d_b2, d_scale, HW, C, S, nblk);
     return launch_ok("se_fc_t_kernel");
 }
 

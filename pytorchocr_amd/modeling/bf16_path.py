@@ -106,7 +106,7 @@ class _Se:
         self.w1t, self.w2t = _f(w1p.t().contiguous(), dev), _f(w2p.t().contiguous(), dev)      # [C][S], [S][C]: the gate kernel's coalesced form
 
 
-SE_SPLIT = os.environ.get("PTOCR_SE_SPLIT", "1") != "0"          # 0: one block per image for every SE gate
+SE_SPLIT = os.environ.get("PTOCR_SE_SPLIT", "0") != "0"          # 1: the wide gates (C >= 256) as the round-4 pair of split launches; default (round 6): one 1024-thread block per image for every gate
 SE_SPLIT_MIN_C = int(os.environ.get("PTOCR_SE_SPLIT_MIN_C", "256"))
 
 
