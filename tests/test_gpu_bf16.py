@@ -228,12 +228,15 @@ def test_stem_kernel_both_forms(hw):
 
 
 def test_se_gate_kernels_match_float64():
-    """hardsigmoid(fc2(relu(fc1(mean)))) from the per-block channel sums: the one-block-per-image kernel and the eight-blocks-per-image
-    pair used for wide layers, against float64"""
+    """hardsigmoid(fc2(relu(fc1(mean)))) from the per-block channel sums: the one-block-per-image kernel (every gate since round 6) and the
+    eight-blocks-per-image pair of round 4 (PTOCR_SE_SPLIT=1), against float64"""
     from pytorchocr_amd import _lib
     from pytorchocr_amd.modeling import bf16_path as bp
     torch.manual_seed(3)
-    for (n, c, s_, nblk, hw) in ((3, 576, 144, 23, 920), (2, 288, 72, 12, 3680), (5, 1024, 256, 7, 49), (1, 96, 24, 24, 3680)):
+    # (round 6: the single kernel splits every output over K slices and runs 1024 threads per image from 64 channels on, 256 below:
+    # the layer shapes of mbv3-small -- 16/8, 96/24, 240/64, 120/32, 144/40 -- and the limits C = 1024, S = 256 are all here)
+    for (n, c, s_, nblk, hw) in ((3, 576, 144, 23, 920), (2, 288, 72, 12, 3680), (5, 1024, 256, 7, 49), (1, 96, 24, 24, 3680),
+                                 (4, 16, 8, 24, 58880), (2, 240, 64, 23, 3680), (3, 120, 32, 16, 3680), (2, 144, 40, 23, 3680), (1, 56, 16, 3, 11)):
         partial = torch.randn(n, nblk, c) * 3
         w1, b1, w2, b2 = torch.randn(s_, c) * 0.1, torch.randn(s_) * 0.1, torch.randn(c, s_) * 0.1, torch.randn(c) * 0.1
         mean = partial.double().sum(1) / hw
