@@ -949,6 +949,9 @@ __device__ __forceinline__ int wt_slot(int *tag, int k) {
 //  * every other state ("generic" pixels: turns, ends, single pixels), ONE PIXEL PER LANE whatever word it sits in -- until round 3 a
 //    lane walked the pixels of its own word one after the other, so a ragged edge (twenty such pixels in a word, each a hundred
 //    dependent instructions and a look-up) kept one lane busy and sixty-three waiting: the stage's time on the scene checkpoint's maps.
+#ifndef BS_DBG
+#define BS_DBG 0            // timing experiments only (tools/dbg/bs_knock.sh): 1 no straight stretches (phase 1), 2 no generic pixels (phase 2)
+#endif
 __global__ __launch_bounds__(256) void border_states_kernel(const unsigned *__restrict__ bits, const int *__restrict__ labels,
                                                             const int *__restrict__ word_lab, const int *__restrict__ strip_totals,
                                                             Acc *__restrict__ acc, DbpostDims d, StageArgs2 sg) {
@@ -1047,7 +1050,7 @@ __global__ __launch_bounds__(256) void border_states_kernel(const unsigned *__re
         int f_key = -2, S = -3, kF = -1;                        // cached per lane: run of the current pixel -> surround, candidate
 #pragma unroll
         for (int side = 0; side < 2; side++) {
-            unsigned M = in_range ? (side ? straight_b : (above ? 0u : straight_t)) : 0u;
+            unsigned M = (in_range && !(BS_DBG & 1)) ? (side ? straight_b : (above ? 0u : straight_t)) : 0u;
             const int zy = side ? y + 1 : y - 1;
             const unsigned rw = side ? dn : up;
             const unsigned code = side ? ((0u << 26) | (4u << 29)) : ((4u << 26) | (0u << 29));        // s_out << 26 | s_in << 29
@@ -1073,7 +1076,7 @@ __global__ __launch_bounds__(256) void border_states_kernel(const unsigned *__re
         }
     }
     // ---- phase 2: the other states, one pixel per lane: pixels with a gap that starts after some other neighbour, or isolated pixels
-    const int G = s_pre[wv][64];
+    const int G = (BS_DBG & 2) ? 0 : s_pre[wv][64];
     for (int base = 0; __builtin_amdgcn_readfirstlane(base) < G; base += 64) {
         const int it = base + lane_t;
         const bool have = it < G;
