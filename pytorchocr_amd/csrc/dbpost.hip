@@ -1162,11 +1162,11 @@ __global__ __launch_bounds__(256) void border_states_kernel(const unsigned *__re
 // per-border stage limits the planner below shares with the stage kernels
 constexpr int W_MW = 1024;                // border width a wave takes (wider: the full-size pass)
 #ifndef PT_BAND_WORDS
-#define PT_BAND_WORDS 256
-#endif
+#define PT_BAND_WORDS 128         // (round 6, re-tuned after the quad role's re-cut, tools/dbg/post_ab_both.sh: 256 / 16 loads in flight 0.2198 ms per call on the stress
+#endif                            //  maps, 128 / 4: 0.2147, 128 / 8: 0.2157, 64: 0.238, 96: 0.226, 512: 0.224; 32 loads in flight 0.251; the scene maps do not care: 0.309-0.315)
 constexpr int BAND_WORDS = PT_BAND_WORDS;           // mask words per score band (two LDS planes of this size per wave)
 #ifndef PT_SCORE_UF
-#define PT_SCORE_UF 16
+#define PT_SCORE_UF 4
 #endif
 constexpr int SCORE_UF = PT_SCORE_UF;     // 16-byte map loads a lane of the score role keeps in flight
 // rows per score band of a border whose bounding box is bw wide
@@ -3392,9 +3392,10 @@ static int dbpost_alloc(ptocr_dbpost *h, int max_n, int max_h, int max_w) {
     DB_ALLOC(h->totals, sizeof(int) * max_n, false);
     DB_ALLOC(h->zeroed, sizeof(int) * 6 * max_n, true);
     DB_ALLOC(h->tickets, sizeof(int) * 4 * max_n, true);
-    // score bands: a border's mask is cut into bands of band_rows() >= BAND_WORDS / (2 pw) rows, so it has at most 2 bh pw / BAND_WORDS + 1
-    // <= max_h / 4 + 1 of them (pw <= 32 words: wider borders go to the full-size pass)
-    h->sc_cap = (long)MAX_CAND * (max_h / 4 + 2);
+    // score bands: a border's mask is cut into bands of band_rows() = BAND_WORDS / pw >= BAND_WORDS / 32 rows (pw <= 32 words: wider borders
+    // go to the full-size pass), so it has at most bh / (BAND_WORDS / 32) + 1 of them
+    static_assert(BAND_WORDS >= 32 && BAND_WORDS % 32 == 0, "a band holds at least one row of the widest border a wave takes");
+    h->sc_cap = (long)MAX_CAND * (max_h / (BAND_WORDS / 32) + 2);
     DB_ALLOC(h->sc_off, sizeof(int) * max_n * MAX_CAND, false);
     DB_ALLOC(h->sc_n, sizeof(int) * max_n, false);
     DB_ALLOC(h->sc_item, sizeof(int) * max_n * h->sc_cap, false);
