@@ -923,7 +923,7 @@ __device__ __forceinline__ int st_in(unsigned s) { return (int)(s >> 29); }
 // staging list of the border states: a record is (state word, candidate | length << 16) -- length > 0: a stretch of straight
 // horizontal states starting at that word, 0: one state; the records of an 8-row x 8-word tile lie behind each other in the tile's
 // fixed slice, their number in the tile's header word
-struct StageArgs2 { uint2 *rec; int *hdr; long cap; };
+struct StageArgs2 { uint2 *rec; int *hdr; long cap; int *tab; };     // tab: per tile, the wave's table of border_states_kernel as it stood at the end -- 64 candidates (-1: free slot), 64 state counts
 
 constexpr int STAGE_TILE = 8192;                // record slots per tile (a pixel has at most four gaps: no reservation, no overflow)
 
@@ -1150,8 +1150,13 @@ __global__ __launch_bounds__(256) void border_states_kernel(const unsigned *__re
     }
     wave_lds_sync();
     if (lane_t == 0) sg.hdr[(long)img * sg.cap / STAGE_TILE + tile] = tile_n;
-    // the wave's table goes to the borders' records: one lane per slot
+    // the wave's table goes to the borders' records: one lane per slot -- and, round 6, to the tile's slice of sg.tab: the scatter pass
+    // starts from these counts instead of adding them up again from the tile's records (a probing CAS and an LDS atomic per record)
     const int k = T.tag[lane_t];
+    if (tile_n) {                                               // (uniform; a tile without records is not read back)
+        int *tb = sg.tab + ((long)img * sg.cap / STAGE_TILE + tile) * (2 * WT_SLOTS);
+        tb[lane_t] = k; tb[WT_SLOTS + lane_t] = T.n[lane_t];
+    }
     if (k >= 0) {
         atomicAdd(reinterpret_cast<unsigned long long *>(&ac[k].nstates), (unsigned long long)(unsigned)T.n[lane_t] | ((unsigned long long)(unsigned)T.np[lane_t] << 32));
         atomicMin(&ac[k].xmin, T.x0[lane_t]); atomicMax(&ac[k].xmax, T.x1[lane_t]);
@@ -1230,13 +1235,10 @@ __global__ __launch_bounds__(256) void scatter_states_kernel(const int *__restri
     unsigned *pl = pool + (long)img * d.pool_cap;
     __shared__ int s_tag[4][WT_SLOTS], s_cnt[4][WT_SLOTS], s_base[4][WT_SLOTS];
     int *tag = s_tag[wv], *cnt = s_cnt[wv], *bs = s_base[wv];
-    tag[lane_t] = -1; cnt[lane_t] = 0;
-    wave_lds_sync();
-    for (int i = lane_t; i < count; i += 64) {
-        const uint2 e = rec[i];
-        const int k = (int)(e.y & 0xffffu), len = (int)(e.y >> 16);
-        const int slot = wt_slot(tag, k);
-        if (slot >= 0) atomicAdd(&cnt[slot], len ? len : 1);
+    {   // (round 6: the table border_states_kernel left for this tile -- candidate and state count per slot -- instead of pass 1's recount;
+        //  a border that found no room in it is not in it here either and takes the direct path below, as before)
+        const int *tb = sg.tab + ((long)img * sg.cap / STAGE_TILE + tile) * (2 * WT_SLOTS);
+        tag[lane_t] = tb[lane_t]; cnt[lane_t] = tb[WT_SLOTS + lane_t];
     }
     wave_lds_sync();
     {
@@ -3346,6 +3348,7 @@ struct ptocr_dbpost {
     int *sc_off; int *sc_n; int *sc_item; ScorePart *sc_part; long sc_cap; int *sc_done;     // score bands: plan, partial sums, tickets (border_wave_kernel)
     int *list; int *tie;          // per border: the hull role's ready word; score tie marker
     int epoch;                    // number of the current call (ready words of other calls are ignored); never 0
+    int *stage_tab;               // per tile: border_states_kernel's table (2 * WT_SLOTS ints), read by scatter_states_kernel
     uint2 *stage; int *stage_hdr; long stage_cap; // border states: staged records (a fixed slice per tile), record count per tile
 };
 
@@ -3416,6 +3419,7 @@ static int dbpost_alloc(ptocr_dbpost *h, int max_n, int max_h, int max_w) {
     h->stage_cap = ((long)cdiv(max_h, 8) * cdiv(max_w, 256) + cdiv(max_h, 8) + cdiv(max_w, 256) + 1) * STAGE_TILE;      // any H x W within the workspace: cdiv(H,8) cdiv(WW,8) tiles
     DB_ALLOC(h->stage, sizeof(uint2) * max_n * h->stage_cap, false);
     DB_ALLOC(h->stage_hdr, sizeof(int) * max_n * (h->stage_cap / STAGE_TILE), false);
+    DB_ALLOC(h->stage_tab, sizeof(int) * max_n * (h->stage_cap / STAGE_TILE) * 2 * WT_SLOTS, false);
     DB_ALLOC(h->hin, sizeof(F2) * (size_t)max_n * MAX_CAND * S_MH, true);          // candidate granules: tag 0 = no call's epoch (put_point)
     DB_ALLOC(h->mini, sizeof(float) * 8 * max_n * MAX_CAND, false);
     DB_ALLOC(h->results, sizeof(Result) * max_n * MAX_CAND, false);
@@ -3436,7 +3440,7 @@ extern "C" int ptocr_dbpost_destroy(ptocr_dbpost_t h) {
     if (!h) return 0;
     void *bufs[] = {h->bits, h->bits2, h->labels, h->word_lab, h->chunk_cnt, h->chunk_roots, h->totals, h->zeroed, h->tickets, h->cands, h->acc, h->pool, h->hin,
                     h->mini, h->results, h->src_wh, h->boxes, h->list, h->tie, h->stamps, h->sc_off, h->sc_n, h->sc_item, h->sc_part, h->sc_done,
-                    h->stage, h->stage_hdr};
+                    h->stage, h->stage_hdr, h->stage_tab};
     for (void *b : bufs) (void)dev_free(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -3623,6 +3627,7 @@ static void run_chain(ptocr_dbpost *h, const float *d_maps, const uint8_t *d_bit
     StageArgs2 sg;
     sg.rec = h->stage + (long)i0 * h->stage_cap;
     sg.hdr = h->stage_hdr + (long)i0 * (h->stage_cap / STAGE_TILE); sg.cap = h->stage_cap;
+    sg.tab = h->stage_tab + (long)i0 * (h->stage_cap / STAGE_TILE) * 2 * WT_SLOTS;
     // ONE enumeration of the border states (count + stage), offsets (+ the score plan), scatter
     hipLaunchKernelGGL(border_states_kernel, all_words, dim3(256), 0, s, bits, w_labels, w_word_lab, w_strip_totals, w_acc, d, sg);
     hipLaunchKernelGGL(pool_offsets_kernel, dim3(N), dim3(1024), 0, s, w_acc, w_totals, w_flags, d, h->sc_off + (long)i0 * MAX_CAND, h->sc_n + i0, h->sc_item + (long)i0 * h->sc_cap, h->sc_cap);
