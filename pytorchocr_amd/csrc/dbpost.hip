@@ -920,8 +920,8 @@ __device__ __forceinline__ int st_y(unsigned s) { return (int)((s >> 11) & 0x7ff
 __device__ __forceinline__ int st_out(unsigned s) { return (int)((s >> 26) & 7u); }
 __device__ __forceinline__ int st_in(unsigned s) { return (int)(s >> 29); }
 
-// staging list of the border states: a record is (state word, candidate | length << 16) -- length > 0: a stretch of straight
-// horizontal states starting at that word, 0: one state; the records of an 8-row x 8-word tile lie behind each other in the tile's
+// staging list of the border states: a record is (state word, candidate | table slot << 10 | length << 16) -- length > 0: a stretch of straight
+// horizontal states starting at that word, 0: one state; table slot: where the tile's wave booked the candidate (sg.tab); the records of an 8-row x 8-word tile lie behind each other in the tile's
 // fixed slice, their number in the tile's header word
 struct StageArgs2 { uint2 *rec; int *hdr; long cap; int *tab; };     // tab: per tile, the wave's table of border_states_kernel as it stood at the end -- 64 candidates (-1: free slot), 64 state counts
 
@@ -996,8 +996,12 @@ __global__ __launch_bounds__(256) void border_states_kernel(const unsigned *__re
     auto emit = [&](bool on, int k, unsigned state, int n, int np, int x0, int x1, int yy) {
         const unsigned long long bal = __ballot(on);
         if (on) {
-            rec[tile_n + __popcll(bal & ((1ull << lane_t) - 1))] = make_uint2(state, (unsigned)k | ((unsigned)(n > 1 || np < 0 ? n : 0) << 16));
             const int slot = wt_slot(T.tag, k);
+            // record: state word | candidate (10 bits) + its slot in the wave's table (6 bits; no slot: 0, which then holds another candidate)
+            // + stretch length (16 bits).  The scatter pass finds the border's cursor through the slot without probing.
+            static_assert(MAX_CAND <= 1024 && WT_SLOTS == 64, "record layout");
+            rec[tile_n + __popcll(bal & ((1ull << lane_t) - 1))] =
+                make_uint2(state, (unsigned)k | ((unsigned)(slot >= 0 ? slot : 0) << 10) | ((unsigned)(n > 1 || np < 0 ? n : 0) << 16));
             const int pts = np < 0 ? 0 : np;
             if (slot >= 0) {
                 atomicAdd(&T.n[slot], n); if (pts) atomicAdd(&T.np[slot], pts);
@@ -1251,13 +1255,10 @@ __global__ __launch_bounds__(256) void scatter_states_kernel(const int *__restri
     wave_lds_sync();
     for (int i = lane_t; i < count; i += 64) {
         const uint2 e = rec[i];
-        const int k = (int)(e.y & 0xffffu), len = (int)(e.y >> 16), n = len ? len : 1;
-        int slot = k & (WT_SLOTS - 1), pos = -1;
-        bool found = false;
-        for (int probe = 0; probe < WT_SLOTS; probe++) {         // (read-only now: the table is complete)
-            if (tag[slot] == k) { found = true; break; }
-            slot = (slot + 1) & (WT_SLOTS - 1);
-        }
+        const int k = (int)(e.y & 0x3ffu), len = (int)(e.y >> 16), n = len ? len : 1;
+        const int slot = (int)((e.y >> 10) & (WT_SLOTS - 1));     // (round 6: the slot travels in the record; a border without one finds another candidate there)
+        int pos = -1;
+        const bool found = tag[slot] == k;
         if (found) { if (bs[slot] >= 0) pos = bs[slot] + atomicAdd(&cnt[slot], n); }
         else { const int off = ac[k].off; if (off >= 0) pos = off + atomicAdd(&ac[k].cursor, n); }      // table was full (speckle): on its own
         if (pos >= 0) {
