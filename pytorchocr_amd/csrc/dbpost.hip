@@ -930,13 +930,21 @@ constexpr int STAGE_TILE = 8192;                // record slots per tile (a pixe
 // A wave's table of the borders it met (LDS): candidate -> slot by k & 63 with linear probing; what is booked there goes to the border's
 // record in global memory ONCE per wave (every direct booking is atomics on one line that all the waves of that border share).
 constexpr int WT_SLOTS = 64;
-struct WaveTable { int tag[WT_SLOTS], n[WT_SLOTS], np[WT_SLOTS], x0[WT_SLOTS], x1[WT_SLOTS], y0[WT_SLOTS], y1[WT_SLOTS]; };
+// (round 6: n = states | contour points << 16 of the tile's share -- one add per state instead of two; a tile holds < 2^14 states)
+struct WaveTable { int tag[WT_SLOTS], n[WT_SLOTS], x0[WT_SLOTS], x1[WT_SLOTS], y0[WT_SLOTS], y1[WT_SLOTS]; };
 // slot of candidate k (claiming a free one), or -1 when the table is full of other candidates (a tile of speckle: more than 64 borders)
 __device__ __forceinline__ int wt_slot(int *tag, int k) {
     int slot = k & (WT_SLOTS - 1);
     for (int probe = 0; probe < WT_SLOTS; probe++) {
-        const int t = atomicCAS(&tag[slot], -1, k);
-        if (t == -1 || t == k) return slot;
+        // (round 6: a look first -- a tag only ever goes from free to one candidate, so a slot seen with this candidate is this candidate's
+        // for good and a slot seen with another one never will be: the CAS is for free slots only, once per border and wave instead of
+        // once per state)
+        const int cur = *reinterpret_cast<volatile int *>(&tag[slot]);
+        if (cur == k) return slot;
+        if (cur == -1) {
+            const int t = atomicCAS(&tag[slot], -1, k);
+            if (t == -1 || t == k) return slot;
+        }
         slot = (slot + 1) & (WT_SLOTS - 1);
     }
     return -1;
@@ -989,7 +997,7 @@ __global__ __launch_bounds__(256) void border_states_kernel(const unsigned *__re
     __shared__ unsigned s_w[4][64];
     __shared__ int s_pre[4][65];                                // exclusive prefix of the words' generic-pixel counts
     WaveTable &T = tabs[wv];
-    T.tag[lane_t] = -1; T.n[lane_t] = 0; T.np[lane_t] = 0; T.x0[lane_t] = 0x7fffffff; T.x1[lane_t] = -1; T.y0[lane_t] = 0x7fffffff; T.y1[lane_t] = -1;
+    T.tag[lane_t] = -1; T.n[lane_t] = 0; T.x0[lane_t] = 0x7fffffff; T.x1[lane_t] = -1; T.y0[lane_t] = 0x7fffffff; T.y1[lane_t] = -1;
     uint2 *rec = sg.rec + (long)img * sg.cap + (long)tile * STAGE_TILE;
     int tile_n = 0;                                             // records of the tile so far (wave-uniform)
     // books a state (or a stretch of n states) of border k and stages its record; every lane of the wave calls it together
@@ -1004,7 +1012,7 @@ __global__ __launch_bounds__(256) void border_states_kernel(const unsigned *__re
                 make_uint2(state, (unsigned)k | ((unsigned)(slot >= 0 ? slot : 0) << 10) | ((unsigned)(n > 1 || np < 0 ? n : 0) << 16));
             const int pts = np < 0 ? 0 : np;
             if (slot >= 0) {
-                atomicAdd(&T.n[slot], n); if (pts) atomicAdd(&T.np[slot], pts);
+                atomicAdd(&T.n[slot], n | (pts << 16));
                 atomicMin(&T.x0[slot], x0); atomicMax(&T.x1[slot], x1); atomicMin(&T.y0[slot], yy); atomicMax(&T.y1[slot], yy);
             } else {                                            // table full (speckle): straight to the border's record
                 atomicAdd(reinterpret_cast<unsigned long long *>(&ac[k].nstates), (unsigned long long)(unsigned)n | ((unsigned long long)(unsigned)pts << 32));
@@ -1159,10 +1167,10 @@ __global__ __launch_bounds__(256) void border_states_kernel(const unsigned *__re
     const int k = T.tag[lane_t];
     if (tile_n) {                                               // (uniform; a tile without records is not read back)
         int *tb = sg.tab + ((long)img * sg.cap / STAGE_TILE + tile) * (2 * WT_SLOTS);
-        tb[lane_t] = k; tb[WT_SLOTS + lane_t] = T.n[lane_t];
+        tb[lane_t] = k; tb[WT_SLOTS + lane_t] = T.n[lane_t] & 0xffff;
     }
     if (k >= 0) {
-        atomicAdd(reinterpret_cast<unsigned long long *>(&ac[k].nstates), (unsigned long long)(unsigned)T.n[lane_t] | ((unsigned long long)(unsigned)T.np[lane_t] << 32));
+        atomicAdd(reinterpret_cast<unsigned long long *>(&ac[k].nstates), (unsigned long long)(unsigned)(T.n[lane_t] & 0xffff) | ((unsigned long long)(unsigned)(T.n[lane_t] >> 16) << 32));
         atomicMin(&ac[k].xmin, T.x0[lane_t]); atomicMax(&ac[k].xmax, T.x1[lane_t]);
         atomicMin(&ac[k].ymin, T.y0[lane_t]); atomicMax(&ac[k].ymax, T.y1[lane_t]);
     }
