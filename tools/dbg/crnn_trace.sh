@@ -1,22 +1,29 @@
-# GPU box: kernel trace of ONE CRNN step (512 lines 32x320): duration, workgroups, workgroup size
+#!/bin/bash
+# GPU box: per-LAUNCH durations of one det forward (forward only: --post-input none), in launch order, from a rocprofv3 kernel trace:
+# which layer each conv launch is and what it costs.  Output: gpurun_out/crnn_trace.txt
+R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-rm -rf $GRAFT_REPO_ROOT/gpurun_out/ct
-rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/ct -- python3 $GRAFT_REPO_ROOT/bench.py --workload crnn --steps 2 --warmup 1 --cpu-lines 0 > $GRAFT_REPO_ROOT/gpurun_out/ct.log 2>&1
-python3 - <<'PY'
-import csv, glob, os
-f = max(glob.glob(os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/ct/*/*kernel_trace.csv"), key=os.path.getmtime)
-rows = list(csv.DictReader(open(f)))
-rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "conv3x3_small_pool" in r["Kernel_Name"]]
-start = idx[-1]
+rm -rf $R/gpurun_out/crnn_trace
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/crnn_trace -- python3 $R/bench.py --steps 6 --warmup 3 --cpu-images 0 --cpu-lines 0 --workload crnn > $R/gpurun_out/crnn_trace.log 2>&1 || { tail -5 $R/gpurun_out/crnn_trace.log; exit 1; }
+cd $R
+python3 - <<'PY' > gpurun_out/crnn_trace.txt
+import csv, glob
+f = glob.glob("gpurun_out/crnn_trace/*/*kernel_trace.csv")[0]
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+rows = [r for r in rows if "ptocr" in r["Kernel_Name"]]
+# one forward = from a stem_pool launch to the next
+starts = [i for i, r in enumerate(rows) if "conv3x3_small_pool16" in r["Kernel_Name"]]
+a, b = starts[-3], starts[-2]
+t0 = int(rows[a]["Start_Timestamp"])
+prev_end = t0
 tot = 0
-for r in rows[start:]:
-    n = r["Kernel_Name"].split("(")[0].replace("void ptocr::", "").replace("ptocr::", "")[:46]
-    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    tot += d
-    wg = int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
-    nb = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) // wg
-    print("%-48s %8.1f us  wgs %7d x %4d thr  lds %6s" % (n, d, nb, wg, r["LDS_Block_Size"]))
-    if "ctc_combine" in n: break
-print("sum %.1f us" % tot)
+for r in rows[a:b]:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    g = (r.get("Grid_Size_X") or r.get("Grid_Size") or "?")
+    print("%9.1f us  +gap %6.1f  dur %8.1f us  grid %-8s %s" % ((s - t0) / 1e3, (s - prev_end) / 1e3, (e - s) / 1e3, g, r["Kernel_Name"].split("(")[0][-60:]))
+    prev_end = e
+    tot += e - s
+print("forward: %.1f us of kernels, %.1f us first start to last end" % (tot / 1e3, (prev_end - t0) / 1e3))
 PY
+cat gpurun_out/crnn_trace.txt
+rm -rf gpurun_out/crnn_trace

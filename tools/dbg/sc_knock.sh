@@ -8,5 +8,5 @@ for v in ${VARIANTS:-0 1 2 4 7}; do
   cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/sck
   PTOCR_EXTRA_HIPCC_FLAGS="-DSC_DBG=$v" rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/sck -- python3 $R/tools/bench_post.py 10 > /tmp/sck.log 2>&1
   cd $R
-  echo "SC_DBG=$v: $(grep border_wave /tmp/sck/*/*kernel_stats.csv | awk -F, '{print $4}') ns"
+  echo "SC_DBG=$v: $(grep border_stage /tmp/sck/*/*kernel_stats.csv | awk -F, '{print $4}') ns"
 done
